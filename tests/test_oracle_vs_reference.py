@@ -1,0 +1,207 @@
+"""Pin the oracle (oracle/dlesm_oracle.c) before anything trusts it.
+
+Bit-exact against tests/golden/ref_*.json -- outputs of the REAL reference run in
+the build container by oracle/make_golden.py -- and against the reference's own
+known-answer tests (test_halos / test_gsum / test_reduction), restated in
+tests/ref_cases.py.  CPU only.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_cases as R
+from conftest import load_golden
+
+
+# --------------------------------------------------------------------------- decomposition
+@pytest.mark.parametrize("case", load_golden("ref_decomp")["cases"],
+                         ids=lambda c: f"{c['domainx']}x{c['domainy']}n{c['ndomains']}")
+def test_decompose_matches_reference(case):
+    d, subs = O.decompose(case["domainx"], case["domainy"], case["ndomains"])
+    assert [d.global_nx, d.global_ny, d.nx, d.ny, d.ndomains, d.max_width, d.max_height] == \
+           [case["global_nx"], case["global_ny"], case["nx"], case["ny"], case["ndom_out"],
+            case["max_width"], case["max_height"]]
+    got = [s.glob.as6() + s.internal.as6() for s in subs]
+    assert got == case["subdomains"]
+
+
+# --------------------------------------------------------------------------- extents + bounds
+def test_extents_and_bounds_match_reference():
+    cases = load_golden("ref_bounds")["cases"]
+    assert len(cases) == 700
+    n_abort = 0
+    for c in cases:
+        d, subs = O.decompose(c["nx"], c["ny"], 1)
+        sub = subs[0]
+        gnx, gny = O.grid_extents(sub.glob.nx, sub.glob.ny, c["alignment"])
+        assert [gnx, gny, d.global_nx, d.global_ny] == c["grid"], c
+        rc, internal, whole = O.field_bounds(c["ptype"], c["offset"], c["bcx"], c["bcy"],
+                                             sub.internal, gnx, gny)
+        assert bool(rc) == c["abort"], c
+        if c["abort"]:
+            n_abort += 1
+            continue
+        assert internal.as6() == c["internal"], c
+        assert whole.as6() == c["whole"], c
+        assert c["shape"] == [gnx, gny]           # every field is allocated grid%nx x grid%ny
+    assert n_abort == 180
+
+
+def test_alignment_formula_large():
+    # A=64 -> N=4096: 4160, 8192: 8256, 16384: 16448 ; A=1: N+3
+    for n, want in [(4096, 4160), (8192, 8256), (16384, 16448)]:
+        assert O.grid_extents(n + 2, n + 2, 64) == (want, n + 3)
+        assert O.grid_extents(n + 2, n + 2, None) == (n + 3, n + 3)
+
+
+# --------------------------------------------------------------------------- config-1 plumbing
+def test_model_and_gather_match_reference():
+    g = load_golden("ref_model")
+    assert g["example_4x10"] == {"U": 40.0, "V": 40.0, "T": 40.0, "F": 40.0}
+    for m in g["model"]:
+        d, subs = O.decompose(m["nx"], m["ny"], 1)
+        gnx, gny = O.grid_extents(subs[0].glob.nx, subs[0].glob.ny)
+        rc, internal, _ = O.field_bounds(R.GO_T, R.OFFSET_NE, R.BC_EXTERNAL, R.BC_EXTERNAL,
+                                         subs[0].internal, gnx, gny)
+        assert rc == 0 and [gnx, gny] == m["grid"][:2]
+        assert internal.as6()[:4] == m["internal"]
+        f = np.full((gny, gnx), m["fill"])
+        cs = O.lib().orc_checksum(f, gnx, *internal.as6()[:4])
+        assert cs == m["checksum"]
+        xt, yt = R.t_coords(1, 1, 2, 2, gnx, gny)
+        assert [xt[0], xt[1], xt[-1]] == m["xt"] and [yt[0], yt[1], yt[-1]] == m["yt"]
+    for m in g["gather"]:
+        d, subs = O.decompose(m["nx"], m["ny"], 1)
+        gnx, gny = O.grid_extents(subs[0].glob.nx, subs[0].glob.ny)
+        glob = R.unique_global(m["nx"], m["ny"])
+        loc = np.zeros((gny, gnx))
+        O.lib().orc_scatter(glob, m["nx"], subs[0], loc, gnx)
+        assert [loc[0, 0], loc[1, 1], loc[m["ny"], m["nx"]], loc[m["ny"] + 1, m["nx"] + 1]] == m["corner"]
+        assert O.lib().orc_checksum(loc, gnx, 2, m["nx"] + 1, 2, m["ny"] + 1) == m["checksum"]
+        back = O.gather_all([loc], [gnx], d, subs)
+        assert back.shape == tuple(m["gather_shape"][::-1])
+        assert np.array_equal(back, glob) and m["gather_mismatch"] == 0
+
+
+# --------------------------------------------------------------------------- message tables
+def _setup(nx, ny, nranks):
+    d, subs = O.decompose(nx, ny, nranks)
+    comms = [O.map_comms(d, subs, nranks, r + 1) for r in range(nranks)]
+    ext = [O.grid_extents(s.glob.nx, s.glob.ny) for s in subs]
+    return d, subs, comms, ext
+
+
+def test_map_comms_matches_survey_probe():
+    g = load_golden("survey_probe_mapcomms")
+    d, subs, comms, ext = _setup(g["domainx"], g["domainy"], g["nranks"])
+    assert (d.nx, d.ny) == (g["ntilex"], g["ntiley"]) and ext[0] == (g["grid_nx"], g["grid_ny"])
+    c1 = comms[0]
+    assert c1.nsend == g["rank1"]["nsend"] and c1.nrecv == g["rank1"]["nrecv"]
+    for got, want in zip(c1.sends(), g["rank1"]["sends"]):
+        assert {k: got[k] for k in want} == want
+    for got, want in zip(c1.recvs(), g["rank1"]["recvs"]):
+        assert {k: got[k] for k in want} == want
+    c4 = comms[3]
+    assert c4.nsend == 5 and c4.nrecv == 5
+    assert [[s["nx"], s["ny"]] for s in c4.sends()] == g["rank4"]["send_shapes"]
+
+
+@pytest.mark.parametrize("nx,ny,nranks", R.HALO_CASES + [(16, 32, 8), (13, 13, 9), (64, 64, 16)])
+def test_map_comms_is_self_consistent(nx, ny, nranks):
+    """every send has exactly one matching receive of the same size (tag = dir) and lands on a
+    halo cell of the receiver; sources are internal cells of the sender"""
+    d, subs, comms, ext = _setup(nx, ny, nranks)
+    for r, c in enumerate(comms):
+        for s in c.sends():
+            peer = comms[s["dest"]]
+            m = [q for q in peer.recvs() if q["src"] == r and q["dir"] == s["dir"]]
+            assert len(m) == 1
+            q = m[0]
+            assert (q["nx"], q["ny"]) == (s["nx"], s["ny"])
+            assert (q["ides"], q["jdes"]) == (s["ides"], s["jdes"])
+            it = subs[r].internal
+            assert it.xstart <= s["isrc"] and s["isrc"] + s["nx"] - 1 <= it.xstop
+            assert it.ystart <= s["jsrc"] and s["jsrc"] + s["ny"] - 1 <= it.ystop
+            ot = subs[s["dest"]].internal
+            inside_x = ot.xstart <= q["ides"] <= ot.xstop
+            inside_y = ot.ystart <= q["jdes"] <= ot.ystop
+            assert not (inside_x and inside_y)
+
+
+# --------------------------------------------------------------------------- reference's dist_mem tests
+@pytest.mark.parametrize("nx,ny,nranks", R.HALO_CASES + [(16, 32, 8), (13, 13, 9)])
+def test_halo_exchange_known_answer(nx, ny, nranks):
+    """tests/dist_mem/test_halos.f90 on the oracle, for U, V, T and F fields"""
+    d, subs, comms, ext = _setup(nx, ny, nranks)
+    for ptype in (R.GO_T, R.GO_U, R.GO_V, R.GO_F):
+        fields, before = [], []
+        for r, s in enumerate(subs):
+            it = s.internal.as6()[:4]              # NE + external: every type = subdomain internal
+            f = R.init_field_hill(ptype, ext[r][0], ext[r][1], it, s.glob.xstart, s.glob.ystart)
+            fields.append(f)
+            before.append(f.copy())
+        assert O.exchange_all(fields, [e[0] for e in ext], comms) == 0
+        for r, s in enumerate(subs):
+            it = s.internal.as6()[:4]
+            bad = R.check_hill_halos(fields[r], ptype, it, s.glob.as6()[:4], nx, ny, corners=True)
+            assert not bad, (r, ptype, bad[:3])
+            # internal cells untouched
+            xs, xe, ys, ye = it
+            assert np.array_equal(fields[r][ys - 1:ye, xs - 1:xe], before[r][ys - 1:ye, xs - 1:xe])
+            # cells outside the depth-1 ring untouched
+            assert np.array_equal(fields[r][ye + 1:, :], before[r][ye + 1:, :])
+            assert np.array_equal(fields[r][:, xe + 1:], before[r][:, xe + 1:])
+
+
+@pytest.mark.parametrize("nx,ny,nranks", R.GSUM_CASES)
+def test_gsum_known_answer(nx, ny, nranks):
+    """tests/dist_mem/test_gsum.f90: global checksum == jpiglo*jpjglo"""
+    d, subs, comms, ext = _setup(nx, ny, nranks)
+    total = 0.0
+    for r, s in enumerate(subs):
+        it = s.internal.as6()[:4]
+        f = R.gsum_field(ext[r][0], ext[r][1], it)
+        total += O.lib().orc_checksum(f, ext[r][0], *it)
+    assert total == float(nx * ny)
+
+
+@pytest.mark.parametrize("nx,ny,nranks", R.REDUCTION_CASES)
+def test_scatter_gather_known_answer(nx, ny, nranks):
+    """tests/dist_mem/test_reduction.f90: scatter is index-exact, gather(value+1) round-trips"""
+    d, subs, comms, ext = _setup(nx, ny, nranks)
+    glob = R.unique_global(nx, ny)
+    fields = []
+    for r, s in enumerate(subs):
+        f = np.zeros((ext[r][1], ext[r][0]))
+        O.lib().orc_scatter(glob, nx, s, f, ext[r][0])
+        xs, xe, ys, ye = s.internal.as6()[:4]
+        want = glob[s.glob.ystart - 1:s.glob.ystop, s.glob.xstart - 1:s.glob.xstop]
+        assert np.array_equal(f[ys - 1:ye, xs - 1:xe], want)
+        f[ys - 1:ye, xs - 1:xe] += 1.0
+        fields.append(f)
+    back = O.gather_all(fields, [e[0] for e in ext], d, subs)
+    assert np.array_equal(back, glob + 1.0)
+
+
+# --------------------------------------------------------------------------- stencil self-checks
+def test_hash_init_twin():
+    f = O.hash_field(20261004, 9, 12, 5, 7, 2, 8, 2, 6)
+    for (j, i) in [(2, 2), (6, 8), (3, 5)]:
+        assert f[j - 1, i - 1] == O.lib().orc_hash_u01(20261004, 5 + i - 1, 7 + j - 1)
+    assert f[0, 0] == 0.0 and 0.0 <= f.min() and f.max() < 1.0
+
+
+def test_jacobi5_against_numpy():
+    """PARITY UNPINNED by the reference (it has no stencil); independent numpy evaluation"""
+    n, ld = 37, 44
+    rng = np.random.default_rng(1)
+    a = rng.random((n + 3, ld))
+    out = np.full_like(a, -7.0)
+    O.jacobi5(a, out, ld, 2, n + 1, 2, n + 1)
+    want = 0.25 * ((a[1:n + 1, 0:n] + a[1:n + 1, 2:n + 2]) + (a[0:n, 1:n + 1] + a[2:n + 2, 1:n + 1]))
+    assert np.array_equal(out[1:n + 1, 1:n + 1], want)
+    out[1:n + 1, 1:n + 1] = -7.0
+    assert np.all(out == -7.0)                    # nothing outside the box is written
+    out2 = np.full_like(a, -7.0)
+    O.jacobi5(a, out2, ld, 2, n + 1, 2, n + 1, threads=3)
+    assert np.array_equal(out2[1:n + 1, 1:n + 1], want)
