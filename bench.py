@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fp64 5-point Jacobi over a dl_esm_inf r2d_field (+ RCCL halo exchange
+when N > 1), BASELINE.json metric "stencil Mcells/s + achieved HBM GB/s, 16384^2 fp64 grid".
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--tile 16384] [--alignment 64]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch: (halo exchange +) one Jacobi sweep of the
+per-GPU tile.  Weak scaling: every GPU owns a tile x tile T-point field; the global domain is
+(tile*P) x (tile*Q) with P x Q what go_decompose picks for N ranks.  Inputs are generated on
+the device (counter-based hash of the global cell index) before the timed region starts.
+
+Prints ONE JSON line (rank 0).  The CPU oracle is used only for the `cpu_baseline` leg.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_CELL = 16            # Jacobi-5: 8 B compulsory read + 8 B write
+SEED = 20261004
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--tile", type=int, default=16384, help="per-GPU interior is tile x tile")
+    ap.add_argument("--alignment", type=int, default=64, help="DL_ESM_ALIGNMENT for the run")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--rows", type=int, default=None, help="tuning: rows per strip")
+    ap.add_argument("--variant", type=int, default=None, help="tuning: kernel variant bits")
+    return ap.parse_args()
+
+
+def cpu_baseline(host_in, ld, box, budget_s):
+    """time the ORACLE (oracle/dlesm_oracle.c, the GOcean-form CPU loops) on this box's host
+    cores, on a bounded sample: whole-tile sweeps until the budget is used"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    xs, xe, ys, ye = box
+    cells = (xe - xs + 1) * (ye - ys + 1)
+    out = np.zeros_like(host_in)
+    threads = max(1, min(O.lib().orc_max_threads(), os.cpu_count() or 1))
+    res = {}
+    for label, nthr, share in (("all", threads, 0.6), ("one", 1, 0.4)):
+        O.jacobi5(host_in, out, ld, xs, xe, ys, ye, threads=nthr)       # first touch / warm
+        t0, sweeps = time.perf_counter(), 0
+        while True:
+            O.jacobi5(host_in, out, ld, xs, xe, ys, ye, threads=nthr)
+            sweeps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s * share or sweeps >= 50:
+                break
+        res[label] = (cells * sweeps / dt / 1e6, sweeps, dt)
+    return {
+        "value": round(res["all"][0], 1), "unit": "Mcells/s", "cores": threads, "kind": "port",
+        "single_core_value": round(res["one"][0], 1),
+        "sample": f"oracle orc_jacobi5 (C, gcc -O3, GOcean kernel form) on the same "
+                  f"{xe - xs + 1}x{ye - ys + 1} tile: {res['all'][1]} sweeps in {res['all'][2]:.1f}s "
+                  f"with {threads} OpenMP threads, {res['one'][1]} sweeps in {res['one'][2]:.1f}s on 1 core",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+
+    import dl_esm_inf_amd as D
+    L = D._cabi.lib()
+    D._cabi.check(L.dlesm_init(local))
+    if args.rows is not None:
+        L.dlesm_set_tuning(b"j5_rows", args.rows)
+    if args.variant is not None:
+        L.dlesm_set_tuning(b"j5_variant", args.variant)
+    os.environ["DL_ESM_ALIGNMENT"] = str(args.alignment)
+    D.parallel_init(rank, world)
+
+    # global domain: what go_decompose will cut into `world` tiles of tile x tile
+    small = int(math.isqrt(world))
+    while world % small:
+        small -= 1
+    P, Q = small, world // small
+    grid = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
+    grid.decompose(args.tile * P, args.tile * Q)
+    assert (grid.decomp.nx, grid.decomp.ny) == (P, Q)
+    D.grid_init(grid, 1.0, 1.0)
+    a, b = D.r2d_field(grid, D.GO_T_POINTS), D.r2d_field(grid, D.GO_T_POINTS)
+    it = a.internal
+    assert it.nx == args.tile and it.ny == args.tile
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        D.psy.hash_init(a, SEED)             # whole region incl. the fixed boundary ring
+        D.copy_field(a, b)                   # same ring in both ping-pong buffers
+        a.halo_exchange(1, stream=stream)    # `in` starts with valid halos
+    stream.synchronize()
+
+    step = D.psy.invoke_jacobi5_dm if world > 1 else D.psy.invoke_jacobi5
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step(b, a, stream=stream)
+            a, b = b, a
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        e0.record(stream)
+        for _ in range(args.steps):
+            step(b, a, stream=stream)
+            a, b = b, a
+        e1.record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+
+    if world > 1:
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(tt[0]), float(tt[1])
+    checksum = D.field_checksum(a)
+
+    cells_step = args.tile * args.tile * world
+    value = cells_step * args.steps / wall / 1e6
+    launch_ms = ev_ms / args.steps
+    achieved = BYTES_PER_CELL * args.tile * args.tile / (launch_ms * 1e-3) / 1e9   # per GPU, GB/s
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-measured HBM bytes per launch
+    if os.path.exists(tj):
+        try:
+            rec = json.load(open(tj))
+            key = f"{args.tile}x{args.tile}/A{args.alignment}"
+            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "stencil Mcells/s", "value": round(value, 1), "unit": "Mcells/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"jacobi5 {args.tile}x{args.tile} fp64 T-field per GPU "
+                               "(BASELINE configs[2]; NE offset, external BCs, fixed boundary ring)",
+                   "tile": args.tile, "decomposition": f"{P}x{Q}",
+                   "global": [args.tile * P, args.tile * Q], "DL_ESM_ALIGNMENT": args.alignment,
+                   "ld": grid.nx, "halo_exchange": "rccl send/recv, overlapped" if world > 1 else "none (1 tile)"},
+        "hbm_gbs_per_gpu": round(achieved, 1),
+        "checksum": checksum,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "jacobi5_march", "launch_ms": round(launch_ms, 5),
+                     "algorithmic_bytes_per_launch": BYTES_PER_CELL * args.tile * args.tile},
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        host = a.get_data()
+        out["cpu_baseline"] = cpu_baseline(host, grid.nx, it.box(), args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        D.parallel_finalise()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+"""ctypes binding of include/dlesm_hip.h (libdlesm_hip.so).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C dl_esm_inf_amd/csrc`.
+There is no fallback: if it is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libdlesm_hip.so")
+MAXCOMM = 16
+UNIQUE_ID_BYTES = 128
+
+OK, EINVAL, ENODEV, EHIP, ERCCL, EABORT, ECOMMS = 0, -1, -2, -3, -4, -5, -12
+
+
+class DlesmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dlesm error {code}: {msg}")
+        self.code = code
+
+
+class GoceanStop(DlesmError):
+    """the reference calls gocean_stop() (fatal) for this input"""
+
+
+class Region(C.Structure):
+    """region_mod.f90:7-12"""
+    _fields_ = [(n, C.c_int) for n in ("nx", "ny", "xstart", "xstop", "ystart", "ystop")]
+
+    def as6(self):
+        return [self.xstart, self.xstop, self.ystart, self.ystop, self.nx, self.ny]
+
+    def box(self):
+        return (self.xstart, self.xstop, self.ystart, self.ystop)
+
+    def __repr__(self):
+        return f"Region(x={self.xstart}:{self.xstop}, y={self.ystart}:{self.ystop}, n={self.nx}x{self.ny})"
+
+
+class Subdomain(C.Structure):
+    """decomposition_mod.f90:44-50 (`global` is a Python keyword, hence glob)"""
+    _fields_ = [("glob", Region), ("internal", Region)]
+
+
+class Decomp(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("global_nx", "global_ny", "nx", "ny", "ndomains",
+                                       "max_width", "max_height")]
+
+
+_COMM_ARRAYS = ("dirsend", "destination", "isrcsend", "jsrcsend", "idessend", "jdessend",
+                "nxsend", "nysend", "dirrecv", "source", "isrcrecv", "jsrcrecv",
+                "idesrecv", "jdesrecv", "nxrecv", "nyrecv")
+
+
+class CommTables(C.Structure):
+    """public tables of parallel_comms_mod.f90:71-83"""
+    _fields_ = [("nsend", C.c_int), ("nrecv", C.c_int)] + \
+               [(n, C.c_int * MAXCOMM) for n in _COMM_ARRAYS]
+
+    def sends(self):
+        return [dict(dir=self.dirsend[k], dest=self.destination[k],
+                     isrc=self.isrcsend[k], jsrc=self.jsrcsend[k],
+                     ides=self.idessend[k], jdes=self.jdessend[k],
+                     nx=self.nxsend[k], ny=self.nysend[k]) for k in range(self.nsend)]
+
+    def recvs(self):
+        return [dict(dir=self.dirrecv[k], src=self.source[k],
+                     isrc=self.isrcrecv[k], jsrc=self.jsrcrecv[k],
+                     ides=self.idesrecv[k], jdes=self.jdesrecv[k],
+                     nx=self.nxrecv[k], ny=self.nyrecv[k]) for k in range(self.nrecv)]
+
+
+class SwParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fsdx", "fsdy", "tdts8", "tdtsdx", "tdtsdy")]
+
+
+# every entry point include/dlesm_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+_pi = C.POINTER(C.c_int)
+PROTOTYPES = {
+    "dlesm_alignment_from_env": (_i, [_pi]),
+    "dlesm_grid_extents": (_i, [_i, _i, _i, _pi, _pi]),
+    "dlesm_field_bounds": (_i, [_i, _i, _i, _i, C.POINTER(Region), _i, _i,
+                                C.POINTER(Region), C.POINTER(Region)]),
+    "dlesm_decompose": (_i, [_i] * 6 + [C.POINTER(Decomp), C.POINTER(Subdomain)]),
+    "dlesm_iprocmap": (_i, [C.POINTER(Decomp), C.POINTER(Subdomain), _i, _i, _i]),
+    "dlesm_map_comms": (_i, [C.POINTER(Decomp), C.POINTER(Subdomain), _i, _i,
+                             C.POINTER(CommTables)]),
+    "dlesm_last_error": (C.c_char_p, []),
+    "dlesm_version": (_i, []),
+    "dlesm_device_count": (_i, []),
+    "dlesm_init": (_i, [_i]),
+    "dlesm_finalize": (_i, []),
+    "dlesm_field_create": (_i, [_i, _i, C.POINTER(_vp)]),
+    "dlesm_field_wrap": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "dlesm_field_destroy": (_i, [_vp]),
+    "dlesm_field_data": (_vp, [_vp]),
+    "dlesm_field_ld": (_i, [_vp]),
+    "dlesm_field_ny": (_i, [_vp]),
+    "dlesm_read_from_device": (None, [_vp, _vp, _i, _i, _i, _i, C.c_bool]),
+    "dlesm_write_to_device": (None, [_vp, _vp, _i, _i, _i, _i, C.c_bool]),
+    "dlesm_transfer_sync": (_i, []),
+    "dlesm_stencil5_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dlesm_shallow_step_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
+    "dlesm_copy_patch_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dlesm_fill_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, _d, _vp]),
+    "dlesm_checksum_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_d), _vp]),
+    "dlesm_hash_init_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.c_uint64, C.c_int64, C.c_int64, _vp]),
+    "dlesm_set_tuning": (_i, [C.c_char_p, _i]),
+    "dlesm_comm_unique_id": (_i, [_vp]),
+    "dlesm_comm_init": (_i, [_vp, _i, _i]),
+    "dlesm_comm_finalize": (_i, []),
+    "dlesm_comm_rank": (_i, []),
+    "dlesm_comm_size": (_i, []),
+    "dlesm_halo_plan_create": (_i, [C.POINTER(CommTables), _i, _i, C.POINTER(_vp)]),
+    "dlesm_halo_plan_destroy": (_i, [_vp]),
+    "dlesm_halo_exchange_f64": (_i, [_vp, _vp, C.c_uint, _vp]),
+    "dlesm_jacobi5_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dlesm_global_sum_f64": (_i, [C.POINTER(_d)]),
+    "dlesm_gather_f64": (_i, [_vp, _vp, _i]),
+}
+
+_lib = None
+
+
+def lib():
+    """load libdlesm_hip.so (after torch, so that the HIP/RCCL runtimes are shared)"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C dl_esm_inf_amd/csrc`). There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64.so.7 / librccl.so.1 first)
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(L, name)         # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = lib().dlesm_last_error().decode(errors="replace")
+    if rc == EABORT:
+        raise GoceanStop(rc, msg)
+    raise DlesmError(rc, msg)

@@ -1,0 +1,347 @@
+// Device-resident halo exchange: the MI355X replacement for
+// r2d_field%halo_exchange -> exchange_generic -> MPI_Irecv/Isend/Waitany
+// (field_mod.f90:1231-1256, parallel_comms_mod.f90:1501-1855,
+//  parallel/parallel_utils_mod.f90:148-211).
+//
+// Design (not a translation of the MPI call pattern):
+//   * fields never leave HBM; the D2H/H2D strip copies of field_mod.f90:1241-1254
+//     disappear;
+//   * y-strips and corner cells are contiguous in memory (nysend = 1), so they are
+//     sent from / received into the field itself; only the strided x-strips are
+//     packed, by ONE kernel launch for all of them, into a persistent buffer;
+//   * all messages of an exchange go out in a single ncclGroupStart/End: every
+//     mesh neighbour of a rank is a direct xGMI peer, messages are <= 128 KiB, so
+//     the exchange is latency bound and what matters is one launch, not link
+//     bandwidth;
+//   * everything is stream ordered: the waits of msg_wait/msg_wait_all become
+//     stream dependencies, and dlesm_jacobi5_step_dm hides the whole exchange
+//     behind the interior stencil on a side stream.
+//
+// Message matching: RCCL has no tags.  Between a given pair of ranks messages
+// match in issue order, so sends to and receives from one peer are both issued
+// in ascending direction code -- the code is the MPI tag offset of the
+// reference (tag_orig + dir, pcomms:1606,1647) and is the same number on the
+// sending and on the receiving side of a message.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "dlesm_internal.h"
+
+using namespace dlesm;
+
+#define DLESM_NCCL_TRY(expr)                                                                \
+    do {                                                                                    \
+        ncclResult_t _r = (expr);                                                           \
+        if (_r != ncclSuccess)                                                              \
+            return ::dlesm::fail(DLESM_ERCCL, "%s failed: %s (%s:%d)", #expr,               \
+                                 ncclGetErrorString(_r), __FILE__, __LINE__);               \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == DLESM_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+namespace {
+
+ncclComm_t g_comm = nullptr;
+int g_rank = -1, g_size = 0;
+hipEvent_t g_ev_frame = nullptr, g_ev_comm = nullptr;
+
+struct Strip { // one packed (strided) message
+    int i0, j0, nx, ny; // 0-based origin and extent inside the field
+    long off;           // offset (doubles) of its slot in the pack buffer
+};
+
+struct Msg {
+    int dir, peer;
+    int i0, j0, nx, ny; // 0-based
+    long count;
+    long off;           // pack-buffer slot, or -1 when sent/received in place
+};
+
+} // namespace
+
+struct dlesm_halo_plan {
+    int ld, ny;
+    std::vector<Msg> sends, recvs; // sorted by (peer, dir)
+    int n_spack = 0, n_rpack = 0;
+    Strip *d_spack = nullptr, *d_rpack = nullptr; // device tables
+    double *sendbuf = nullptr, *recvbuf = nullptr;
+    long sendbuf_len = 0, recvbuf_len = 0;
+    int max_strip = 0;
+};
+
+// gather the strided strips into their slots: grid.y = strip, j outer / i inner
+// exactly like the pack loop of parallel_comms_mod.f90:1678-1683
+__global__ void pack_strips(const double *__restrict__ f, int ld, const Strip *__restrict__ tab,
+                            double *__restrict__ buf)
+{
+    const Strip s = tab[blockIdx.y];
+    const long n = (long)s.nx * s.ny;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(t / s.nx), i = (int)(t % s.nx);
+        buf[s.off + t] = f[(size_t)(s.j0 + j) * ld + s.i0 + i];
+    }
+}
+
+// inverse, parallel_comms_mod.f90:1788-1793
+__global__ void unpack_strips(double *__restrict__ f, int ld, const Strip *__restrict__ tab,
+                              const double *__restrict__ buf)
+{
+    const Strip s = tab[blockIdx.y];
+    const long n = (long)s.nx * s.ny;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(t / s.nx), i = (int)(t % s.nx);
+        f[(size_t)(s.j0 + j) * ld + s.i0 + i] = buf[s.off + t];
+    }
+}
+
+// single strip passed by value: used for partial (masked) exchanges
+__global__ void unpack_one(double *__restrict__ f, int ld, Strip s, const double *__restrict__ buf)
+{
+    const long n = (long)s.nx * s.ny;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(t / s.nx), i = (int)(t % s.nx);
+        f[(size_t)(s.j0 + j) * ld + s.i0 + i] = buf[s.off + t];
+    }
+}
+
+extern "C" int dlesm_comm_unique_id(void *id)
+{
+    DLESM_REQUIRE(id != nullptr, "null id buffer");
+    ncclUniqueId uid;
+    DLESM_NCCL_TRY(ncclGetUniqueId(&uid));
+    std::memcpy(id, &uid, sizeof(uid));
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_comm_init(const void *id, int nranks, int rank0)
+{
+    DLESM_REQUIRE(id != nullptr, "null id buffer");
+    DLESM_REQUIRE(nranks >= 1 && rank0 >= 0 && rank0 < nranks, "rank %d of %d", rank0, nranks);
+    DLESM_REQUIRE(g_comm == nullptr, "communicator already initialised");
+    if (int rc = ensure_device()) return rc;
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    DLESM_NCCL_TRY(ncclCommInitRank(&g_comm, nranks, uid, rank0));
+    g_rank = rank0;
+    g_size = nranks;
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_comm_finalize(void)
+{
+    if (g_comm) {
+        (void)hipDeviceSynchronize();
+        DLESM_NCCL_TRY(ncclCommDestroy(g_comm));
+        g_comm = nullptr;
+    }
+    g_rank = -1;
+    g_size = 0;
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_comm_rank(void) { return g_rank; }
+extern "C" int dlesm_comm_size(void) { return g_size; }
+
+static bool by_peer_dir(const Msg &a, const Msg &b)
+{
+    return a.peer != b.peer ? a.peer < b.peer : a.dir < b.dir;
+}
+
+extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny, dlesm_halo_plan **out)
+{
+    DLESM_REQUIRE(t != nullptr && out != nullptr, "null pointer");
+    DLESM_REQUIRE(ld > 0 && ny > 0, "field extents %dx%d", ld, ny);
+    DLESM_REQUIRE(t->nsend >= 0 && t->nsend <= DLESM_MAXCOMM && t->nrecv >= 0 && t->nrecv <= DLESM_MAXCOMM,
+                  "message counts %d/%d", t->nsend, t->nrecv);
+    if (int rc = ensure_device()) return rc;
+    dlesm_halo_plan *p = new dlesm_halo_plan;
+    p->ld = ld;
+    p->ny = ny;
+    std::vector<Strip> spack, rpack;
+    auto add = [&](std::vector<Msg> &list, std::vector<Strip> &pk, long &buflen, int dir, int peer, int i1,
+                   int j1, int nx, int nyy) -> int {
+        if (peer < 0 || nx <= 0) return DLESM_OK; // skipped by the reference too (pcomms:1603,1639)
+        if (i1 < 1 || j1 < 1 || i1 + nx - 1 > ld || j1 + nyy - 1 > ny || nyy < 1)
+            return fail(DLESM_EINVAL, "message patch (%d,%d)+%dx%d outside field %dx%d", i1, j1, nx, nyy, ld, ny);
+        Msg m{dir, peer, i1 - 1, j1 - 1, nx, nyy, (long)nx * nyy, -1};
+        if (nyy > 1 && nx != ld) { // rows of the patch are not adjacent in memory
+            m.off = buflen;
+            pk.push_back(Strip{m.i0, m.j0, nx, nyy, buflen});
+            buflen += m.count;
+            if (m.count > p->max_strip) p->max_strip = (int)m.count;
+        }
+        list.push_back(m);
+        return DLESM_OK;
+    };
+    int rc = DLESM_OK;
+    for (int k = 0; k < t->nsend && !rc; k++)
+        rc = add(p->sends, spack, p->sendbuf_len, t->dirsend[k], t->destination[k], t->isrcsend[k],
+                 t->jsrcsend[k], t->nxsend[k], t->nysend[k]);
+    for (int k = 0; k < t->nrecv && !rc; k++)
+        rc = add(p->recvs, rpack, p->recvbuf_len, t->dirrecv[k], t->source[k], t->idesrecv[k],
+                 t->jdesrecv[k], t->nxrecv[k], t->nyrecv[k]);
+    if (rc) {
+        delete p;
+        return rc;
+    }
+    std::stable_sort(p->sends.begin(), p->sends.end(), by_peer_dir);
+    std::stable_sort(p->recvs.begin(), p->recvs.end(), by_peer_dir);
+    p->n_spack = (int)spack.size();
+    p->n_rpack = (int)rpack.size();
+    auto upload = [&](const std::vector<Strip> &v, Strip **d) -> int {
+        if (v.empty()) return DLESM_OK;
+        DLESM_HIP_TRY(hipMalloc((void **)d, v.size() * sizeof(Strip)));
+        DLESM_HIP_TRY(hipMemcpy(*d, v.data(), v.size() * sizeof(Strip), hipMemcpyHostToDevice));
+        return DLESM_OK;
+    };
+    if ((rc = upload(spack, &p->d_spack)) || (rc = upload(rpack, &p->d_rpack))) {
+        dlesm_halo_plan_destroy(p);
+        return rc;
+    }
+    // persistent buffers: allocated once, unlike recvBuff which the reference
+    // reallocates on every exchange (pcomms:1574-1592,1852)
+    if (p->sendbuf_len) DLESM_HIP_TRY(hipMalloc((void **)&p->sendbuf, p->sendbuf_len * sizeof(double)));
+    if (p->recvbuf_len) DLESM_HIP_TRY(hipMalloc((void **)&p->recvbuf, p->recvbuf_len * sizeof(double)));
+    *out = p;
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_halo_plan_destroy(dlesm_halo_plan *p)
+{
+    if (!p) return DLESM_OK;
+    (void)hipDeviceSynchronize();
+    if (p->d_spack) (void)hipFree(p->d_spack);
+    if (p->d_rpack) (void)hipFree(p->d_rpack);
+    if (p->sendbuf) (void)hipFree(p->sendbuf);
+    if (p->recvbuf) (void)hipFree(p->recvbuf);
+    delete p;
+    return DLESM_OK;
+}
+
+static bool dir_enabled(unsigned mask, int dir)
+{
+    if (mask == 0) return true;
+    auto on = [&](int d) { return (mask >> (d - 1)) & 1u; };
+    switch (dir) { // diagonals follow their two edges, parallel_comms_mod.f90:1568-1571
+    case DLESM_IPLUSJPLUS: return on(DLESM_IPLUS) && on(DLESM_JPLUS);
+    case DLESM_IMINUSJMINUS: return on(DLESM_IMINUS) && on(DLESM_JMINUS);
+    case DLESM_IPLUSJMINUS: return on(DLESM_IPLUS) && on(DLESM_JMINUS);
+    case DLESM_IMINUSJPLUS: return on(DLESM_IMINUS) && on(DLESM_JPLUS);
+    default: return dir >= 1 && dir <= 4 && on(dir);
+    }
+}
+
+static int exchange_on(dlesm_halo_plan *p, double *f, unsigned mask, hipStream_t s)
+{
+    const bool any = !p->sends.empty() || !p->recvs.empty();
+    if (!any) return DLESM_OK; // serial run: nothing to do (pcomms:1546)
+    DLESM_REQUIRE(g_comm != nullptr, "halo exchange before dlesm_comm_init");
+    if (p->n_spack) {
+        int gx = (p->max_strip + 255) / 256;
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(pack_strips, dim3(gx, p->n_spack), dim3(256), 0, s, f, p->ld, p->d_spack, p->sendbuf);
+    }
+    DLESM_NCCL_TRY(ncclGroupStart());
+    for (const Msg &m : p->recvs) {
+        if (!dir_enabled(mask, m.dir)) continue;
+        double *dst = m.off >= 0 ? p->recvbuf + m.off : f + (size_t)m.j0 * p->ld + m.i0;
+        DLESM_NCCL_TRY(ncclRecv(dst, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
+    }
+    for (const Msg &m : p->sends) {
+        if (!dir_enabled(mask, m.dir)) continue;
+        const double *src = m.off >= 0 ? p->sendbuf + m.off : f + (size_t)m.j0 * p->ld + m.i0;
+        DLESM_NCCL_TRY(ncclSend(src, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
+    }
+    DLESM_NCCL_TRY(ncclGroupEnd());
+    if (p->n_rpack) {
+        int gx = (p->max_strip + 255) / 256;
+        if (gx > 64) gx = 64;
+        // a masked-out direction leaves its halo untouched: unpack only what arrived
+        if (mask == 0) {
+            hipLaunchKernelGGL(unpack_strips, dim3(gx, p->n_rpack), dim3(256), 0, s, f, p->ld, p->d_rpack, p->recvbuf);
+        } else {
+            for (const Msg &m : p->recvs) {
+                if (m.off < 0 || !dir_enabled(mask, m.dir)) continue;
+                hipLaunchKernelGGL(unpack_one, dim3(gx, 1), dim3(256), 0, s, f, p->ld,
+                                   Strip{m.i0, m.j0, m.nx, m.ny, m.off}, p->recvbuf);
+            }
+        }
+    }
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_halo_exchange_f64(dlesm_halo_plan *p, double *field, unsigned dirs_mask, void *stream)
+{
+    DLESM_REQUIRE(p != nullptr && field != nullptr, "null pointer");
+    if (int rc = ensure_device()) return rc;
+    return exchange_on(p, field, dirs_mask & 0xFu, (hipStream_t)stream);
+}
+
+extern "C" int dlesm_jacobi5_step_dm(dlesm_halo_plan *p, const double *in, double *out, int ld, int ny,
+                                     int xstart, int xstop, int ystart, int ystop, void *stream)
+{
+    DLESM_REQUIRE(p != nullptr && in != nullptr && out != nullptr, "null pointer");
+    DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
+    if (int rc = ensure_device()) return rc;
+    hipStream_t s = (hipStream_t)stream, side = side_stream();
+    if (!g_ev_frame) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_frame, hipEventDisableTiming));
+    if (!g_ev_comm) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_comm, hipEventDisableTiming));
+    const bool comms = !p->sends.empty() || !p->recvs.empty();
+    if (!comms) // single tile: one launch over the whole box
+        return launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s);
+    // 1. the frame of `out`: the only cells a neighbour will ask for
+    if (int rc = launch_stencil5_frame(in, out, ld, ny, xstart, xstop, ystart, ystop, s)) return rc;
+    DLESM_HIP_TRY(hipEventRecord(g_ev_frame, s));
+    // 2. exchange out's frame on the side stream ...
+    DLESM_HIP_TRY(hipStreamWaitEvent(side, g_ev_frame, 0));
+    if (int rc = exchange_on(p, out, 0, side)) return rc;
+    DLESM_HIP_TRY(hipEventRecord(g_ev_comm, side));
+    // 3. ... while the interior streams through HBM on the caller's stream
+    if (int rc = launch_stencil5(in, out, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, s)) return rc;
+    // 4. join: the next step reads out's halos
+    DLESM_HIP_TRY(hipStreamWaitEvent(s, g_ev_comm, 0));
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_global_sum_f64(double *value)
+{
+    DLESM_REQUIRE(value != nullptr, "null pointer");
+    if (g_size <= 1) return DLESM_OK; // the stub's no-op (parallel_utils_stub_mod.f90:148-150)
+    if (int rc = ensure_device()) return rc;
+    static double *d = nullptr;
+    if (!d) DLESM_HIP_TRY(hipMalloc((void **)&d, sizeof(double)));
+    hipStream_t s = side_stream();
+    DLESM_HIP_TRY(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, s));
+    DLESM_NCCL_TRY(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, g_comm, s));
+    DLESM_HIP_TRY(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, s));
+    DLESM_HIP_TRY(hipStreamSynchronize(s));
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_gather_f64(const double *send, double *recv, int n)
+{
+    DLESM_REQUIRE(send != nullptr && n >= 0, "bad arguments");
+    if (int rc = ensure_device()) return rc;
+    hipStream_t s = side_stream();
+    if (g_size <= 1) { // the stub's copy (parallel_utils_stub_mod.f90:154-161)
+        DLESM_REQUIRE(recv != nullptr, "null receive buffer");
+        DLESM_HIP_TRY(hipMemcpyAsync(recv, send, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        DLESM_HIP_TRY(hipStreamSynchronize(s));
+        return DLESM_OK;
+    }
+    // MPI_Gather to root 0 (parallel_utils_mod.f90:242-255) as grouped send/recv
+    DLESM_REQUIRE(g_rank != 0 || recv != nullptr, "null receive buffer on root");
+    DLESM_NCCL_TRY(ncclGroupStart());
+    if (g_rank == 0) {
+        for (int r = 0; r < g_size; r++)
+            DLESM_NCCL_TRY(ncclRecv(recv + (size_t)r * n, (size_t)n, ncclDouble, r, g_comm, s));
+    }
+    DLESM_NCCL_TRY(ncclSend(send, (size_t)n, ncclDouble, 0, g_comm, s));
+    DLESM_NCCL_TRY(ncclGroupEnd());
+    DLESM_HIP_TRY(hipStreamSynchronize(s));
+    return DLESM_OK;
+}

@@ -1,0 +1,484 @@
+// CDNA4 (gfx950) kernels of the dl_esm_inf hot path: the PSy-layer loop nests
+// over r2d_field%data, re-done as HBM-streaming HIP kernels.
+//
+// All of them are memory bound (<= 0.25 flop/byte): no MFMA, no GEMM reshaping.
+// What matters is that every cell is fetched from HBM once, in 16-byte-per-lane
+// coalesced requests, with enough requests in flight per CU.
+#include <mutex>
+
+#include "dlesm_internal.h"
+
+namespace dlesm {
+
+// ===========================================================================
+// 5-point Jacobi, "march in y" form.
+//
+// A wave owns 64*VEC consecutive columns and walks up a strip of rows keeping
+// the three live rows (jj-1, jj, jj+1) in registers, so each input row is
+// loaded once per strip.  West/east neighbours come from the adjacent lane by
+// a wave64 shuffle; the two values a wave cannot get from its own lanes (left
+// of lane 0, right of lane 63) are fetched by those two lanes with one extra
+// 8-byte load per row (an L1/L2 hit: the line is being streamed by the
+// neighbouring wave).  Rows are processed U at a time so that U row loads are
+// in flight per lane before the first is consumed.
+//
+// Chunks are anchored at column 0 of the padded row: with ld even (any
+// DL_ESM_ALIGNMENT that is a multiple of 2) and a 16-byte aligned base every
+// lane's double2 is 16-byte aligned although the interior starts at column 1
+// (internal%xstart = 2, parallel_mod.f90:273).  Odd ld falls back to VEC = 1.
+// ===========================================================================
+
+template <int VEC> struct Vec;
+template <> struct Vec<1> { double v[1]; };
+template <> struct __attribute__((aligned(16))) Vec<2> { double v[2]; };
+
+template <int VEC, bool NT>
+__device__ __forceinline__ Vec<VEC> load_chunk(const double *p)
+{
+    Vec<VEC> r;
+    if constexpr (VEC == 2) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 t = NT ? __builtin_nontemporal_load((const d2 *)p) : *(const d2 *)p;
+        r.v[0] = t.x;
+        r.v[1] = t.y;
+    } else {
+        r.v[0] = NT ? __builtin_nontemporal_load(p) : *p;
+    }
+    return r;
+}
+
+template <int VEC, bool NT>
+__device__ __forceinline__ void store_chunk(double *p, const double (&o)[VEC], bool m0, bool m1)
+{
+    if constexpr (VEC == 2) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        if (m0 && m1) {
+            d2 t = {o[0], o[1]};
+            if (NT) __builtin_nontemporal_store(t, (d2 *)p);
+            else *(d2 *)p = t;
+        } else {
+            if (m0) p[0] = o[0];
+            if (m1) p[1] = o[1];
+        }
+    } else {
+        if (m0) {
+            if (NT) __builtin_nontemporal_store(o[0], p);
+            else p[0] = o[0];
+        }
+    }
+}
+
+// one output row from the three live rows; `edge` is meaningful in lanes 0 and 63 only
+template <int VEC>
+__device__ __forceinline__ void jacobi_row(const Vec<VEC> &south, const Vec<VEC> &mid,
+                                           const Vec<VEC> &north, double edge, int lane,
+                                           double (&o)[VEC])
+{
+    double west = __shfl_up(mid.v[VEC - 1], 1);
+    double east = __shfl_down(mid.v[0], 1);
+    if (lane == 0) west = edge;
+    if (lane == 63) east = edge;
+    if constexpr (VEC == 2) {
+        o[0] = 0.25 * ((west + mid.v[1]) + (south.v[0] + north.v[0]));
+        o[1] = 0.25 * ((mid.v[0] + east) + (south.v[1] + north.v[1]));
+    } else {
+        o[0] = 0.25 * ((west + east) + (south.v[0] + north.v[0]));
+    }
+}
+
+// x0..x1, y0..y1: 0-based inclusive interior box.  c_first: first chunk holding an
+// interior column.  nxb: blocks per strip.  rows: strip height.
+template <int VEC, int U, bool NT>
+__global__ __launch_bounds__(256) void jacobi5_march(const double *__restrict__ in,
+                                                     double *__restrict__ out, int ld, int x0,
+                                                     int x1, int y0, int y1, int c_first, int nxb,
+                                                     int rows, int serpentine)
+{
+    const int bx = blockIdx.x % nxb, by = blockIdx.x / nxb;
+    const int lane = threadIdx.x & 63;
+    const int c = c_first + bx * 256 + (int)threadIdx.x; // this lane's chunk
+    const int c_last = x1 / VEC;                         // last chunk holding an interior column
+    // a wave whose first chunk lies beyond the last interior chunk has nothing to do
+    if (c - lane > c_last) return;
+    const int c_ld = ld / VEC - 1;                       // last whole chunk inside a row
+    const int cl = c < c_ld ? c : c_ld;                  // clamp loads of trailing lanes
+    const int col = cl * VEC;
+    const bool m0 = c <= c_last && c * VEC >= x0 && c * VEC <= x1;
+    const bool m1 = VEC == 2 && c <= c_last && c * VEC + 1 >= x0 && c * VEC + 1 <= x1;
+    // which single extra column this lane fetches per row (-1: none)
+    int ecol = -1;
+    if (lane == 0 && m0) ecol = c * VEC - 1;
+    if (lane == 63 && (VEC == 2 ? m1 : m0)) ecol = c * VEC + VEC;
+
+    const int jb = y0 + by * rows;
+    int je = jb + rows - 1;
+    if (je > y1) je = y1;
+    // serpentine: odd strips walk downwards so that the two strips sharing a
+    // boundary row touch it at the same time (re-read served by L2 / MALL)
+    const int dir = (serpentine && (by & 1)) ? -1 : 1;
+    int j = dir > 0 ? jb : je;
+    const int jend = dir > 0 ? je : jb;
+
+    const double *pin = in + col;
+    double *pout = out + (size_t)c * VEC;
+    auto row = [&](int jj) { return load_chunk<VEC, NT>(pin + (size_t)jj * ld); };
+    auto edge_of = [&](int jj) { return ecol >= 0 ? in[(size_t)jj * ld + ecol] : 0.0; };
+
+    Vec<VEC> behind = row(j - dir), mid = row(j);
+    double emid = edge_of(j);
+    const int nrow = (jend - j) * dir + 1;
+    int done = 0;
+    for (; done + U <= nrow; done += U) {
+        Vec<VEC> ahead[U];
+        double eahead[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            ahead[u] = row(j + dir * (u + 1));
+            eahead[u] = edge_of(j + dir * (u + 1));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            double o[VEC];
+            // (south + north) is commutative: walking down only swaps the operands
+            if (dir > 0) jacobi_row<VEC>(behind, mid, ahead[u], emid, lane, o);
+            else jacobi_row<VEC>(ahead[u], mid, behind, emid, lane, o);
+            store_chunk<VEC, NT>(pout + (size_t)(j + dir * u) * ld, o, m0, m1);
+            behind = mid;
+            mid = ahead[u];
+            emid = eahead[u];
+        }
+        j += dir * U;
+    }
+    for (; done < nrow; done++) {
+        Vec<VEC> ahead = row(j + dir);
+        double ea = edge_of(j + dir);
+        double o[VEC];
+        if (dir > 0) jacobi_row<VEC>(behind, mid, ahead, emid, lane, o);
+        else jacobi_row<VEC>(ahead, mid, behind, emid, lane, o);
+        store_chunk<VEC, NT>(pout + (size_t)j * ld, o, m0, m1);
+        behind = mid;
+        mid = ahead;
+        emid = ea;
+        j += dir;
+    }
+}
+
+// The one-cell-wide frame of the box (rows ystart/ystop, columns xstart/xstop):
+// the cells whose values neighbours need first in the distributed step.
+__global__ __launch_bounds__(256) void jacobi5_frame(const double *__restrict__ in,
+                                                     double *__restrict__ out, int ld, int x0, int x1,
+                                                     int y0, int y1)
+{
+    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+    const int ncol = h > 2 ? h - 2 : 0;
+    const int nrows = h > 1 ? 2 : 1;
+    const long total = (long)nrows * w + 2L * ncol * (w > 1 ? 1 : 0) + (w == 1 ? ncol : 0);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long)gridDim.x * blockDim.x) {
+        int i, j;
+        if (t < (long)nrows * w) {
+            j = t < w ? y0 : y1;
+            i = x0 + (int)(t % w);
+        } else {
+            long k = t - (long)nrows * w;
+            if (w == 1) { i = x0; j = y0 + 1 + (int)k; }
+            else { i = k < ncol ? x0 : x1; j = y0 + 1 + (int)(k % ncol); }
+        }
+        const size_t o = (size_t)j * ld + i;
+        out[o] = 0.25 * ((in[o - 1] + in[o + 1]) + (in[o - ld] + in[o + ld]));
+    }
+}
+
+static int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                     int ring)
+{
+    if (ld < 1 || ny < 1) return fail(DLESM_EINVAL, "%s: array extents %dx%d", who, ld, ny);
+    if (xstart - ring < 1 || xstop + ring > ld || ystart - ring < 1 || ystop + ring > ny)
+        return fail(DLESM_EINVAL, "%s: box (%d:%d,%d:%d) with a %d-cell stencil ring does not fit in "
+                                  "an array of %dx%d", who, xstart, xstop, ystart, ystop, ring, ld, ny);
+    return DLESM_OK;
+}
+
+template <int VEC, bool NT>
+static void launch_march(const double *in, double *out, int ld, int x0, int x1, int y0, int y1,
+                         int rows, int serp, hipStream_t s)
+{
+    const int c_first = x0 / VEC, c_last = x1 / VEC;
+    const int nch = c_last - c_first + 1;
+    const int nxb = (nch + 255) / 256;
+    const int nstrips = (y1 - y0 + rows) / rows;
+    dim3 grid((unsigned)(nxb * nstrips)), block(256);
+    hipLaunchKernelGGL((jacobi5_march<VEC, 4, NT>), grid, block, 0, s, in, out, ld, x0, x1, y0, y1,
+                       c_first, nxb, rows, serp);
+}
+
+int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart,
+                    int ystop, hipStream_t s)
+{
+    if (xstop < xstart || ystop < ystart) return DLESM_OK; // empty box: a zero-trip loop nest
+    if (int rc = check_box("dlesm_stencil5_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    DLESM_REQUIRE(in != nullptr && out != nullptr && in != out, "stencil5: null or aliased arrays");
+    const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
+    int rows = tuning("j5_rows", 64);
+    if (rows < 1) rows = 1;
+    const int variant = tuning("j5_variant", 0); // bit0: non-temporal, bit1: serpentine, bit2: force VEC=1
+    const bool nt = variant & 1;
+    const int serp = (variant >> 1) & 1;
+    const bool vec2 = !(variant & 4) && (ld % 2 == 0) && ((uintptr_t)in % 16 == 0) &&
+                      ((uintptr_t)out % 16 == 0);
+    if (vec2) {
+        if (nt) launch_march<2, true>(in, out, ld, x0, x1, y0, y1, rows, serp, s);
+        else launch_march<2, false>(in, out, ld, x0, x1, y0, y1, rows, serp, s);
+    } else {
+        if (nt) launch_march<1, true>(in, out, ld, x0, x1, y0, y1, rows, serp, s);
+        else launch_march<1, false>(in, out, ld, x0, x1, y0, y1, rows, serp, s);
+    }
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop,
+                          int ystart, int ystop, hipStream_t s)
+{
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("stencil5 frame", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    const long cells = 2L * (xstop - xstart + 1) + 2L * (ystop - ystart + 1);
+    int blocks = (int)((cells + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(jacobi5_frame, dim3(blocks), dim3(256), 0, s, in, out, ld, xstart - 1, xstop - 1,
+                       ystart - 1, ystop - 1);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+// ===========================================================================
+// Shallow-water u/v/h update, NE staggering, all intermediates (cu, cv, z, h)
+// recomputed in registers from the 3x3 neighbourhood of u, v, p: 6 fields read,
+// 3 written = 72 B/cell of algorithmic traffic.
+// First, direct form: neighbours come from L1/L2.
+// ===========================================================================
+__global__ __launch_bounds__(256) void shallow_step_direct(
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, const double *__restrict__ u,
+    const double *__restrict__ v, const double *__restrict__ p, const double *__restrict__ uold,
+    const double *__restrict__ vold, const double *__restrict__ pold, double *__restrict__ unew,
+    double *__restrict__ vnew, double *__restrict__ pnew)
+{
+    const int i = x0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = y0 + blockIdx.y;
+    if (i > x1 || j > y1) return;
+    const size_t o = (size_t)j * ld + i;
+#define U_(di, dj) u[o + (di) + (long)(dj) * ld]
+#define V_(di, dj) v[o + (di) + (long)(dj) * ld]
+#define P_(di, dj) p[o + (di) + (long)(dj) * ld]
+    // cu(a,b) = 0.5*(p(a+1,b)+p(a,b))*u(a,b) ; cv(a,b) = 0.5*(p(a,b+1)+p(a,b))*v(a,b)
+#define CU(di, dj) (0.5 * (P_((di) + 1, dj) + P_(di, dj)) * U_(di, dj))
+#define CV(di, dj) (0.5 * (P_(di, (dj) + 1) + P_(di, dj)) * V_(di, dj))
+    // z(a,b) at the NE corner of T(a,b)
+#define Z(di, dj)                                                                                   \
+    ((q.fsdx * (V_((di) + 1, dj) - V_(di, dj)) - q.fsdy * (U_(di, (dj) + 1) - U_(di, dj))) /         \
+     (P_(di, dj) + P_((di) + 1, dj) + P_((di) + 1, (dj) + 1) + P_(di, (dj) + 1)))
+#define H(di, dj)                                                                                   \
+    (P_(di, dj) + 0.25 * (U_(di, dj) * U_(di, dj) + U_((di)-1, dj) * U_((di)-1, dj) +                \
+                          V_(di, dj) * V_(di, dj) + V_(di, (dj)-1) * V_(di, (dj)-1)))
+    const double z00 = Z(0, 0), z0m = Z(0, -1), zm0 = Z(-1, 0);
+    const double h00 = H(0, 0), hp0 = H(1, 0), h0p = H(0, 1);
+    const double cu00 = CU(0, 0), cum0 = CU(-1, 0), cu0p = CU(0, 1), cump = CU(-1, 1);
+    const double cv00 = CV(0, 0), cv0m = CV(0, -1), cvp0 = CV(1, 0), cvpm = CV(1, -1);
+    unew[o] = uold[o] + q.tdts8 * (z00 + z0m) * (cvp0 + cv00 + cv0m + cvpm) - q.tdtsdx * (hp0 - h00);
+    vnew[o] = vold[o] - q.tdts8 * (z00 + zm0) * (cu0p + cump + cum0 + cu00) - q.tdtsdy * (h0p - h00);
+    pnew[o] = pold[o] - q.tdtsdx * (cu00 - cum0) - q.tdtsdy * (cv00 - cv0m);
+#undef U_
+#undef V_
+#undef P_
+#undef CU
+#undef CV
+#undef Z
+#undef H
+}
+
+// ===========================================================================
+// small utility kernels
+// ===========================================================================
+__global__ void copy_patch_k(const double *__restrict__ src, double *__restrict__ dst, int ld, int sx0,
+                             int sy0, int dx0, int dy0, int nx, int ny)
+{
+    for (int j = blockIdx.y; j < ny; j += gridDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += gridDim.x * blockDim.x)
+            dst[(size_t)(dy0 + j) * ld + dx0 + i] = src[(size_t)(sy0 + j) * ld + sx0 + i];
+}
+
+__global__ void fill_k(double *__restrict__ f, int ld, int x0, int y0, int nx, int ny, double value)
+{
+    for (int j = blockIdx.y; j < ny; j += gridDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += gridDim.x * blockDim.x)
+            f[(size_t)(y0 + j) * ld + x0 + i] = value;
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+__global__ void hash_init_k(double *__restrict__ f, int ld, int x0, int y0, int nx, int ny,
+                            uint64_t seed, int64_t gx0, int64_t gy0)
+{
+    for (int j = blockIdx.y; j < ny; j += gridDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += gridDim.x * blockDim.x) {
+            const uint64_t gi = (uint64_t)(gx0 + x0 + i), gj = (uint64_t)(gy0 + y0 + j);
+            const uint64_t h = splitmix64(seed ^ (gi + (gj << 32)));
+            f[(size_t)(y0 + j) * ld + x0 + i] = (double)(h >> 11) * 0x1.0p-53;
+        }
+}
+
+// SUM(ABS()) in a fixed tree order: lane strides -> wave shuffle tree -> LDS
+// across the 4 waves -> one partial per block -> second pass over the partials.
+__device__ __forceinline__ double block_sum_256(double v)
+{
+    __shared__ double wsum[4];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void abs_sum_rows(const double *__restrict__ f, int ld, int x0, int y0,
+                                                    int nx, int ny, double *__restrict__ partial)
+{
+    double acc = 0.0;
+    for (int j = blockIdx.x; j < ny; j += gridDim.x) {
+        const double *r = f + (size_t)(y0 + j) * ld + x0;
+        for (int i = threadIdx.x; i < nx; i += 256) acc += fabs(r[i]);
+    }
+    acc = block_sum_256(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void sum_partials(const double *__restrict__ partial, int n,
+                                                    double *__restrict__ result)
+{
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    acc = block_sum_256(acc);
+    if (threadIdx.x == 0) *result = acc;
+}
+
+static std::mutex g_scratch_mu;
+static double *g_partials = nullptr; // 4096 partials + 1 result
+static const int kMaxPartials = 4096;
+
+} // namespace dlesm
+
+using namespace dlesm;
+
+extern "C" int dlesm_stencil5_f64(const double *in, double *out, int ld, int ny, int xstart,
+                                  int xstop, int ystart, int ystop, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    return launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, (hipStream_t)stream);
+}
+
+extern "C" int dlesm_shallow_step_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop,
+                                      int ystart, int ystop, const double *u, const double *v,
+                                      const double *p, const double *uold, const double *vold,
+                                      const double *pold, double *unew, double *vnew, double *pnew,
+                                      void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(q && u && v && p && uold && vold && pold && unew && vnew && pnew, "null pointer");
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("dlesm_shallow_step_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    DLESM_REQUIRE(unew != u && unew != v && unew != p && vnew != u && vnew != v && vnew != p &&
+                      pnew != u && pnew != v && pnew != p,
+                  "shallow step: outputs alias the 3x3-read inputs");
+    const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
+    dim3 block(256), grid((nx + 255) / 256, nyb);
+    DLESM_REQUIRE(nyb <= 65535 * 1024, "box too tall");
+    hipLaunchKernelGGL(shallow_step_direct, grid, block, 0, (hipStream_t)stream, *q, ld, xstart - 1,
+                       xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold, unew, vnew, pnew);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+static dim3 grid2d(int nx, int ny)
+{
+    int gx = (nx + 255) / 256;
+    if (gx > 64) gx = 64;
+    int gy = ny > 4096 ? 4096 : ny;
+    return dim3(gx, gy);
+}
+
+extern "C" int dlesm_copy_patch_f64(const double *src, double *dst, int ld, int ny_arr, int sx0, int sy0,
+                                    int dx0, int dy0, int nx, int ny, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(src && dst, "null pointer");
+    if (nx <= 0 || ny <= 0) return DLESM_OK;
+    if (int rc = check_box("dlesm_copy_patch_f64(src)", ld, ny_arr, sx0, sx0 + nx - 1, sy0, sy0 + ny - 1, 0)) return rc;
+    if (int rc = check_box("dlesm_copy_patch_f64(dst)", ld, ny_arr, dx0, dx0 + nx - 1, dy0, dy0 + ny - 1, 0)) return rc;
+    if (src == dst) {
+        const bool overlap = !(dx0 + nx <= sx0 || sx0 + nx <= dx0 || dy0 + ny <= sy0 || sy0 + ny <= dy0);
+        DLESM_REQUIRE(!overlap, "copy_patch: overlapping source and destination patches");
+    }
+    hipLaunchKernelGGL(copy_patch_k, grid2d(nx, ny), dim3(256), 0, (hipStream_t)stream, src, dst, ld,
+                       sx0 - 1, sy0 - 1, dx0 - 1, dy0 - 1, nx, ny);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_fill_f64(double *f, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                              double value, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(f != nullptr, "null pointer");
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("dlesm_fill_f64", ld, ny, xstart, xstop, ystart, ystop, 0)) return rc;
+    const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
+    hipLaunchKernelGGL(fill_k, grid2d(nx, nyb), dim3(256), 0, (hipStream_t)stream, f, ld, xstart - 1,
+                       ystart - 1, nx, nyb, value);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_hash_init_f64(double *f, int ld, int ny, int xstart, int xstop, int ystart,
+                                   int ystop, uint64_t seed, int64_t gx0, int64_t gy0, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(f != nullptr, "null pointer");
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("dlesm_hash_init_f64", ld, ny, xstart, xstop, ystart, ystop, 0)) return rc;
+    const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
+    hipLaunchKernelGGL(hash_init_k, grid2d(nx, nyb), dim3(256), 0, (hipStream_t)stream, f, ld, xstart - 1,
+                       ystart - 1, nx, nyb, seed, gx0, gy0);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_checksum_f64(const double *f, int ld, int ny, int xstart, int xstop, int ystart,
+                                  int ystop, double *result, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(f != nullptr && result != nullptr, "null pointer");
+    if (xstop < xstart || ystop < ystart) {
+        *result = 0.0;
+        return DLESM_OK;
+    }
+    if (int rc = check_box("dlesm_checksum_f64", ld, ny, xstart, xstop, ystart, ystop, 0)) return rc;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_partials) DLESM_HIP_TRY(hipMalloc((void **)&g_partials, (kMaxPartials + 1) * sizeof(double)));
+    const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
+    const int blocks = nyb < kMaxPartials ? nyb : kMaxPartials;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(abs_sum_rows, dim3(blocks), dim3(256), 0, s, f, ld, xstart - 1, ystart - 1, nx, nyb,
+                       g_partials);
+    hipLaunchKernelGGL(sum_partials, dim3(1), dim3(256), 0, s, g_partials, blocks, g_partials + kMaxPartials);
+    DLESM_HIP_TRY(hipGetLastError());
+    DLESM_HIP_TRY(hipMemcpyAsync(result, g_partials + kMaxPartials, sizeof(double), hipMemcpyDeviceToHost, s));
+    DLESM_HIP_TRY(hipStreamSynchronize(s));
+    return DLESM_OK;
+}

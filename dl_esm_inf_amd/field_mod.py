@@ -1,0 +1,151 @@
+"""Python mirror of field_mod (reference: finite_difference/src/field_mod.f90).
+
+The field's data lives in HBM for its whole life (a torch tensor provides the allocation);
+`get_data()/set_data()` are the only host transfers, exactly the two the reference routes
+through its device callbacks (field_mod.f90:530-559).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi, grid_mod
+from ._cabi import Region, check
+
+GO_U_POINTS, GO_V_POINTS, GO_T_POINTS, GO_F_POINTS, GO_ALL_POINTS = 0, 1, 2, 3, 4
+NBOUNDARY = 1
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _cabi.DlesmError(_cabi.ENODEV, "r2d_field needs a GPU: no HIP device is visible "
+                                             "(this package has no CPU path)")
+    return torch
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def field_bounds(grid, grid_points):
+    """set_field_bounds (field_mod.f90:563-624) -> (internal, whole)"""
+    internal, whole = Region(), Region()
+    check(_cabi.lib().dlesm_field_bounds(grid_points, grid.offset, grid.boundary_conditions[0],
+                                         grid.boundary_conditions[1],
+                                         C.byref(grid.subdomain.internal), grid.nx, grid.ny,
+                                         C.byref(internal), C.byref(whole)))
+    return internal, whole
+
+
+class r2d_field:
+    """r2d_field (field_mod.f90:139-166) with device-resident data"""
+
+    def __init__(self, grid, grid_points, init_global_data=None):
+        self.grid = grid
+        self.defined_on = grid_points
+        self.internal, self.whole = field_bounds(grid, grid_points)
+        torch = _torch()
+        # data(1:grid%nx, 1:grid%ny), zeroed (field_mod.f90:350,375); row-major (ny, nx) here
+        self.data = torch.zeros((grid.ny, grid.nx), dtype=torch.float64, device="cuda")
+        self.data_on_device = True
+        self.ntiles = 0
+        if init_global_data is not None:                   # field_mod.f90:378-389
+            g = np.asarray(init_global_data, dtype=np.float64)
+            s = grid.subdomain
+            dx = s.glob.xstart - self.internal.xstart
+            dy = s.glob.ystart - self.internal.ystart
+            si = s.internal
+            patch = g[si.ystart + dy - 1:si.ystop + dy, si.xstart + dx - 1:si.xstop + dx]
+            self.data[si.ystart - 1:si.ystop, si.xstart - 1:si.xstop] = torch.from_numpy(
+                np.ascontiguousarray(patch)).cuda()
+
+    # -- raw views ---------------------------------------------------------
+    @property
+    def device_ptr(self):
+        return C.c_void_p(self.data.data_ptr())
+
+    def get_data(self):
+        """host copy, shape (ny, nx) (field_mod.f90:530-542)"""
+        return self.data.cpu().numpy()
+
+    def set_data(self, array):
+        """field_mod.f90:546-559"""
+        torch = _torch()
+        self.data.copy_(torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64)))
+        return 0
+
+    # -- halo exchange -----------------------------------------------------
+    def halo_exchange(self, depth=1, stream=None):
+        """halo_exchange (field_mod.f90:1231-1256); depth is ignored as in the reference"""
+        plan = grid_mod.halo_plan(self.grid)
+        check(_cabi.lib().dlesm_halo_exchange_f64(plan, self.device_ptr, 0, _stream_ptr(stream)))
+
+    def gather_inner_data(self):
+        """gather_inner_data (field_mod.f90:1313-1390): global (ny, nx) array on rank 1, else None"""
+        from . import parallel_mod
+        torch = _torch()
+        g = self.grid
+        nranks = parallel_mod.get_num_ranks()
+        it = self.internal
+        if nranks == 1:
+            return self.data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop].cpu().numpy().copy()
+        halo_x, halo_y = it.xstart - 1, it.ystart - 1      # field_mod.f90:1348-1351
+        n = (g.decomp.max_width - 2 * halo_x) * (g.decomp.max_height - 2 * halo_y)
+        send = torch.zeros(n, dtype=torch.float64, device="cuda")
+        inner = self.data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop].reshape(-1)
+        send[:inner.numel()] = inner
+        recv = torch.zeros(n * nranks, dtype=torch.float64, device="cuda") if parallel_mod.on_master() else None
+        torch.cuda.synchronize()
+        check(_cabi.lib().dlesm_gather_f64(C.c_void_p(send.data_ptr()),
+                                           C.c_void_p(recv.data_ptr()) if recv is not None else None, n))
+        if not parallel_mod.on_master():
+            return None
+        out = np.zeros((g.global_ny, g.global_nx))
+        host = recv.cpu().numpy()
+        for r in range(nranks):
+            s = g.decomp.subdomains[r].glob
+            w, h = s.xstop - s.xstart + 1, s.ystop - s.ystart + 1
+            out[s.ystart - 1:s.ystop, s.xstart - 1:s.xstop] = host[r * n:r * n + w * h].reshape(h, w)
+        return out
+
+
+def field_checksum(field, stream=None):
+    """field_checksum (field_mod.f90:1209-1219, 1289-1307): SUM(ABS(internal)) + global_sum"""
+    val = C.c_double()
+    it = field.internal
+    check(_cabi.lib().dlesm_checksum_f64(field.device_ptr, field.grid.nx, field.grid.ny, it.xstart,
+                                         it.xstop, it.ystart, it.ystop, C.byref(val),
+                                         _stream_ptr(stream)))
+    check(_cabi.lib().dlesm_global_sum_f64(C.byref(val)))
+    return val.value
+
+
+def copy_field(field_in, field_out=None, src=None, dest=None, stream=None):
+    """copy_field (field_mod.f90:1126-1187): whole-field copy, or patch copy src -> dest
+    (Region objects) inside one field."""
+    L = _cabi.lib()
+    if src is None:
+        g = field_in.grid
+        check(L.dlesm_copy_patch_f64(field_in.device_ptr, field_out.device_ptr, g.nx, g.ny,
+                                     1, 1, 1, 1, g.nx, g.ny, _stream_ptr(stream)))
+    else:
+        g = field_in.grid
+        check(L.dlesm_copy_patch_f64(field_in.device_ptr, field_in.device_ptr, g.nx, g.ny,
+                                     src.xstart, src.ystart, dest.xstart, dest.ystart,
+                                     src.xstop - src.xstart + 1, src.ystop - src.ystart + 1,
+                                     _stream_ptr(stream)))
+
+
+def set_field(fld, val, stream=None):
+    """set_field (field_mod.f90:1191-1202)"""
+    g = fld.grid
+    check(_cabi.lib().dlesm_fill_f64(fld.device_ptr, g.nx, g.ny, 1, g.nx, 1, g.ny, float(val),
+                                     _stream_ptr(stream)))
+
+
+def free_field(fld):
+    """free_field (field_mod.f90:395-403)"""
+    fld.data = None

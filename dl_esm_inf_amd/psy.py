@@ -1,0 +1,53 @@
+"""The "PSy layer" for the Python mirror: what PSyclone would generate around each kernel
+(`do jj = fld%internal%ystart, ... ; do ji = ...; call kern_code(ji, jj, ...)`, form
+infrastructure_mod.f90:32-41) becomes one launch of the matching HIP kernel over the same
+index box."""
+import ctypes as C
+
+from . import _cabi, grid_mod
+from ._cabi import SwParams, check
+from .field_mod import _stream_ptr
+
+
+def invoke_jacobi5(out_fld, in_fld, stream=None):
+    """out = 0.25*((w+e)+(s+n)) over out_fld%internal"""
+    g, it = out_fld.grid, out_fld.internal
+    check(_cabi.lib().dlesm_stencil5_f64(in_fld.device_ptr, out_fld.device_ptr, g.nx, g.ny,
+                                         it.xstart, it.xstop, it.ystart, it.ystop,
+                                         _stream_ptr(stream)))
+
+
+def invoke_jacobi5_dm(out_fld, in_fld, stream=None):
+    """distributed step: frame, then exchange(out) hidden behind the interior"""
+    g, it = out_fld.grid, out_fld.internal
+    plan = grid_mod.halo_plan(g)
+    check(_cabi.lib().dlesm_jacobi5_step_dm(plan, in_fld.device_ptr, out_fld.device_ptr, g.nx, g.ny,
+                                            it.xstart, it.xstop, it.ystart, it.ystop,
+                                            _stream_ptr(stream)))
+
+
+def shallow_params(dx, dy, dt):
+    """constants of the shallow-water step: tdt = 2*dt (leapfrog)"""
+    tdt = dt + dt
+    return SwParams(fsdx=4.0 / dx, fsdy=4.0 / dy, tdts8=tdt / 8.0, tdtsdx=tdt / dx, tdtsdy=tdt / dy)
+
+
+def invoke_shallow_step(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
+    g, it = p.grid, p.internal
+    check(_cabi.lib().dlesm_shallow_step_f64(C.byref(params), g.nx, g.ny, it.xstart, it.xstop,
+                                             it.ystart, it.ystop, u.device_ptr, v.device_ptr,
+                                             p.device_ptr, uold.device_ptr, vold.device_ptr,
+                                             pold.device_ptr, unew.device_ptr, vnew.device_ptr,
+                                             pnew.device_ptr, _stream_ptr(stream)))
+
+
+def hash_init(fld, seed, box=None, stream=None):
+    """synthetic initial condition on `box` (default: the field's whole region), a function of
+    the GLOBAL cell index so that every decomposition produces the same global field"""
+    g = fld.grid
+    b = box or fld.whole
+    s = g.subdomain
+    gx0 = s.glob.xstart - s.internal.xstart + 1    # global index of local cell 1
+    gy0 = s.glob.ystart - s.internal.ystart + 1
+    check(_cabi.lib().dlesm_hash_init_f64(fld.device_ptr, g.nx, g.ny, b.xstart, b.xstop, b.ystart,
+                                          b.ystop, seed, gx0, gy0, _stream_ptr(stream)))

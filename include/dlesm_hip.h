@@ -1,0 +1,268 @@
+/*
+ * dlesm_hip.h -- C ABI of the MI355X-native dl_esm_inf hot path.
+ *
+ * Everything a host language binds is declared here: plain C, plain pointers
+ * and sizes, no C++ or torch types.  The Fortran side binds these through
+ * ISO_C_BINDING (dl_esm_inf_amd/fortran/dlesm_hip_mod.f90), Python through
+ * ctypes (dl_esm_inf_amd/_cabi.py).  INTEGRATION.md shows the stub a
+ * maintainer of stfc/dl_esm_inf would add.
+ *
+ * Each entry cites the reference interface it replaces; paths are relative to
+ * the reference's finite_difference/src/ directory.
+ *
+ * Conventions
+ *   - all grid indices are 1-based and inclusive, exactly as in the Fortran;
+ *   - a field is a column-major array data(1:ld, 1:ny) of doubles
+ *     (field_mod.f90:350); element (ji,jj) lives at (jj-1)*ld + (ji-1);
+ *   - functions return 0 on success, a negative DLESM_E* code otherwise;
+ *     dlesm_last_error() gives the text.  Nothing falls back to the CPU:
+ *     device entry points fail with DLESM_ENODEV when there is no GPU.
+ *   - `stream` arguments are hipStream_t handles passed as void*; NULL is the
+ *     HIP null stream.  Device entry points are asynchronous on that stream
+ *     unless stated otherwise.
+ */
+#ifndef DLESM_HIP_H
+#define DLESM_HIP_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLESM_VERSION 100
+
+/* error codes */
+#define DLESM_OK 0
+#define DLESM_EINVAL (-1)   /* bad argument / shape mismatch              */
+#define DLESM_ENODEV (-2)   /* no usable HIP device                       */
+#define DLESM_EHIP (-3)     /* a HIP runtime call failed                  */
+#define DLESM_ERCCL (-4)    /* an RCCL call failed                        */
+#define DLESM_EABORT (-5)   /* the reference aborts (gocean_stop) here    */
+#define DLESM_ECOMMS (-12)  /* comm list overflow, parallel_comms_mod.f90:1223 */
+
+/* enumerations shared with the Fortran API (values are the reference's) */
+enum { DLESM_U_POINTS = 0, DLESM_V_POINTS = 1, DLESM_T_POINTS = 2,
+       DLESM_F_POINTS = 3, DLESM_ALL_POINTS = 4 };            /* field_mod.f90:47-52 */
+enum { DLESM_OFFSET_SW = 0, DLESM_OFFSET_SE = 1, DLESM_OFFSET_NW = 2,
+       DLESM_OFFSET_NE = 3, DLESM_OFFSET_ANY = 4 };           /* grid_mod.f90:52-60  */
+enum { DLESM_BC_PERIODIC = 0, DLESM_BC_EXTERNAL = 1, DLESM_BC_NONE = 2 }; /* grid_mod.f90:64-69 */
+/* halo-exchange direction codes, parallel_comms_mod.f90:101-110 */
+enum { DLESM_IPLUS = 1, DLESM_IMINUS = 2, DLESM_JPLUS = 3, DLESM_JMINUS = 4,
+       DLESM_IPLUSJPLUS = 5, DLESM_IMINUSJMINUS = 6, DLESM_IPLUSJMINUS = 7,
+       DLESM_IMINUSJPLUS = 8 };
+
+/* region_mod.f90:7-12 -- member order matches the Fortran type so that
+ * type(region_type) can be passed by reference. */
+typedef struct dlesm_region {
+    int nx, ny;
+    int xstart, xstop;
+    int ystart, ystop;
+} dlesm_region;
+
+/* decomposition_mod.f90:44-50 */
+typedef struct dlesm_subdomain {
+    dlesm_region global;   /* internal part in global coordinates; nx,ny = WHOLE extent */
+    dlesm_region internal; /* internal part in local coordinates                        */
+} dlesm_subdomain;
+
+/* scalar part of decomposition_mod.f90:54-68 */
+typedef struct dlesm_decomp {
+    int global_nx, global_ny; /* size of the decomposed domain        */
+    int nx, ny;               /* grid of subdomains                   */
+    int ndomains;
+    int max_width, max_height;
+} dlesm_decomp;
+
+#define DLESM_MAXCOMM 16 /* parallel_comms_mod.f90:70 */
+
+/* One rank's message lists: the public tables of parallel_comms_mod.f90:71-83,156-161.
+ * destination/source are 0-based ranks, coordinates are local 1-based. */
+typedef struct dlesm_comm_tables {
+    int nsend, nrecv;
+    int dirsend[DLESM_MAXCOMM], destination[DLESM_MAXCOMM];
+    int isrcsend[DLESM_MAXCOMM], jsrcsend[DLESM_MAXCOMM];
+    int idessend[DLESM_MAXCOMM], jdessend[DLESM_MAXCOMM];
+    int nxsend[DLESM_MAXCOMM], nysend[DLESM_MAXCOMM];
+    int dirrecv[DLESM_MAXCOMM], source[DLESM_MAXCOMM];
+    int isrcrecv[DLESM_MAXCOMM], jsrcrecv[DLESM_MAXCOMM];
+    int idesrecv[DLESM_MAXCOMM], jdesrecv[DLESM_MAXCOMM];
+    int nxrecv[DLESM_MAXCOMM], nyrecv[DLESM_MAXCOMM];
+} dlesm_comm_tables;
+
+/* ------------------------------------------------------------------------
+ * 1. Host-side index maps (no GPU needed; bit-exact with the reference)
+ * ---------------------------------------------------------------------- */
+
+/* grid_init's DL_ESM_ALIGNMENT block, grid_mod.f90:349-363: parse the
+ * environment variable.  *alignment = 1 when unset.  DLESM_EABORT when the
+ * reference would gocean_stop (more than 3 characters, not a positive int). */
+int dlesm_alignment_from_env(int *alignment);
+
+/* grid_mod.f90:364-385: allocated extents of every field on a subdomain whose
+ * whole size is sub_global_nx x sub_global_ny. */
+int dlesm_grid_extents(int sub_global_nx, int sub_global_ny, int alignment, int *nx, int *ny);
+
+/* set_field_bounds + c{u,v,t,f}_{sw,ne}_init + field_init, field_mod.f90:563-1122.
+ * DLESM_EABORT for the combinations on which the reference stops. */
+int dlesm_field_bounds(int grid_points, int offset, int bc_x, int bc_y,
+                       const dlesm_region *subdomain_internal, int grid_nx, int grid_ny,
+                       dlesm_region *internal, dlesm_region *whole);
+
+/* go_decompose, parallel_mod.f90:70-332.  ntilex,ntiley <= 0 selects the
+ * reference's automatic tiling.  subdomains must hold ndomains entries. */
+int dlesm_decompose(int domainx, int domainy, int ndomains, int ntilex, int ntiley,
+                    int halo_width, dlesm_decomp *decomp, dlesm_subdomain *subdomains);
+
+/* iprocmap, parallel_comms_mod.f90:1365-1398 (1-based owner, 0 if none) */
+int dlesm_iprocmap(const dlesm_decomp *decomp, const dlesm_subdomain *subdomains,
+                   int nranks, int ia, int ja);
+
+/* map_comms, parallel_comms_mod.f90:178-1172, for rank `rank1` (1-based, as
+ * get_rank() returns it, parallel_utils_mod.f90:84). */
+int dlesm_map_comms(const dlesm_decomp *decomp, const dlesm_subdomain *subdomains,
+                    int nranks, int rank1, dlesm_comm_tables *tables);
+
+/* ------------------------------------------------------------------------
+ * 2. Runtime
+ * ---------------------------------------------------------------------- */
+
+const char *dlesm_last_error(void);
+int dlesm_version(void);
+
+/* number of visible HIP devices (0 when there is none; never an error) */
+int dlesm_device_count(void);
+
+/* Bind this process to a device -- the HIP counterpart of
+ * acc_init(acc_device_nvidia) in gocean_initialise, gocean_mod.F90:31-33.
+ * Creates the library's side stream and events.  Idempotent. */
+int dlesm_init(int device);
+int dlesm_finalize(void);
+
+/* ------------------------------------------------------------------------
+ * 3. Device-resident fields and the reference's device-sync callbacks
+ * ---------------------------------------------------------------------- */
+
+/* What r2d_field%device_ptr (field_mod.f90:153) points at: an opaque
+ * descriptor that remembers the device buffer and its row stride, which the
+ * C-flavour callbacks below are not told. */
+typedef struct dlesm_field dlesm_field;
+
+/* allocate ld*ny doubles on the device and zero them (field_mod.f90:350,375) */
+int dlesm_field_create(int ld, int ny, dlesm_field **field);
+/* describe device memory owned by the caller (e.g. a torch tensor) */
+int dlesm_field_wrap(void *device_data, int ld, int ny, dlesm_field **field);
+int dlesm_field_destroy(dlesm_field *field);
+double *dlesm_field_data(const dlesm_field *field); /* raw device pointer */
+int dlesm_field_ld(const dlesm_field *field);
+int dlesm_field_ny(const dlesm_field *field);
+
+/* read_from_device_c_interface / write_to_device_c_interface,
+ * field_mod.f90:65-73 and 86-94, with exactly that argument list:
+ *   read : from = device_ptr (dlesm_field*), to = C_LOC(host data)
+ *   write: from = C_LOC(host data),          to = device_ptr (dlesm_field*)
+ * startx,starty are 1-based, nx,ny the extent of the patch.  Assign them to
+ * fld%read_from_device_c / fld%write_to_device_c.  Errors abort the process
+ * (the reference's error model: gocean_stop, gocean_mod.F90:50-57). */
+void dlesm_read_from_device(void *from, void *to, int startx, int starty, int nx, int ny,
+                            bool blocking);
+void dlesm_write_to_device(void *from, void *to, int startx, int starty, int nx, int ny,
+                           bool blocking);
+/* wait for non-blocking transfers issued by the two callbacks */
+int dlesm_transfer_sync(void);
+
+/* ------------------------------------------------------------------------
+ * 4. Kernels over a 1-based inclusive index box (the PSy-layer loop nest
+ *    `do jj = ystart,ystop ; do ji = xstart,xstop ; call kern_code(ji,jj,...)`,
+ *    form: infrastructure_mod.f90:32-41, bounds: field_mod.f90:116-119).
+ *    Raw device pointers; ld,ny describe every array passed.
+ * ---------------------------------------------------------------------- */
+
+/* out(ji,jj) = 0.25*((in(ji-1,jj)+in(ji+1,jj)) + (in(ji,jj-1)+in(ji,jj+1))) */
+int dlesm_stencil5_f64(const double *in, double *out, int ld, int ny,
+                       int xstart, int xstop, int ystart, int ystop, void *stream);
+
+/* Shallow-water u/v/h update: reads u,v,p (3x3 footprint)
+ * and uold,vold,pold, writes unew,vnew,pnew on the box. */
+typedef struct dlesm_sw_params {
+    double fsdx, fsdy;            /* 4/dx, 4/dy            */
+    double tdts8, tdtsdx, tdtsdy; /* tdt/8, tdt/dx, tdt/dy */
+} dlesm_sw_params;
+int dlesm_shallow_step_f64(const dlesm_sw_params *params, int ld, int ny,
+                           int xstart, int xstop, int ystart, int ystop,
+                           const double *u, const double *v, const double *p,
+                           const double *uold, const double *vold, const double *pold,
+                           double *unew, double *vnew, double *pnew, void *stream);
+
+/* field_copy_code over a box (infrastructure_mod.f90:32-41) and the patch copy
+ * used for periodic boundaries (copy_2dfield_patch, field_mod.f90:1179-1187):
+ * dst(dx0.., dy0..) = src(sx0.., sy0..) for an nx x ny patch. */
+int dlesm_copy_patch_f64(const double *src, double *dst, int ld, int ny_arr,
+                         int sx0, int sy0, int dx0, int dy0, int nx, int ny, void *stream);
+/* set_field, field_mod.f90:1191-1202, restricted to a box */
+int dlesm_fill_f64(double *f, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                   double value, void *stream);
+/* array_checksum's local part, SUM(ABS(f(xs:xe,ys:ye))), field_mod.f90:1298-1302.
+ * Synchronous: returns the value in *result (host). Deterministic tree order. */
+int dlesm_checksum_f64(const double *f, int ld, int ny, int xstart, int xstop,
+                       int ystart, int ystop, double *result, void *stream);
+/* synthetic initial condition of BASELINE.md: f(i,j) = u01(splitmix64(seed ^ (gi + gj<<32)))
+ * on the box, gi = gx0+i-1, gj = gy0+j-1; cells outside the box are left alone. */
+int dlesm_hash_init_f64(double *f, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                        uint64_t seed, int64_t gx0, int64_t gy0, void *stream);
+
+/* kernel tuning knobs ("j5_rows", "j5_variant", ...) for benchmarking; returns previous value */
+int dlesm_set_tuning(const char *key, int value);
+
+/* ------------------------------------------------------------------------
+ * 5. Device-resident halo exchange over RCCL
+ *    (replaces r2d_field%halo_exchange -> exchange_generic,
+ *     field_mod.f90:1231-1256, parallel_comms_mod.f90:1501-1855, and the
+ *     MPI calls of parallel/parallel_utils_mod.f90:148-183)
+ * ---------------------------------------------------------------------- */
+
+#define DLESM_UNIQUE_ID_BYTES 128
+/* rank 0 creates the id, the host program distributes it (file, MPI, torch store ...) */
+int dlesm_comm_unique_id(void *id /* DLESM_UNIQUE_ID_BYTES */);
+/* parallel_init, parallel_utils_mod.f90:77-90: rank0 is 0-based here */
+int dlesm_comm_init(const void *id, int nranks, int rank0);
+int dlesm_comm_finalize(void);
+int dlesm_comm_rank(void);   /* 0-based, -1 before init */
+int dlesm_comm_size(void);
+
+/* Message plan for fields of shape (ld, ny): device copy of the tables, pack
+ * buffers for the strided (east/west) strips.  One plan serves every field of
+ * that shape (all dl_esm_inf fields share the grid's extents, field_mod.f90:327-333). */
+typedef struct dlesm_halo_plan dlesm_halo_plan;
+int dlesm_halo_plan_create(const dlesm_comm_tables *tables, int ld, int ny,
+                           dlesm_halo_plan **plan);
+int dlesm_halo_plan_destroy(dlesm_halo_plan *plan);
+
+/* halo_exchange(depth=1) of one device field: pack -> grouped ncclSend/ncclRecv
+ * -> unpack, all enqueued on `stream`.  dirs_mask selects the enabled edge
+ * directions (bit d-1 for DLESM_IPLUS..DLESM_JMINUS); diagonals are enabled
+ * when both their edges are, parallel_comms_mod.f90:1557-1571.  0 means all. */
+int dlesm_halo_exchange_f64(dlesm_halo_plan *plan, double *field, unsigned dirs_mask,
+                            void *stream);
+
+/* One distributed Jacobi time step with the exchange hidden behind the
+ * interior: frame(out) on `stream`, then [exchange(out) on the library's side
+ * stream] || [interior(out) on `stream`], joined on `stream`.  On return
+ * (asynchronously) `out` holds the new values AND valid depth-1 halos, i.e. it
+ * is ready to be the `in` of the next step.  `in` must have valid halos. */
+int dlesm_jacobi5_step_dm(dlesm_halo_plan *plan, const double *in, double *out,
+                          int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                          void *stream);
+
+/* global_sum, parallel_utils_mod.f90:230-238: in-place sum of one host double
+ * over all ranks (synchronous). */
+int dlesm_global_sum_f64(double *value);
+/* gather, parallel_utils_mod.f90:242-255: n doubles per rank (device memory)
+ * -> n*nranks doubles on rank 0 (device memory). Synchronous. */
+int dlesm_gather_f64(const double *send, double *recv, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLESM_HIP_H */

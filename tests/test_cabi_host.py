@@ -1,0 +1,209 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/dlesm_hip.h declares,
+and its host-side index maps (extents, bounds, decomposition, message tables) are bit-exact
+with the reference goldens and with the oracle.  No device compute is called here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_cases as R
+from conftest import ROOT, load_golden
+
+import dl_esm_inf_amd as D
+from dl_esm_inf_amd import _cabi
+
+L = _cabi.lib()
+
+
+# --------------------------------------------------------------------------- the boundary
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "dlesm_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dlesm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _header_symbols()
+    assert len(syms) >= 35
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _cabi.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    missing = [s for s in syms if s not in exported]
+    assert not missing, missing
+    # and the ctypes binding covers exactly the header
+    assert sorted(_cabi.PROTOTYPES) == syms
+    assert L.dlesm_version() == 100
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_cabi.Region) == 24 and C.sizeof(_cabi.Subdomain) == 48
+    assert C.sizeof(_cabi.Decomp) == 28
+    assert C.sizeof(_cabi.CommTables) == 4 * (2 + 16 * 16)
+    assert C.sizeof(_cabi.SwParams) == 40
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    if L.dlesm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    a = np.zeros((8, 8))
+    rc = L.dlesm_stencil5_f64(a.ctypes.data, a.ctypes.data, 8, 8, 2, 7, 2, 7, None)
+    assert rc == _cabi.ENODEV
+    assert b"no HIP device" in L.dlesm_last_error()
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    D.parallel_init(0, 1)
+    g.decompose(8, 8)
+    D.grid_init(g, 1.0, 1.0)
+    with pytest.raises(D.DlesmError):
+        D.r2d_field(g, D.GO_T_POINTS)
+
+
+def test_product_never_touches_the_oracle():
+    """the shipped package must not import, link or open anything under oracle/"""
+    pkg = os.path.join(ROOT, "dl_esm_inf_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if os.sep + "lib" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".f90", ".F90", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in txt and "dlesm_oracle" not in txt and "oracle_lib" not in txt, \
+                    os.path.join(dirpath, f)
+    needed = subprocess.check_output(["readelf", "-d", _cabi.LIB_PATH], text=True)
+    assert "oracle" not in needed
+
+
+# --------------------------------------------------------------------------- alignment env
+@pytest.mark.parametrize("val,want", [(None, 1), ("1", 1), ("8", 8), ("64", 64), ("128", 128),
+                                      (" 16", 16), ("16 ", 16), ("999", 999), ("+4", 4)])
+def test_alignment_env_ok(monkeypatch, val, want):
+    if val is None:
+        monkeypatch.delenv("DL_ESM_ALIGNMENT", raising=False)
+    else:
+        monkeypatch.setenv("DL_ESM_ALIGNMENT", val)
+    a = C.c_int(-1)
+    assert L.dlesm_alignment_from_env(C.byref(a)) == 0
+    assert a.value == want
+
+
+@pytest.mark.parametrize("val", ["0", "-8", "abc", "1024", "8x", ""])
+def test_alignment_env_aborts_like_reference(monkeypatch, val):
+    """grid_mod.f90:353-362: >3 characters, non-numeric or < 1 is fatal"""
+    monkeypatch.setenv("DL_ESM_ALIGNMENT", val)
+    a = C.c_int(-1)
+    assert L.dlesm_alignment_from_env(C.byref(a)) == _cabi.EABORT
+    assert b"DL_ESM_ALIGNMENT" in L.dlesm_last_error()
+
+
+# --------------------------------------------------------------------------- goldens
+@pytest.mark.parametrize("case", load_golden("ref_decomp")["cases"],
+                         ids=lambda c: f"{c['domainx']}x{c['domainy']}n{c['ndomains']}")
+def test_go_decompose_matches_reference(case):
+    d = D.go_decompose(case["domainx"], case["domainy"], ndomains=case["ndomains"])
+    assert [d.global_nx, d.global_ny, d.nx, d.ny, d.ndomains, d.max_width, d.max_height] == \
+           [case["global_nx"], case["global_ny"], case["nx"], case["ny"], case["ndom_out"],
+            case["max_width"], case["max_height"]]
+    assert [s.glob.as6() + s.internal.as6() for s in d.subdomains] == case["subdomains"]
+
+
+def test_extents_and_bounds_match_reference(monkeypatch):
+    """grid_type/decompose/grid_init/r2d_field bounds through the Python mirror, i.e. through
+    the same C-ABI calls the Fortran layer makes"""
+    D.parallel_init(0, 1)
+    n_abort = 0
+    for c in load_golden("ref_bounds")["cases"]:
+        if c["alignment"] is None:
+            monkeypatch.delenv("DL_ESM_ALIGNMENT", raising=False)
+        else:
+            monkeypatch.setenv("DL_ESM_ALIGNMENT", str(c["alignment"]))
+        g = D.grid_type(D.GO_ARAKAWA_C, (c["bcx"], c["bcy"], D.GO_BC_NONE), c["offset"])
+        g.decompose(c["nx"], c["ny"])
+        D.grid_init(g, 1.0, 1.0)
+        assert [g.nx, g.ny, g.global_nx, g.global_ny] == c["grid"]
+        try:
+            internal, whole = D.field_mod.field_bounds(g, c["ptype"])
+        except D.GoceanStop as e:
+            assert c["abort"], (c, str(e))
+            n_abort += 1
+            continue
+        assert not c["abort"], c
+        assert internal.as6() == c["internal"] and whole.as6() == c["whole"], c
+    assert n_abort == 180
+
+
+def test_user_tiling_and_bad_arguments():
+    d = D.go_decompose(12, 9, ndomainx=3, ndomainy=2)
+    assert (d.nx, d.ny, d.ndomains) == (3, 2, 6)
+    with pytest.raises(D.GoceanStop):
+        D.go_decompose(12, 9, ndomainx=3)                    # parallel_mod.f90:120-122
+    info, subs = _cabi.Decomp(), (_cabi.Subdomain * 4)()
+    assert L.dlesm_decompose(10, 10, 4, 3, 2, 1, C.byref(info), subs) == _cabi.EINVAL
+    assert L.dlesm_decompose(0, 10, 4, 0, 0, 1, C.byref(info), subs) == _cabi.EINVAL
+
+
+# --------------------------------------------------------------------------- vs the oracle
+def _tables_equal(t, c):
+    if (t.nsend, t.nrecv) != (c.nsend, c.nrecv):
+        return False
+    return t.sends() == c.sends() and t.recvs() == c.recvs()
+
+
+MESHES = R.HALO_CASES + R.GSUM_CASES + [(16, 32, 8), (32, 16, 8), (13, 13, 9), (64, 64, 16),
+                                        (100, 37, 7), (37, 100, 7), (12, 9, 5), (7, 5, 2),
+                                        (16384, 32768, 8), (31, 29, 12), (9, 50, 10), (50, 9, 3)]
+
+
+@pytest.mark.parametrize("nx,ny,nranks", MESHES)
+def test_map_comms_bit_exact_with_oracle(nx, ny, nranks):
+    """the mesh-first table builder must reproduce the reference's border-scan tables, entry for
+    entry and in the same order, for every rank"""
+    od, osubs = O.decompose(nx, ny, nranks)
+    d = D.go_decompose(nx, ny, ndomains=nranks)
+    assert [s.glob.as6() + s.internal.as6() for s in d.subdomains] == \
+           [s.glob.as6() + s.internal.as6() for s in osubs]
+    for r in range(1, nranks + 1):
+        t = D.map_comms(d, rank1=r, nranks=nranks)
+        c = O.map_comms(od, osubs, nranks, r)
+        assert _tables_equal(t, c), (r, t.sends(), c.sends(), t.recvs(), c.recvs())
+        # unset slots carry the reference's -999 sentinel
+        assert all(t.dirsend[k] == -999 for k in range(t.nsend, 16))
+    # iprocmap agrees on a sample of points including outside the domain
+    rng = np.random.default_rng(nx * 131 + ny)
+    for _ in range(200):
+        ia, ja = int(rng.integers(-1, nx + 3)), int(rng.integers(-1, ny + 3))
+        assert L.dlesm_iprocmap(C.byref(d._info), d.subdomains, nranks, ia, ja) == \
+               O.lib().orc_iprocmap(C.byref(od), osubs, nranks, ia, ja)
+
+
+def test_map_comms_matches_survey_probe():
+    g = load_golden("survey_probe_mapcomms")
+    d = D.go_decompose(g["domainx"], g["domainy"], ndomains=g["nranks"])
+    t1 = D.map_comms(d, rank1=1, nranks=8)
+    for got, want in zip(t1.sends(), g["rank1"]["sends"]):
+        assert {k: got[k] for k in want} == want
+    for got, want in zip(t1.recvs(), g["rank1"]["recvs"]):
+        assert {k: got[k] for k in want} == want
+    t4 = D.map_comms(d, rank1=4, nranks=8)
+    assert [[s["nx"], s["ny"]] for s in t4.sends()] == g["rank4"]["send_shapes"]
+
+
+def test_map_comms_rejects_what_it_cannot_represent():
+    d = D.go_decompose(10, 10, ndomains=4)
+    t = _cabi.CommTables()
+    assert L.dlesm_map_comms(C.byref(d._info), d.subdomains, 3, 1, C.byref(t)) == _cabi.EINVAL
+    assert L.dlesm_map_comms(C.byref(d._info), d.subdomains, 4, 5, C.byref(t)) == _cabi.EINVAL
+    d.subdomains[1].glob.xstart += 1            # no longer a tile mesh
+    assert L.dlesm_map_comms(C.byref(d._info), d.subdomains, 4, 1, C.byref(t)) == _cabi.EINVAL
+
+
+def test_grid_extents_random_vs_oracle():
+    rng = np.random.default_rng(7)
+    for _ in range(500):
+        n, m = int(rng.integers(1, 40000)), int(rng.integers(1, 40000))
+        a = int(rng.choice([0, 1, 2, 3, 8, 16, 64, 128, 999]))
+        nx, ny = C.c_int(), C.c_int()
+        assert L.dlesm_grid_extents(n, m, a, C.byref(nx), C.byref(ny)) == 0
+        assert (nx.value, ny.value) == O.grid_extents(n, m, a)
+        assert nx.value % max(a, 1) == 0 and nx.value > n

@@ -1,0 +1,346 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs; bit-exact wherever the arithmetic allows it.
+
+Tolerance stated by the north star: 1e-12 relative for fp64 field values.  The Jacobi and
+shallow-water kernels evaluate the same expression tree as the oracle with FMA contraction off
+on both sides, so they are additionally required to agree bit for bit.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_cases as R
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20261004
+
+
+@pytest.fixture(scope="module")
+def D():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    import dl_esm_inf_amd as d
+    torch.cuda.set_device(0)
+    d.parallel_init(0, 1)
+    return d
+
+
+def _grid(D, nx, ny, alignment=None, offset=None, bc=(1, 1, 2)):
+    if alignment is None:
+        os.environ.pop("DL_ESM_ALIGNMENT", None)
+    else:
+        os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, bc, D.GO_OFFSET_NE if offset is None else offset)
+    g.decompose(nx, ny)
+    D.grid_init(g, 1.0, 1.0)
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+    return g
+
+
+def _set_tuning(D, **kw):
+    for k, v in kw.items():
+        D._cabi.lib().dlesm_set_tuning(k.encode(), v)
+
+
+# --------------------------------------------------------------------------- init kernel
+def test_hash_init_matches_oracle(D):
+    g = _grid(D, 100, 37, 8)
+    f = D.r2d_field(g, D.GO_T_POINTS)
+    D.psy.hash_init(f, SEED)
+    w = f.whole
+    want = O.hash_field(SEED, g.ny, g.nx, 1, 1, w.xstart, w.xstop, w.ystart, w.ystop)
+    assert np.array_equal(f.get_data(), want)
+
+
+# --------------------------------------------------------------------------- Jacobi-5
+JACOBI_CASES = [
+    # (nx, ny, alignment)  -> even/odd leading dimension, tiny, ragged, multi-block
+    (4, 10, None), (10, 4, None), (1, 1, None), (2, 3, 2), (5, 5, 8), (64, 64, None), (64, 64, 64),
+    (61, 67, None), (61, 67, 2), (255, 130, 64), (256, 256, None), (511, 70, 4), (1021, 33, 64),
+    (1500, 200, 64), (1500, 200, None), (4096, 300, 64),
+]
+
+
+@pytest.mark.parametrize("nx,ny,alignment", JACOBI_CASES)
+@pytest.mark.parametrize("variant,rows", [(0, 64), (1, 7), (2, 16), (3, 5), (4, 64)])
+def test_jacobi5_bit_exact(D, nx, ny, alignment, variant, rows):
+    _set_tuning(D, j5_variant=variant, j5_rows=rows)
+    try:
+        g = _grid(D, nx, ny, alignment)
+        a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+        D.psy.hash_init(a, SEED)
+        D.set_field(b, -7.0)
+        D.psy.invoke_jacobi5(b, a)
+        hin, got = a.get_data(), b.get_data()
+        want = np.full_like(hin, -7.0)
+        it = b.internal
+        O.jacobi5(hin, want, g.nx, it.xstart, it.xstop, it.ystart, it.ystop)
+        # bit-exact, including every cell outside the box being left alone
+        assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    finally:
+        _set_tuning(D, j5_variant=0, j5_rows=64)
+
+
+def test_jacobi5_sub_boxes_and_empty(D):
+    """arbitrary PSy boxes (what the frame/interior split uses), incl. zero-trip loops"""
+    g = _grid(D, 300, 90, 64)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    D.psy.hash_init(a, SEED)
+    hin = a.get_data()
+    L = D._cabi.lib()
+    for box in [(3, 300, 3, 90), (2, 2, 2, 91), (17, 18, 40, 40), (129, 257, 2, 91), (301, 301, 91, 91),
+                (5, 4, 2, 91), (2, 301, 9, 8)]:
+        D.set_field(b, 3.0)
+        D._cabi.check(L.dlesm_stencil5_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *box, None))
+        want = np.full_like(hin, 3.0)
+        O.jacobi5(hin, want, g.nx, *box)
+        assert np.array_equal(b.get_data(), want), box
+
+
+def test_jacobi5_rejects_bad_shapes(D):
+    g = _grid(D, 32, 32)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    L = D._cabi.lib()
+    E = D._cabi.EINVAL
+    assert L.dlesm_stencil5_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, 1, 33, 2, 33, None) == E
+    assert L.dlesm_stencil5_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, 2, g.nx, 2, 33, None) == E
+    assert L.dlesm_stencil5_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, 2, 33, 2, g.ny, None) == E
+    assert L.dlesm_stencil5_f64(a.device_ptr, a.device_ptr, g.nx, g.ny, 2, 33, 2, 33, None) == E
+    assert L.dlesm_stencil5_f64(None, b.device_ptr, g.nx, g.ny, 2, 33, 2, 33, None) == E
+
+
+def test_jacobi5_ten_steps_golden(D):
+    """64x64, 10 ping-pong steps against the committed golden checksums (generated from the
+    oracle by tests/golden/make_stencil_golden.py)"""
+    gold = load_golden("jacobi5_64")
+    g = _grid(D, 64, 64)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    D.psy.hash_init(a, SEED)
+    D.copy_field(a, b)
+    for step in range(1, 11):
+        D.psy.invoke_jacobi5(b, a)
+        a, b = b, a
+        if str(step) in gold["checksums"]:
+            cs = D.field_checksum(a)
+            want = gold["checksums"][str(step)]
+            assert abs(cs - want) <= 1e-12 * abs(want), (step, cs, want)
+    h = a.get_data()
+    for (j, i, v) in gold["samples"]:
+        assert h[j - 1, i - 1] == v
+
+
+@pytest.mark.parametrize("n,alignment", [(4096, 64), (16384, 64), (16384, None)])
+def test_jacobi5_full_size_properties(D, n, alignment):
+    """BASELINE sizes: (i) a constant field is a fixed point, exactly; (ii) sampled rows and
+    the four edge rows/columns agree bit for bit with the oracle run on 3-row slabs;
+    (iii) out's boundary ring is untouched"""
+    import torch
+    g = _grid(D, n, n, alignment)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = b.internal
+    D.set_field(a, 1.5)
+    D.set_field(b, -1.0)
+    D.psy.invoke_jacobi5(b, a)
+    inner = b.data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop]
+    assert bool((inner == 1.5).all())
+    assert float(b.data.sum().item()) == 1.5 * n * n - 1.0 * (g.nx * g.ny - n * n)
+    D.psy.hash_init(a, SEED)
+    D.psy.invoke_jacobi5(b, a)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(n)
+    rows = sorted(set([it.ystart, it.ystart + 1, it.ystop - 1, it.ystop] +
+                      [int(r) for r in rng.integers(it.ystart, it.ystop + 1, 24)]))
+    for jj in rows:
+        slab = a.data[jj - 2:jj + 1, :].cpu().numpy()            # rows jj-1, jj, jj+1
+        want = np.full_like(slab, -1.0)
+        O.jacobi5(slab, want, g.nx, it.xstart, it.xstop, 2, 2)
+        got = b.data[jj - 1, :].cpu().numpy()
+        assert np.array_equal(got, want[1]), jj
+    assert bool((b.data[0, :] == -1.0).all()) and bool((b.data[it.ystop:, :] == -1.0).all())
+    assert bool((b.data[:, 0] == -1.0).all()) and bool((b.data[:, it.xstop:] == -1.0).all())
+
+
+# --------------------------------------------------------------------------- checksum / fill / copy
+@pytest.mark.parametrize("nx,ny,alignment", [(4, 10, None), (256, 256, None), (1000, 333, 64)])
+def test_checksum_matches_oracle(D, nx, ny, alignment):
+    g = _grid(D, nx, ny, alignment)
+    f = D.r2d_field(g, D.GO_T_POINTS)
+    D.psy.hash_init(f, SEED)
+    f.data.sub_(0.5)                                   # mixed signs so that ABS matters
+    it = f.internal
+    want = O.lib().orc_checksum(f.get_data(), g.nx, it.xstart, it.xstop, it.ystart, it.ystop)
+    got = D.field_checksum(f)
+    assert abs(got - want) <= 1e-12 * abs(want)
+
+
+def test_config1_plumbing_matches_reference_golden(D):
+    """BASELINE config 0: the reference example scaled to 256x256, checksum exactly 65536"""
+    for m in load_golden("ref_model")["model"]:
+        g = _grid(D, m["nx"], m["ny"])
+        t = D.r2d_field(g, D.GO_T_POINTS)
+        assert [g.nx, g.ny] == m["grid"][:2] and list(t.internal.box()) == m["internal"]
+        D.set_field(t, m["fill"])
+        t.halo_exchange(1)
+        assert D.field_checksum(t) == m["checksum"]
+    # the reference's own example: four fields filled with the rank, 4x10 -> 40.0 each
+    ex = load_golden("ref_model")["example_4x10"]
+    g = _grid(D, 4, 10)
+    for name, pt in (("U", D.GO_U_POINTS), ("V", D.GO_V_POINTS), ("T", D.GO_T_POINTS), ("F", D.GO_F_POINTS)):
+        f = D.r2d_field(g, pt)
+        D.set_field(f, float(D.get_rank()))
+        f.halo_exchange(1)
+        assert D.field_checksum(f) == ex[name]
+
+
+def test_scatter_gather_matches_reference_golden(D):
+    for m in load_golden("ref_model")["gather"]:
+        g = _grid(D, m["nx"], m["ny"])
+        glob = R.unique_global(m["nx"], m["ny"])
+        t = D.r2d_field(g, D.GO_T_POINTS, init_global_data=glob)
+        h = t.get_data()
+        assert [h[0, 0], h[1, 1], h[m["ny"], m["nx"]], h[m["ny"] + 1, m["nx"] + 1]] == m["corner"]
+        assert D.field_checksum(t) == m["checksum"]
+        back = t.gather_inner_data()
+        assert list(back.shape[::-1]) == m["gather_shape"] and np.array_equal(back, glob)
+
+
+def test_copy_patch_periodic_halos(D):
+    """the periodic-BC halo copies (field_mod.f90:1394-1464) done with the device patch copy,
+    regions taken from the reference golden for SW-offset periodic T fields"""
+    case = next(c for c in load_golden("ref_bounds")["cases"]
+                if c["offset"] == 0 and c["bcx"] == 0 and c["bcy"] == 0 and c["ptype"] == 2
+                and c["nx"] == 10 and c["ny"] == 10 and c["alignment"] == 8)
+    g = _grid(D, 10, 10, 8, offset=D.GO_OFFSET_SW, bc=(0, 0, 2))
+    f = D.r2d_field(g, D.GO_T_POINTS)
+    D.psy.hash_init(f, SEED)
+    want = f.get_data()
+    Reg = D._cabi.Region
+    for h in case["halos"]:
+        src = Reg(xstart=h[0], xstop=h[1], ystart=h[2], ystop=h[3])
+        dst = Reg(xstart=h[4], xstop=h[5], ystart=h[6], ystop=h[7])
+        D.copy_field(f, src=src, dest=dst)
+        want[dst.ystart - 1:dst.ystop, dst.xstart - 1:dst.xstop] = \
+            want[src.ystart - 1:src.ystop, src.xstart - 1:src.xstop].copy()
+    assert np.array_equal(f.get_data(), want)
+
+
+# --------------------------------------------------------------------------- B1: sync callbacks
+def test_device_io_callbacks_match_reference_test(D):
+    """tests/device_computation/test_device_io.f90 replayed against the real device through the
+    two C-flavour callbacks, compared with the array the reference test prints"""
+    import torch
+    L = D._cabi.lib()
+    for run in load_golden("ref_device_io")["runs"]:
+        g = _grid(D, 5, 5, run["alignment"])
+        ld, ny = g.nx, g.ny
+        assert (ld, ny) == (8, 8)
+        fld = C.c_void_p()
+        D._cabi.check(L.dlesm_field_create(ld, ny, C.byref(fld)))
+        host = np.zeros((ny, ld))
+        L.dlesm_write_to_device(host.ctypes.data, fld, 1, 1, ld, ny, True)      # all zeros
+        host[:] = 1.0
+        L.dlesm_write_to_device(host.ctypes.data, fld, 2, 2, 5, 5, True)        # 5x5 block of ones
+        dev = L.dlesm_field_data(fld)
+        t = C.c_void_p()
+        D._cabi.check(L.dlesm_field_wrap(dev, ld, ny, C.byref(t)))              # "device computation": x2
+        assert L.dlesm_field_ld(t) == ld and L.dlesm_field_ny(t) == ny
+        tmp = np.zeros((ny, ld))
+        L.dlesm_read_from_device(t, tmp.ctypes.data, 1, 1, ld, ny, True)
+        tmp *= 2.0
+        L.dlesm_write_to_device(tmp.ctypes.data, t, 1, 1, ld, ny, False)
+        D._cabi.check(L.dlesm_transfer_sync())
+        L.dlesm_read_from_device(fld, host.ctypes.data, 5, 5, 4, 4, True)       # bottom-right quadrant
+        assert host.tolist() == run["rows"]
+        D._cabi.check(L.dlesm_field_destroy(t))
+        D._cabi.check(L.dlesm_field_destroy(fld))
+    torch.cuda.synchronize()
+
+
+# --------------------------------------------------------------------------- halo exchange (loop-back)
+def test_halo_exchange_loopback_on_one_gpu(D):
+    """RCCL send/recv path on a single GPU: a hand-made table in which rank 0 sends its east
+    column / north row / NE corner to ITSELF as west / south / SW halos (periodic wrap), checked
+    against the oracle's exchange on the same tables."""
+    import torch
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    g = _grid(D, 37, 23, 8)
+    f = D.r2d_field(g, D.GO_T_POINTS)
+    D.psy.hash_init(f, SEED)
+    it = f.internal
+    t = D._cabi.CommTables()
+    msgs = [  # dir, isrc, jsrc, ides, jdes, nx, ny
+        (2, it.xstop, it.ystart, it.xstart - 1, it.ystart, 1, it.ny),    # E col -> W halo
+        (1, it.xstart, it.ystart, it.xstop + 1, it.ystart, 1, it.ny),                     # W col -> E halo
+        (4, it.xstart, it.ystop, it.xstart, it.ystart - 1, it.nx, 1),                     # N row -> S halo
+        (3, it.xstart, it.ystart, it.xstart, it.ystop + 1, it.nx, 1),                     # S row -> N halo
+        (6, it.xstop, it.ystop, it.xstart - 1, it.ystart - 1, 1, 1),                      # NE cell -> SW halo
+    ]
+    t.nsend = t.nrecv = len(msgs)
+    for k, (d_, isrc, jsrc, ides, jdes, nx, ny) in enumerate(msgs):
+        t.dirsend[k] = t.dirrecv[k] = d_
+        t.destination[k] = t.source[k] = 0
+        t.isrcsend[k], t.jsrcsend[k], t.idessend[k], t.jdessend[k] = isrc, jsrc, ides, jdes
+        t.nxsend[k], t.nysend[k] = nx, ny
+        t.isrcrecv[k], t.jsrcrecv[k], t.idesrecv[k], t.jdesrecv[k] = isrc, jsrc, ides, jdes
+        t.nxrecv[k], t.nyrecv[k] = nx, ny
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    want = f.get_data()
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    assert O.exchange_all([want], [g.nx], [oc]) == 0
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        D._cabi.check(L.dlesm_halo_exchange_f64(plan, f.device_ptr, 0, C.c_void_p(s.cuda_stream)))
+    s.synchronize()
+    assert np.array_equal(f.get_data(), want)
+    # distributed step on the same plan == plain stencil followed by the exchange of `out`
+    a, b, c = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    D.psy.hash_init(a, SEED + 1)
+    D._cabi.check(L.dlesm_jacobi5_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), None))
+    D.psy.invoke_jacobi5(c, a)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, c.device_ptr, 0, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(b.get_data(), c.get_data())
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+# --------------------------------------------------------------------------- shallow water
+@pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (64, 48, 8), (300, 70, 64), (257, 129, None)])
+def test_shallow_step_matches_oracle(D, nx, ny, alignment):
+    import torch
+    g = _grid(D, nx, ny, alignment)
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    F = {n: D.r2d_field(g, pts[n[0]]) for n in names}
+    for k, n in enumerate(names[:6]):
+        D.psy.hash_init(F[n], SEED + k)
+        if n[0] == "p":
+            F[n].data.add_(1.0)               # p in [1,2)
+        else:
+            F[n].data.sub_(0.5)               # u,v in [-0.5,0.5)
+    for n in names[6:]:
+        D.set_field(F[n], 9.0)
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
+    D.psy.invoke_shallow_step(prm, *[F[n] for n in names])
+    torch.cuda.synchronize()
+    H = {n: F[n].get_data() for n in names}
+    want = {n: np.full_like(H["u"], 9.0) for n in names[6:]}
+    scratch = [np.zeros_like(H["u"]) for _ in range(4)]
+    op = O.SwParams(prm.fsdx, prm.fsdy, prm.tdts8, prm.tdtsdx, prm.tdtsdy)
+    it = F["p"].internal
+    O.lib().orc_sw_step(C.byref(op), g.nx, it.xstart, it.xstop, it.ystart, it.ystop,
+                        H["u"], H["v"], H["p"], H["uold"], H["vold"], H["pold"], *scratch,
+                        want["unew"], want["vnew"], want["pnew"])
+    for n in names[6:]:
+        got = H[n]
+        err = np.max(np.abs(got - want[n]) / np.maximum(np.abs(want[n]), 1e-300))
+        assert err <= 1e-12, (n, err)
+        assert np.array_equal(got, want[n]), (n, "not bit-exact", err)
