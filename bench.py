@@ -50,14 +50,18 @@ def cpu_baseline(host_in, ld, box, budget_s):
     import oracle_lib as O
     xs, xe, ys, ye = box
     cells = (xe - xs + 1) * (ye - ys + 1)
-    out = np.zeros_like(host_in)
-    threads = max(1, min(O.lib().orc_max_threads(), os.cpu_count() or 1))
+    threads = min(O.host_threads(), int(os.environ.get("DLESM_CPU_THREADS", "16")))
     res = {}
     for label, nthr, share in (("all", threads, 0.6), ("one", 1, 0.4)):
-        O.jacobi5(host_in, out, ld, xs, xe, ys, ye, threads=nthr)       # first touch / warm
+        # fresh pages, first touched by the threads that will stream them
+        src, out = np.empty_like(host_in), np.empty_like(host_in)
+        O.lib().orc_copy_rows_omp(src, host_in, ld, host_in.shape[0], nthr)
+        O.lib().orc_copy_rows_omp(out, host_in, ld, host_in.shape[0], nthr)
+        host_in_t = src
+        O.jacobi5(host_in_t, out, ld, xs, xe, ys, ye, threads=nthr)     # warm
         t0, sweeps = time.perf_counter(), 0
         while True:
-            O.jacobi5(host_in, out, ld, xs, xe, ys, ye, threads=nthr)
+            O.jacobi5(host_in_t, out, ld, xs, xe, ys, ye, threads=nthr)
             sweeps += 1
             dt = time.perf_counter() - t0
             if dt > budget_s * share or sweeps >= 50:

@@ -88,11 +88,18 @@ __device__ __forceinline__ void jacobi_row(const Vec<VEC> &south, const Vec<VEC>
 
 // x0..x1, y0..y1: 0-based inclusive interior box.  c_first: first chunk holding an
 // interior column.  nxb: blocks per strip.  rows: strip height.
-template <int VEC, int U, bool NT>
+//
+// PIPE: register double buffering.  The loads of group g+1 are ISSUED before the
+// stores of group g: vmcnt retires loads and stores in issue order, so a wave that
+// issues its next loads only after its stores cannot consume them until those stores
+// have been acknowledged, and streams in bursts.  flags bit0 (diagnostic builds of a
+// profile run only): skip the two edge loads, to price them -- results are then wrong
+// at wave boundaries.
+template <int VEC, int U, bool NT, bool PIPE>
 __global__ __launch_bounds__(256) void jacobi5_march(const double *__restrict__ in,
                                                      double *__restrict__ out, int ld, int x0,
                                                      int x1, int y0, int y1, int c_first, int nxb,
-                                                     int rows, int serpentine)
+                                                     int rows, int flags)
 {
     const int bx = blockIdx.x % nxb, by = blockIdx.x / nxb;
     const int lane = threadIdx.x & 63;
@@ -109,58 +116,184 @@ __global__ __launch_bounds__(256) void jacobi5_march(const double *__restrict__ 
     int ecol = -1;
     if (lane == 0 && m0) ecol = c * VEC - 1;
     if (lane == 63 && (VEC == 2 ? m1 : m0)) ecol = c * VEC + VEC;
+    if (flags & 1) ecol = -1;
 
     const int jb = y0 + by * rows;
     int je = jb + rows - 1;
     if (je > y1) je = y1;
-    // serpentine: odd strips walk downwards so that the two strips sharing a
-    // boundary row touch it at the same time (re-read served by L2 / MALL)
-    const int dir = (serpentine && (by & 1)) ? -1 : 1;
-    int j = dir > 0 ? jb : je;
-    const int jend = dir > 0 ? je : jb;
+    int j = jb;
 
     const double *pin = in + col;
     double *pout = out + (size_t)c * VEC;
     auto row = [&](int jj) { return load_chunk<VEC, NT>(pin + (size_t)jj * ld); };
     auto edge_of = [&](int jj) { return ecol >= 0 ? in[(size_t)jj * ld + ecol] : 0.0; };
 
-    Vec<VEC> behind = row(j - dir), mid = row(j);
+    Vec<VEC> south = row(j - 1), mid = row(j);
     double emid = edge_of(j);
-    const int nrow = (jend - j) * dir + 1;
-    int done = 0;
-    for (; done + U <= nrow; done += U) {
-        Vec<VEC> ahead[U];
-        double eahead[U];
+    // rows jbase+1 .. jbase+U: the north rows of outputs jbase .. jbase+U-1
+    auto load_group = [&](Vec<VEC>(&g)[U], double(&e)[U], int jbase) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            ahead[u] = row(j + dir * (u + 1));
-            eahead[u] = edge_of(j + dir * (u + 1));
+            g[u] = row(jbase + 1 + u);
+            e[u] = edge_of(jbase + 1 + u);
         }
+    };
+    auto compute_group = [&](Vec<VEC>(&g)[U], double(&e)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             double o[VEC];
-            // (south + north) is commutative: walking down only swaps the operands
-            if (dir > 0) jacobi_row<VEC>(behind, mid, ahead[u], emid, lane, o);
-            else jacobi_row<VEC>(ahead[u], mid, behind, emid, lane, o);
-            store_chunk<VEC, NT>(pout + (size_t)(j + dir * u) * ld, o, m0, m1);
-            behind = mid;
-            mid = ahead[u];
-            emid = eahead[u];
+            jacobi_row<VEC>(south, mid, g[u], emid, lane, o);
+            store_chunk<VEC, NT>(pout + (size_t)(j + u) * ld, o, m0, m1);
+            south = mid;
+            mid = g[u];
+            emid = e[u];
         }
-        j += dir * U;
+        j += U;
+    };
+
+    int remaining = je - jb + 1;
+    if constexpr (PIPE) {
+        Vec<VEC> A[U], B[U];
+        double eA[U], eB[U];
+        if (remaining >= U) {
+            load_group(A, eA, j);
+            for (;;) {
+                bool more = remaining >= 2 * U;
+                if (more) load_group(B, eB, j + U);
+                compute_group(A, eA);
+                remaining -= U;
+                if (!more) break;
+                more = remaining >= 2 * U;
+                if (more) load_group(A, eA, j + U);
+                compute_group(B, eB);
+                remaining -= U;
+                if (!more) break;
+            }
+        }
+    } else {
+        while (remaining >= U) {
+            Vec<VEC> A[U];
+            double eA[U];
+            load_group(A, eA, j);
+            compute_group(A, eA);
+            remaining -= U;
+        }
     }
-    for (; done < nrow; done++) {
-        Vec<VEC> ahead = row(j + dir);
-        double ea = edge_of(j + dir);
+    for (; remaining > 0; remaining--) {
+        Vec<VEC> north = row(j + 1);
+        double en = edge_of(j + 1);
         double o[VEC];
-        if (dir > 0) jacobi_row<VEC>(behind, mid, ahead, emid, lane, o);
-        else jacobi_row<VEC>(ahead, mid, behind, emid, lane, o);
+        jacobi_row<VEC>(south, mid, north, emid, lane, o);
         store_chunk<VEC, NT>(pout + (size_t)j * ld, o, m0, m1);
-        behind = mid;
-        mid = ahead;
-        emid = ea;
-        j += dir;
+        south = mid;
+        mid = north;
+        emid = en;
+        j++;
     }
+}
+
+// ===========================================================================
+// 5-point Jacobi, "XCD band sweep" form (the default).
+//
+// Measured on MI355X (scripts/membench.hip): a read+write stream reaches its best
+// rate, 6.3 TB/s, when the workgroups of a launch sweep memory linearly in
+// dispatch order with short-lived groups; long-lived groups marching far apart
+// (62 fronts across 2 GB) lose 15 %.  So the box is cut into NB horizontal bands,
+// one per XCD (workgroups are dealt round-robin to the 8 XCDs: group b runs on
+// XCD b % 8), and inside its band every XCD walks wave tiles of 64*VEC columns x
+// R rows in row-major order.  Consequences:
+//   * the two halo rows a tile shares with the tile above/below were fetched by
+//     the SAME XCD a few dozen tiles earlier -> served by that XCD's L2, not by
+//     the fabric; the same holds for the single edge column shared with the
+//     left/right tile.  HBM sees each input line once (plus NB-1 band seams);
+//   * all R+2 row loads of a tile are issued before the first is consumed
+//     (straight-line code, no loop-carried vmcnt wait), (R+2) KiB in flight/wave;
+//   * waves are independent (no LDS, no barrier): a 256-thread group is just four
+//     consecutive tiles, so a ragged last column costs one partial wave per strip.
+// Placement only affects speed: any other group->XCD assignment gives the same
+// results.
+// ===========================================================================
+template <int VEC, int R, bool NT>
+__global__ __launch_bounds__(256) void jacobi5_tile(const double *__restrict__ in,
+                                                    double *__restrict__ out, int ld, int x0, int x1,
+                                                    int y0, int y1, int c_first, int nxw, int nbands,
+                                                    int band_rows, int flags)
+{
+    const int lane = threadIdx.x & 63;
+    const int band = blockIdx.x % nbands;
+    const int w = (blockIdx.x / nbands) * 4 + (threadIdx.x >> 6); // wave-tile number inside the band
+    const int xw = w % nxw, strip = w / nxw;
+    const int by0 = y0 + band * band_rows;
+    int by1 = by0 + band_rows - 1;
+    if (by1 > y1) by1 = y1;
+    const int jb = by0 + strip * R;
+    if (jb > by1) return;
+    int je = jb + R - 1;
+    if (je > by1) je = by1;
+
+    const int c = c_first + xw * 64 + lane;
+    const int c_last = x1 / VEC;
+    const int c_ld = ld / VEC - 1;
+    const int cl = c < c_ld ? c : c_ld;
+    const bool m0 = c <= c_last && c * VEC >= x0 && c * VEC <= x1;
+    const bool m1 = VEC == 2 && c <= c_last && c * VEC + 1 >= x0 && c * VEC + 1 <= x1;
+    int ecol = -1;
+    if (lane == 0 && m0) ecol = c * VEC - 1;
+    if (lane == 63 && (VEC == 2 ? m1 : m0)) ecol = c * VEC + VEC;
+    if (flags & 1) ecol = -1;
+
+    const double *pin = in + (size_t)cl * VEC;
+    double *pout = out + (size_t)c * VEC;
+    // rows jb-1 .. jb+R ; rows beyond je+1 (short last strip of a band) are clamped:
+    // they are loaded again but never used
+    Vec<VEC> r[R + 2];
+    double e[R + 2];
+#pragma unroll
+    for (int u = 0; u < R + 2; u++) {
+        int jj = jb - 1 + u;
+        if (jj > je + 1) jj = je + 1;
+        r[u] = load_chunk<VEC, NT>(pin + (size_t)jj * ld);
+        e[u] = ecol >= 0 ? in[(size_t)jj * ld + ecol] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < R; u++) {
+        if (jb + u <= je) {
+            double o[VEC];
+            jacobi_row<VEC>(r[u], r[u + 1], r[u + 2], e[u + 1], lane, o);
+            store_chunk<VEC, NT>(pout + (size_t)(jb + u) * ld, o, m0, m1);
+        }
+    }
+}
+
+template <int VEC, bool NT>
+static void launch_tile(const double *in, double *out, int ld, int x0, int x1, int y0, int y1, int R,
+                        int nbands, int flags, hipStream_t s)
+{
+    if (R != 1 && R != 2 && R != 3 && R != 4 && R != 6 && R != 12 && R != 16) R = 8;
+    const int c_first = x0 / VEC, c_last = x1 / VEC;
+    const int nxw = (c_last - c_first + 64) / 64;       // wave tiles per row
+    const int h = y1 - y0 + 1;
+    if (nbands > h / R) nbands = h / R;                  // tiny boxes: fewer, never empty, bands
+    if (nbands < 1) nbands = 1;
+    int band_rows = (h + nbands - 1) / nbands;
+    band_rows = (band_rows + R - 1) / R * R;             // whole strips per band
+    const int strips = band_rows / R;
+    const long tiles = (long)nxw * strips;               // per band
+    const unsigned grid = (unsigned)(((tiles + 3) / 4) * nbands);
+#define DLESM_TILE(RR)                                                                               \
+    hipLaunchKernelGGL((jacobi5_tile<VEC, RR, NT>), dim3(grid), dim3(256), 0, s, in, out, ld, x0, x1, \
+                       y0, y1, c_first, nxw, nbands, band_rows, flags)
+    switch (R) {
+    case 1: DLESM_TILE(1); break;
+    case 2: DLESM_TILE(2); break;
+    case 3: DLESM_TILE(3); break;
+    case 4: DLESM_TILE(4); break;
+    case 6: DLESM_TILE(6); break;
+    case 12: DLESM_TILE(12); break;
+    case 16: DLESM_TILE(16); break;
+    default: DLESM_TILE(8); break;
+    }
+#undef DLESM_TILE
 }
 
 // The one-cell-wide frame of the box (rows ystart/ystop, columns xstart/xstop):
@@ -199,17 +332,50 @@ static int check_box(const char *who, int ld, int ny, int xstart, int xstop, int
     return DLESM_OK;
 }
 
-template <int VEC, bool NT>
-static void launch_march(const double *in, double *out, int ld, int x0, int x1, int y0, int y1,
-                         int rows, int serp, hipStream_t s)
+template <int VEC, int U, bool NT, bool PIPE>
+static void launch_march_u(const double *in, double *out, int ld, int x0, int x1, int y0, int y1,
+                           int rows, int flags, hipStream_t s)
 {
     const int c_first = x0 / VEC, c_last = x1 / VEC;
     const int nch = c_last - c_first + 1;
     const int nxb = (nch + 255) / 256;
     const int nstrips = (y1 - y0 + rows) / rows;
     dim3 grid((unsigned)(nxb * nstrips)), block(256);
-    hipLaunchKernelGGL((jacobi5_march<VEC, 4, NT>), grid, block, 0, s, in, out, ld, x0, x1, y0, y1,
-                       c_first, nxb, rows, serp);
+    hipLaunchKernelGGL((jacobi5_march<VEC, U, NT, PIPE>), grid, block, 0, s, in, out, ld, x0, x1, y0, y1,
+                       c_first, nxb, rows, flags);
+}
+
+template <int VEC, bool NT, bool PIPE>
+static void launch_march(const double *in, double *out, int ld, int x0, int x1, int y0, int y1,
+                         int rows, int flags, int unroll, hipStream_t s)
+{
+    if (unroll == 2) launch_march_u<VEC, 2, NT, PIPE>(in, out, ld, x0, x1, y0, y1, rows, flags, s);
+    else if (unroll == 8) launch_march_u<VEC, 8, NT, PIPE>(in, out, ld, x0, x1, y0, y1, rows, flags, s);
+    else launch_march_u<VEC, 4, NT, PIPE>(in, out, ld, x0, x1, y0, y1, rows, flags, s);
+}
+
+// Strip height when the caller does not fix it: give every resident block slot
+// (8 blocks of 256 threads per CU) exactly one strip, so that the whole grid is
+// co-resident, all blocks stream for the whole duration of the launch (no tail
+// round) and the re-read of the two halo rows per strip is amortised over as
+// many rows as possible.
+static int auto_rows(int ncols_vec, int height)
+{
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+        }
+        slots = cus * 8;
+    }
+    const int nxb = (ncols_vec + 255) / 256;
+    int nstrips = slots / nxb;
+    if (nstrips < 1) nstrips = 1;
+    int rows = (height + nstrips - 1) / nstrips;
+    return rows < 1 ? 1 : rows;
 }
 
 int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart,
@@ -219,20 +385,35 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
     if (int rc = check_box("dlesm_stencil5_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     DLESM_REQUIRE(in != nullptr && out != nullptr && in != out, "stencil5: null or aliased arrays");
     const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
-    int rows = tuning("j5_rows", 64);
-    if (rows < 1) rows = 1;
-    const int variant = tuning("j5_variant", 0); // bit0: non-temporal, bit1: serpentine, bit2: force VEC=1
+    // tuning bits -- 1: non-temporal loads/stores, 2: no register double buffering,
+    // 4: force VEC=1, 8: diagnostic "no edge loads" (wrong results, profiling only)
+    const int variant = tuning("j5_variant", 0);
     const bool nt = variant & 1;
-    const int serp = (variant >> 1) & 1;
+    const bool pipe = !(variant & 2);
+    const int flags = (variant >> 3) & 1;
+    const int unroll = tuning("j5_unroll", 4);
     const bool vec2 = !(variant & 4) && (ld % 2 == 0) && ((uintptr_t)in % 16 == 0) &&
                       ((uintptr_t)out % 16 == 0);
-    if (vec2) {
-        if (nt) launch_march<2, true>(in, out, ld, x0, x1, y0, y1, rows, serp, s);
-        else launch_march<2, false>(in, out, ld, x0, x1, y0, y1, rows, serp, s);
-    } else {
-        if (nt) launch_march<1, true>(in, out, ld, x0, x1, y0, y1, rows, serp, s);
-        else launch_march<1, false>(in, out, ld, x0, x1, y0, y1, rows, serp, s);
+    if (tuning("j5_kernel", 0) == 0) { // XCD band sweep (default)
+        const int R = tuning("j5_tile_rows", 2), nb = tuning("j5_bands", 1);
+        if (vec2) { if (nt) launch_tile<2, true>(in, out, ld, x0, x1, y0, y1, R, nb, flags, s);
+                    else launch_tile<2, false>(in, out, ld, x0, x1, y0, y1, R, nb, flags, s); }
+        else { if (nt) launch_tile<1, true>(in, out, ld, x0, x1, y0, y1, R, nb, flags, s);
+               else launch_tile<1, false>(in, out, ld, x0, x1, y0, y1, R, nb, flags, s); }
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
     }
+    int rows = tuning("j5_rows", 0);
+    if (rows < 1) rows = auto_rows(vec2 ? x1 / 2 - x0 / 2 + 1 : x1 - x0 + 1, y1 - y0 + 1);
+#define DLESM_J5(V, N, P) launch_march<V, N, P>(in, out, ld, x0, x1, y0, y1, rows, flags, unroll, s)
+    if (vec2) {
+        if (nt) { if (pipe) DLESM_J5(2, true, true); else DLESM_J5(2, true, false); }
+        else { if (pipe) DLESM_J5(2, false, true); else DLESM_J5(2, false, false); }
+    } else {
+        if (nt) { if (pipe) DLESM_J5(1, true, true); else DLESM_J5(1, true, false); }
+        else { if (pipe) DLESM_J5(1, false, true); else DLESM_J5(1, false, false); }
+    }
+#undef DLESM_J5
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }

@@ -533,6 +533,15 @@ void orc_jacobi5_omp(const double *in, double *out, int ld,
         for (int ji = xstart; ji <= xstop; ji++) jacobi5_code(ji, jj, out, in, ld);
 }
 
+/* row-parallel copy with the same static schedule as orc_jacobi5_omp: used by the
+ * cpu_baseline leg to first-touch its input on the threads that will read it */
+void orc_copy_rows_omp(double *dst, const double *src, int ld, int ny, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int jj = 0; jj < ny; jj++) memcpy(dst + (size_t)jj * ld, src + (size_t)jj * ld, (size_t)ld * sizeof(double));
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

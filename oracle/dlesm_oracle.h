@@ -127,6 +127,7 @@ void orc_sw_step(const orc_sw_params *p, int ld, int xstart, int xstop, int ysta
                  double *cu, double *cv, double *z, double *h,
                  double *unew, double *vnew, double *pnew);
 
+void orc_copy_rows_omp(double *dst, const double *src, int ld, int ny, int nthreads);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

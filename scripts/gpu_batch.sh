@@ -1,0 +1,72 @@
+#!/bin/bash
+# One gpurun call = one batch of GPU work (getting a box costs minutes, so batch).
+# Every step runs under its own timeout; a step that TIMES OUT (rc 124/137) stops the batch
+# (no further GPU step after a hang), an ordinary failure is logged and the batch goes on.
+#
+#   scripts/gpu_batch.sh tests sweep prof pmc bench      (any subset, in that order)
+set -u
+cd "$(dirname "$0")/.."
+OUT=gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+
+step() { # name timeout cmd...
+    local name=$1 t=$2; shift 2
+    echo "=== [$name] $(date +%T) : $*"
+    timeout -k 10 "$t" "$@"
+    local rc=$?
+    echo "=== [$name] rc=$rc"
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then
+        echo "=== [$name] TIMED OUT - stopping the batch"; exit 99
+    fi
+    return $rc
+}
+
+for what in "$@"; do
+case $what in
+tests)
+    step tests 1000 python -m pytest tests -m gpu -q -x --timeout=600 > $OUT/gpu_tests.log 2>&1
+    tail -15 $OUT/gpu_tests.log ;;
+sweep)
+    step sweep64 300 python scripts/sweep_j5.py --out $OUT/sweep_a64.json > $OUT/sweep_a64.log 2>&1
+    head -12 $OUT/sweep_a64.log
+    step sweep1 200 python scripts/sweep_j5.py --alignment 1 --variants 0,1 --rows 16,64,256 --out $OUT/sweep_a1.json > $OUT/sweep_a1.log 2>&1
+    head -8 $OUT/sweep_a1.log ;;
+prof)
+    rm -rf $OUT/prof_stats
+    step prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/prof_stats.log 2>&1
+    tail -2 $OUT/prof_stats.log
+    python scripts/parse_rocprof.py stats $OUT/prof_stats $OUT/prof_stats_summary.md > /dev/null 2>&1 || echo "parse failed" ;;
+pmc)
+    rm -rf $OUT/pmc_fetch $OUT/pmc_write
+    step pmcF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+    step pmcW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+    python scripts/parse_rocprof.py pmc $OUT/pmc_fetch $OUT/pmc_write "16384x16384/A64" $OUT/traffic.json 2>&1 | tail -12 ;;
+bench)
+    step bench 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+    cat $OUT/bench.json ;;
+smoke)
+    step smoke 200 python __graft_entry__.py smoke ;;
+sweep2)
+    step sweep2 400 python scripts/sweep_j5.py --variants ${SWEEP_VARIANTS:-0,2} --rows ${SWEEP_ROWS:-0,8,16,264,265,270,300,530} --unroll ${SWEEP_UNROLL:-2,4,8} --out $OUT/sweep2.json > $OUT/sweep2.log 2>&1
+    head -${SWEEP_HEAD:-30} $OUT/sweep2.log ;;
+probe)
+    rm -rf $OUT/probe_fetch $OUT/probe_write
+    step probeF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/probe_fetch -- python3 scripts/pmc_probe.py > $OUT/probe_fetch.log 2>&1
+    step probeW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/probe_write -- python3 scripts/pmc_probe.py > $OUT/probe_write.log 2>&1
+    python scripts/parse_probe.py $OUT/probe_fetch $OUT/probe_write > $OUT/probe_table.txt 2>&1
+    cat $OUT/probe_table.txt ;;
+tune)
+    # TUNE_ARGS: the --grid ... arguments of scripts/sweep_tune.py
+    step tune 500 python scripts/sweep_tune.py ${TUNE_ARGS} --out $OUT/sweep_tune.json > $OUT/sweep_tune.log 2>&1
+    head -${SWEEP_HEAD:-40} $OUT/sweep_tune.log ;;
+membench)
+    step membench 300 ./build/membench > $OUT/membench.log 2>&1
+    cat $OUT/membench.log ;;
+counters)
+    step counters 120 rocprofv3 -L > $OUT/counters.txt 2>&1
+    grep -c . $OUT/counters.txt ;;
+*)  echo "unknown step $what" ;;
+esac
+done
+ls -la $OUT | head -30

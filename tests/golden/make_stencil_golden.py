@@ -24,7 +24,7 @@ def main():
     n = 64
     d, subs = O.decompose(n, n, 1)
     nx, ny = O.grid_extents(subs[0].glob.nx, subs[0].glob.ny)          # 67 x 67, no alignment
-    a = O.hash_field(SEED, ny, nx, 1, 1, 1, n + 2, 1, n + 2)           # whole region incl. ring
+    a = O.hash_field(SEED, ny, nx, 0, 0, 1, n + 2, 1, n + 2)           # whole region incl. ring; local cell 1 = global cell 0
     b = a.copy()
     cs = {}
     for step in range(1, 11):

@@ -93,6 +93,7 @@ def lib():
     L.orc_jacobi5_omp.argtypes = [_dp, _dp] + [C.c_int] * 6
     L.orc_sw_step.argtypes = [C.POINTER(SwParams)] + [C.c_int] * 5 + [_dp] * 13
     L.orc_max_threads.restype = C.c_int
+    L.orc_copy_rows_omp.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int]
     _lib = L
     return L
 
@@ -165,6 +166,19 @@ def hash_field(seed, ny, ld, gx0, gy0, xlo, xhi, ylo, yhi):
         x = x ^ (x >> np.uint64(31))
     f[ylo - 1:yhi, xlo - 1:xhi] = (x >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
     return f
+
+
+def host_threads():
+    """threads this process may really use: cgroup quota / affinity / OpenMP limit (a GPU box
+    gives a 1-GPU job a share of the host's cores, not all of them)"""
+    n = min(lib().orc_max_threads(), len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def jacobi5(inp, out, ld, xs, xe, ys, ye, threads=1):

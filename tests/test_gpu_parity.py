@@ -54,7 +54,8 @@ def test_hash_init_matches_oracle(D):
     f = D.r2d_field(g, D.GO_T_POINTS)
     D.psy.hash_init(f, SEED)
     w = f.whole
-    want = O.hash_field(SEED, g.ny, g.nx, 1, 1, w.xstart, w.xstop, w.ystart, w.ystop)
+    # local cell 1 is global cell 0: the boundary ring sits just outside the 1..N domain
+    want = O.hash_field(SEED, g.ny, g.nx, 0, 0, w.xstart, w.xstop, w.ystart, w.ystop)
     assert np.array_equal(f.get_data(), want)
 
 
@@ -67,10 +68,25 @@ JACOBI_CASES = [
 ]
 
 
+DEFAULT_TUNING = dict(j5_kernel=0, j5_tile_rows=2, j5_bands=1, j5_variant=0, j5_rows=0, j5_unroll=4)
+# every code path of both kernels: band-sweep tiles of every height / band count / VEC / nt,
+# and the y-march kernel with and without register double buffering
+TUNINGS = [
+    dict(j5_kernel=0), dict(j5_kernel=0, j5_tile_rows=8, j5_bands=8), dict(j5_kernel=0, j5_tile_rows=3, j5_bands=4),
+    dict(j5_kernel=0, j5_tile_rows=1, j5_bands=3), dict(j5_kernel=0, j5_tile_rows=2, j5_bands=1),
+    dict(j5_kernel=0, j5_tile_rows=4, j5_bands=8, j5_variant=1), dict(j5_kernel=0, j5_tile_rows=6, j5_bands=5),
+    dict(j5_kernel=0, j5_tile_rows=12, j5_bands=2), dict(j5_kernel=0, j5_tile_rows=16, j5_bands=8),
+    dict(j5_kernel=0, j5_variant=4),
+    dict(j5_kernel=1, j5_rows=64), dict(j5_kernel=1, j5_rows=7, j5_variant=1),
+    dict(j5_kernel=1, j5_rows=16, j5_variant=2, j5_unroll=2), dict(j5_kernel=1, j5_rows=5, j5_variant=3, j5_unroll=8),
+    dict(j5_kernel=1, j5_variant=4), dict(j5_kernel=1, j5_rows=9, j5_unroll=2),
+]
+
+
 @pytest.mark.parametrize("nx,ny,alignment", JACOBI_CASES)
-@pytest.mark.parametrize("variant,rows", [(0, 64), (1, 7), (2, 16), (3, 5), (4, 64)])
-def test_jacobi5_bit_exact(D, nx, ny, alignment, variant, rows):
-    _set_tuning(D, j5_variant=variant, j5_rows=rows)
+@pytest.mark.parametrize("tune", TUNINGS, ids=lambda t: "-".join(f"{k[3:]}{v}" for k, v in t.items()))
+def test_jacobi5_bit_exact(D, nx, ny, alignment, tune):
+    _set_tuning(D, **{**DEFAULT_TUNING, **tune})
     try:
         g = _grid(D, nx, ny, alignment)
         a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
@@ -84,7 +100,7 @@ def test_jacobi5_bit_exact(D, nx, ny, alignment, variant, rows):
         # bit-exact, including every cell outside the box being left alone
         assert np.array_equal(got, want), np.argwhere(got != want)[:5]
     finally:
-        _set_tuning(D, j5_variant=0, j5_rows=64)
+        _set_tuning(D, **DEFAULT_TUNING)
 
 
 def test_jacobi5_sub_boxes_and_empty(D):
