@@ -181,7 +181,7 @@ def main():
         "checksum": checksum,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "jacobi5_march", "launch_ms": round(launch_ms, 5),
+                     "kernel": "jacobi5_tile<2,2>", "launch_ms": round(launch_ms, 5),
                      "algorithmic_bytes_per_launch": BYTES_PER_CELL * args.tile * args.tile},
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:

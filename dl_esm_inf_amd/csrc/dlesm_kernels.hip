@@ -217,16 +217,33 @@ template <int VEC, int R, bool NT>
 __global__ __launch_bounds__(256) void jacobi5_tile(const double *__restrict__ in,
                                                     double *__restrict__ out, int ld, int x0, int x1,
                                                     int y0, int y1, int c_first, int nxw, int nbands,
-                                                    int band_rows, int flags)
+                                                    int band_rows, int gs, int flags)
 {
     const int lane = threadIdx.x & 63;
-    const int band = blockIdx.x % nbands;
-    const int w = (blockIdx.x / nbands) * 4 + (threadIdx.x >> 6); // wave-tile number inside the band
-    const int xw = w % nxw, strip = w / nxw;
-    const int by0 = y0 + band * band_rows;
-    int by1 = by0 + band_rows - 1;
-    if (by1 > y1) by1 = y1;
-    const int jb = by0 + strip * R;
+    int xw, jb, by1;
+    if (gs > 0) {
+        // XCD-aware order.  Strips are taken in groups of gs; a group's tiles, padded to a
+        // whole number of 8-block rounds, are numbered COLUMN-major (slot = xw*gs + s) and
+        // XCD k = blockIdx % 8 receives the k-th eighth of the slots.  A tile's vertical and
+        // horizontal neighbours then sit on the same XCD (and the 4 waves of a block are 4
+        // vertically stacked tiles), so halo rows / edge columns are L1/L2 hits; all 8 XCDs
+        // work on the same gs*R rows at a time, and groups follow each other linearly.
+        const int bpg = band_rows;                       // blocks per group (multiple of 8)
+        const int g = blockIdx.x / bpg, bg = blockIdx.x % bpg;
+        const int slot = ((bg % 8) * (bpg / 8) + bg / 8) * 4 + (threadIdx.x >> 6);
+        xw = slot / gs;
+        if (xw >= nxw) return;
+        jb = y0 + (g * gs + slot % gs) * R;
+        by1 = y1;
+    } else {
+        const int band = blockIdx.x % nbands;
+        const int w = (blockIdx.x / nbands) * 4 + (threadIdx.x >> 6); // wave-tile number inside the band
+        xw = w % nxw;
+        const int by0 = y0 + band * band_rows;
+        by1 = by0 + band_rows - 1;
+        if (by1 > y1) by1 = y1;
+        jb = by0 + (w / nxw) * R;
+    }
     if (jb > by1) return;
     int je = jb + R - 1;
     if (je > by1) je = by1;
@@ -267,22 +284,31 @@ __global__ __launch_bounds__(256) void jacobi5_tile(const double *__restrict__ i
 
 template <int VEC, bool NT>
 static void launch_tile(const double *in, double *out, int ld, int x0, int x1, int y0, int y1, int R,
-                        int nbands, int flags, hipStream_t s)
+                        int nbands, int gs, int flags, hipStream_t s)
 {
     if (R != 1 && R != 2 && R != 3 && R != 4 && R != 6 && R != 12 && R != 16) R = 8;
     const int c_first = x0 / VEC, c_last = x1 / VEC;
     const int nxw = (c_last - c_first + 64) / 64;       // wave tiles per row
     const int h = y1 - y0 + 1;
-    if (nbands > h / R) nbands = h / R;                  // tiny boxes: fewer, never empty, bands
-    if (nbands < 1) nbands = 1;
-    int band_rows = (h + nbands - 1) / nbands;
-    band_rows = (band_rows + R - 1) / R * R;             // whole strips per band
-    const int strips = band_rows / R;
-    const long tiles = (long)nxw * strips;               // per band
-    const unsigned grid = (unsigned)(((tiles + 3) / 4) * nbands);
+    unsigned grid;
+    int band_rows;
+    if (gs > 0) {
+        const int strips = (h + R - 1) / R, groups = (strips + gs - 1) / gs;
+        const int bpg = ((nxw * gs + 31) / 32) * 8;      // blocks per group, whole 8-XCD rounds
+        band_rows = bpg;                                 // (parameter reused)
+        grid = (unsigned)(groups * bpg);
+        nbands = 1;
+    } else {
+        if (nbands > h / R) nbands = h / R;              // tiny boxes: fewer, never empty, bands
+        if (nbands < 1) nbands = 1;
+        band_rows = (h + nbands - 1) / nbands;
+        band_rows = (band_rows + R - 1) / R * R;         // whole strips per band
+        const long tiles = (long)nxw * (band_rows / R);  // per band
+        grid = (unsigned)(((tiles + 3) / 4) * nbands);
+    }
 #define DLESM_TILE(RR)                                                                               \
     hipLaunchKernelGGL((jacobi5_tile<VEC, RR, NT>), dim3(grid), dim3(256), 0, s, in, out, ld, x0, x1, \
-                       y0, y1, c_first, nxw, nbands, band_rows, flags)
+                       y0, y1, c_first, nxw, nbands, band_rows, gs, flags)
     switch (R) {
     case 1: DLESM_TILE(1); break;
     case 2: DLESM_TILE(2); break;
@@ -395,11 +421,11 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
     const bool vec2 = !(variant & 4) && (ld % 2 == 0) && ((uintptr_t)in % 16 == 0) &&
                       ((uintptr_t)out % 16 == 0);
     if (tuning("j5_kernel", 0) == 0) { // XCD band sweep (default)
-        const int R = tuning("j5_tile_rows", 2), nb = tuning("j5_bands", 1);
-        if (vec2) { if (nt) launch_tile<2, true>(in, out, ld, x0, x1, y0, y1, R, nb, flags, s);
-                    else launch_tile<2, false>(in, out, ld, x0, x1, y0, y1, R, nb, flags, s); }
-        else { if (nt) launch_tile<1, true>(in, out, ld, x0, x1, y0, y1, R, nb, flags, s);
-               else launch_tile<1, false>(in, out, ld, x0, x1, y0, y1, R, nb, flags, s); }
+        const int R = tuning("j5_tile_rows", 2), nb = tuning("j5_bands", 1), gs = tuning("j5_group", 0);
+        if (vec2) { if (nt) launch_tile<2, true>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s);
+                    else launch_tile<2, false>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s); }
+        else { if (nt) launch_tile<1, true>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s);
+               else launch_tile<1, false>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s); }
         DLESM_HIP_TRY(hipGetLastError());
         return DLESM_OK;
     }
