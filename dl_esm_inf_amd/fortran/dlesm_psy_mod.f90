@@ -1,0 +1,147 @@
+!> PSy-layer building blocks for HIP: what replaces the generated
+!!     do jj = fld%internal%ystart, fld%internal%ystop
+!!        do ji = fld%internal%xstart, fld%internal%xstop
+!!           call kern_code(ji, jj, out%data, in%data, ...)
+!! loop nests (form: reference infrastructure_mod.f90:32-41) -- one call that launches the
+!! matching CDNA4 kernel over the same index box on the fields' device copies.
+!!
+!! Also provides infrastructure_mod, the reference's field-copy "kernel" module, with its
+!! metadata type and pointwise code unchanged in meaning.
+module infrastructure_mod
+  use kind_params_mod
+  use kernel_mod
+  use argument_mod
+  use grid_mod
+  use field_mod
+  implicit none
+
+  type, extends(kernel_type) :: copy
+     type(go_arg), dimension(2) :: meta_args = &
+          (/ go_arg(GO_WRITE, GO_EVERY, GO_POINTWISE), &
+             go_arg(GO_READ,  GO_EVERY, GO_POINTWISE) /)
+     integer :: ITERATES_OVER = GO_ALL_PTS
+     integer :: index_offset = GO_OFFSET_ANY
+   contains
+     procedure, nopass :: code => field_copy_code
+  end type copy
+
+contains
+
+  subroutine field_copy_code(ji, jj, output, input)
+    integer, intent(in) :: ji, jj
+    real(go_wp), dimension(:,:), intent(in) :: input
+    real(go_wp), dimension(:,:), intent(out) :: output
+    output(ji, jj) = input(ji, jj)
+  end subroutine field_copy_code
+
+end module infrastructure_mod
+
+
+module dlesm_psy_mod
+  use iso_c_binding
+  use kind_params_mod
+  use grid_mod
+  use field_mod
+  use gocean_mod, only: gocean_stop
+  use dlesm_hip_mod
+  implicit none
+  private
+
+  public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
+  public :: shallow_params, c_sw_params, device_sync
+
+contains
+
+  subroutine device_sync()
+    if (hipDeviceSynchronize() /= 0) call gocean_stop('device synchronisation failed')
+  end subroutine device_sync
+
+  subroutine need_device(f)
+    type(r2d_field), intent(inout), target :: f
+    if (.not. f%data_on_device) call field_to_device(f)
+    if (.not. field_on_dlesm_device(f)) call gocean_stop('PSy layer: field lives on a foreign device')
+  end subroutine need_device
+
+  !> out = 0.25*((w+e)+(s+n)) of `in` over out%internal
+  subroutine invoke_jacobi5(out, in)
+    type(r2d_field), intent(inout), target :: out, in
+    integer(c_int) :: rc
+    call need_device(in);  call need_device(out)
+    rc = dlesm_stencil5_f64(field_device_data(in), field_device_data(out), &
+                            int(out%grid%nx, c_int), int(out%grid%ny, c_int), &
+                            int(out%internal%xstart, c_int), int(out%internal%xstop, c_int), &
+                            int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_jacobi5: ' // dlesm_error_text())
+  end subroutine invoke_jacobi5
+
+  !> Distributed Jacobi step: `in` must have valid halos; on return (asynchronously) `out`
+  !! holds the update AND its halos, the exchange having run behind the interior sweep.
+  subroutine invoke_jacobi5_dm(out, in)
+    use parallel_comms_mod, only: halo_plan_for
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(r2d_field), intent(inout), target :: out, in
+    integer(c_int) :: rc
+    if (.not. DIST_MEM_ENABLED) then
+       call invoke_jacobi5(out, in)
+       return
+    end if
+    call need_device(in);  call need_device(out)
+    rc = dlesm_jacobi5_step_dm(halo_plan_for(out%grid%nx, out%grid%ny), field_device_data(in), &
+                               field_device_data(out), int(out%grid%nx, c_int), int(out%grid%ny, c_int), &
+                               int(out%internal%xstart, c_int), int(out%internal%xstop, c_int), &
+                               int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_jacobi5_dm: ' // dlesm_error_text())
+  end subroutine invoke_jacobi5_dm
+
+  !> Constants of the shallow-water step; tdt = 2*dt (leapfrog)
+  function shallow_params(dx, dy, dt) result(p)
+    real(go_wp), intent(in) :: dx, dy, dt
+    type(c_sw_params) :: p
+    real(go_wp) :: tdt
+    tdt = dt + dt
+    p%fsdx = 4.0_go_wp / dx;  p%fsdy = 4.0_go_wp / dy
+    p%tdts8 = tdt / 8.0_go_wp
+    p%tdtsdx = tdt / dx;  p%tdtsdy = tdt / dy
+  end function shallow_params
+
+  subroutine invoke_shallow_step(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)
+    type(c_sw_params), intent(in) :: prm
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    rc = dlesm_shallow_step_f64(prm, int(p%grid%nx, c_int), int(p%grid%ny, c_int), &
+                                int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                                int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                                field_device_data(u), field_device_data(v), field_device_data(p), &
+                                field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                field_device_data(unew), field_device_data(vnew), field_device_data(pnew), &
+                                c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step
+
+  !> The `copy` kernel of infrastructure_mod over all points
+  subroutine invoke_copy(out, in)
+    type(r2d_field), intent(inout), target :: out, in
+    call need_device(in);  call need_device(out)
+    call copy_field(in, out)
+  end subroutine invoke_copy
+
+  !> Synthetic initial condition: a hash of the GLOBAL cell index on the field's whole region
+  subroutine invoke_hash_init(fld, seed)
+    type(r2d_field), intent(inout), target :: fld
+    integer(c_int64_t), intent(in) :: seed
+    integer(c_int) :: rc
+    integer(c_int64_t) :: gx0, gy0
+    call need_device(fld)
+    gx0 = fld%grid%subdomain%global%xstart - fld%grid%subdomain%internal%xstart + 1
+    gy0 = fld%grid%subdomain%global%ystart - fld%grid%subdomain%internal%ystart + 1
+    rc = dlesm_hash_init_f64(field_device_data(fld), int(fld%grid%nx, c_int), int(fld%grid%ny, c_int), &
+                             int(fld%whole%xstart, c_int), int(fld%whole%xstop, c_int), &
+                             int(fld%whole%ystart, c_int), int(fld%whole%ystop, c_int), seed, gx0, gy0, &
+                             c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_hash_init: ' // dlesm_error_text())
+  end subroutine invoke_hash_init
+
+end module dlesm_psy_mod

@@ -1,0 +1,123 @@
+"""One rank of the CPU multi-process tests (launched by tests/test_multirank_gloo.py, gloo
+backend, no GPU).  It drives the PRODUCT's host logic for its own rank -- parallel_init,
+grid_type%decompose, grid_init (-> map_comms through the C ABI) -- and then plays the
+reference's dist_mem tests (test_halos / test_gsum / test_reduction) with numpy arrays as the
+fields and gloo send/recv as a TEST-ONLY transport that follows the product's message tables
+(ordering rule of the RCCL path: per peer, ascending direction code).  What this checks is
+everything about the N>1 path that is not the GPU itself: tile ownership, message tables,
+peer/ordering logic, scatter/gather index maps.
+
+    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/gloo_worker.py NX NY
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import ref_cases as R  # noqa: E402
+
+
+def exchange(field, tables, rank):
+    """halo exchange of a (ny, ld) numpy field over gloo, message order as in dlesm_halo.hip"""
+    sends = sorted(tables.sends(), key=lambda m: (m["dest"], m["dir"]))
+    recvs = sorted(tables.recvs(), key=lambda m: (m["src"], m["dir"]))
+    reqs, bufs = [], []
+    for m in recvs:
+        buf = torch.empty(m["nx"] * m["ny"], dtype=torch.float64)
+        reqs.append(dist.irecv(buf, src=m["src"], tag=m["dir"]))
+        bufs.append((m, buf))
+    for m in sends:
+        patch = field[m["jsrc"] - 1:m["jsrc"] - 1 + m["ny"], m["isrc"] - 1:m["isrc"] - 1 + m["nx"]]
+        reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(patch).reshape(-1)), dst=m["dest"],
+                               tag=m["dir"]))
+    for q in reqs:
+        q.wait()
+    for m, buf in bufs:
+        field[m["jdes"] - 1:m["jdes"] - 1 + m["ny"], m["ides"] - 1:m["ides"] - 1 + m["nx"]] = \
+            buf.numpy().reshape(m["ny"], m["nx"])
+
+
+def main():
+    nx, ny = int(sys.argv[1]), int(sys.argv[2])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dl_esm_inf_amd as D
+    D.parallel_init(rank, world, use_rccl=False)
+    assert D.get_rank() == rank + 1 and D.get_num_ranks() == world
+    g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
+    g.decompose(nx, ny)
+    D.grid_init(g, 1.0, 1.0)
+    sub = g.subdomain
+    t = g.comm_tables
+    # every message has a partner on the other side: exchange the table summaries
+    mine = [(m["dest"], m["dir"], m["nx"] * m["ny"]) for m in t.sends()]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, {"sends": mine, "recvs": [(m["src"], m["dir"], m["nx"] * m["ny"])
+                                                              for m in t.recvs()]})
+    for peer, summary in enumerate(everyone):
+        for (dest, d, n) in summary["sends"]:
+            if dest == rank:
+                assert (peer, d, n) in [(m["src"], m["dir"], m["nx"] * m["ny"]) for m in t.recvs()]
+
+    errors = 0
+    # ---- test_halos: U, V, T, F fields --------------------------------------------------
+    for ptype in (R.GO_T, R.GO_U, R.GO_V, R.GO_F):
+        internal, _ = D.field_mod.field_bounds(g, ptype)
+        it = internal.box()
+        f = R.init_field_hill(ptype, g.nx, g.ny, it, sub.glob.xstart, sub.glob.ystart)
+        before = f.copy()
+        exchange(f, t, rank)
+        bad = R.check_hill_halos(f, ptype, it, sub.glob.box(), nx, ny, corners=True)
+        if bad:
+            print(f"rank {rank}: ERROR in halo values for ptype {ptype}: {bad[:3]}", flush=True)
+            errors += 1
+        xs, xe, ys, ye = it
+        if not np.array_equal(f[ys - 1:ye, xs - 1:xe], before[ys - 1:ye, xs - 1:xe]):
+            print(f"rank {rank}: ERROR internal cells modified", flush=True)
+            errors += 1
+    # ---- test_gsum: checksum of ones == jpiglo*jpjglo --------------------------------
+    internal, _ = D.field_mod.field_bounds(g, R.GO_T)
+    f = R.gsum_field(g.nx, g.ny, internal.box())
+    xs, xe, ys, ye = internal.box()
+    local = torch.tensor([np.abs(f[ys - 1:ye, xs - 1:xe]).sum()], dtype=torch.float64)
+    dist.all_reduce(local)
+    if float(local[0]) != float(nx * ny):
+        print(f"rank {rank}: ERROR global sum {float(local[0])} != {nx * ny}", flush=True)
+        errors += 1
+    # ---- test_reduction: scatter by the subdomain's global box, gather back + 1 --------
+    glob = R.unique_global(nx, ny)
+    f = np.zeros((g.ny, g.nx))
+    dx, dy = sub.glob.xstart - xs, sub.glob.ystart - ys
+    f[ys - 1:ye, xs - 1:xe] = glob[ys + dy - 1:ye + dy, xs + dx - 1:xe + dx] + 1.0
+    halo_x, halo_y = xs - 1, ys - 1
+    n = (g.decomp.max_width - 2 * halo_x) * (g.decomp.max_height - 2 * halo_y)
+    send = torch.zeros(n, dtype=torch.float64)
+    inner = f[ys - 1:ye, xs - 1:xe].reshape(-1)
+    send[:inner.size] = torch.from_numpy(inner.copy())
+    slots = [torch.zeros(n, dtype=torch.float64) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, slots, dst=0)
+    if rank == 0:
+        back = np.zeros((ny, nx))
+        for r in range(world):
+            s = g.decomp.subdomains[r].glob
+            w, h = s.xstop - s.xstart + 1, s.ystop - s.ystart + 1
+            back[s.ystart - 1:s.ystop, s.xstart - 1:s.xstop] = slots[r].numpy()[:w * h].reshape(h, w)
+        if not np.array_equal(back, glob + 1.0):
+            print("rank 0: ERROR gathered field incorrect", flush=True)
+            errors += 1
+    tot = torch.tensor([errors])
+    dist.all_reduce(tot)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(1 if int(tot[0]) else 0)
+
+
+if __name__ == "__main__":
+    main()

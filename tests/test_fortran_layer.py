@@ -1,0 +1,140 @@
+"""The Fortran API layer (dl_esm_inf_amd/fortran -> lib_fd_hip.a), driven through Fortran
+programs exactly as a GOcean application would use it.
+
+CPU part: tests/fortran/ftest_dump.f90 prints the same "G:" lines for this library as
+oracle/ref_drivers/ref_dump.f90 printed for the REAL reference; they are compared with the
+committed goldens (bit-exact integers) and, for the per-rank message tables, with the oracle.
+GPU part (-m gpu): tests/fortran/ftest_device.f90 replays the reference's device-io test on the
+real device and runs a Jacobi model through the PSy layer.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_cases as R
+from conftest import ROOT, load_golden
+
+FDIR = os.path.join(ROOT, "dl_esm_inf_amd", "fortran")
+BUILD = os.path.join(FDIR, "build")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    subprocess.check_call(["make", "-C", FDIR], stdout=subprocess.DEVNULL)
+
+    def run(name, *args, env=None, check=True):
+        e = dict(os.environ)
+        e.pop("DL_ESM_ALIGNMENT", None)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            e.pop(k, None)
+        e.update(env or {})
+        p = subprocess.run([os.path.join(BUILD, name), *map(str, args)], env=e, capture_output=True,
+                           text=True, timeout=300)
+        if check:
+            assert p.returncode == 0, p.stderr[-2000:]
+        g = {}
+        for line in p.stdout.splitlines():
+            if line.startswith("G: "):
+                t = line[3:].split()
+                g.setdefault(t[0], []).append(t[1:])
+        return p.returncode, g, p.stderr
+    return run
+
+
+def ints(t):
+    return [int(x) for x in t]
+
+
+def test_fortran_go_decompose_matches_reference(exe):
+    for c in load_golden("ref_decomp")["cases"]:
+        _, g, _ = exe("ftest_dump.exe", "decomp", c["domainx"], c["domainy"], c["ndomains"])
+        assert ints(g["decomp"][0]) == [c["global_nx"], c["global_ny"], c["nx"], c["ny"], c["ndom_out"],
+                                        c["max_width"], c["max_height"]]
+        assert [ints(s)[1:] for s in g["sub"]] == c["subdomains"]
+
+
+def test_fortran_bounds_match_reference(exe):
+    """grid_type + decompose + grid_init + r2d_field through the Fortran layer, incl. the
+    combinations on which the reference stops (gocean_stop -> non-zero exit)"""
+    cases = [c for c in load_golden("ref_bounds")["cases"]
+             if c["alignment"] in (None, 64) and (c["nx"], c["ny"]) in ((10, 4), (256, 256), (5, 5))]
+    assert len(cases) == 210
+    n_abort = 0
+    for c in cases:
+        env = {"DL_ESM_ALIGNMENT": str(c["alignment"])} if c["alignment"] else None
+        rc, g, err = exe("ftest_dump.exe", "bounds", c["nx"], c["ny"], c["offset"], c["bcx"], c["bcy"],
+                         c["ptype"], env=env, check=False)
+        assert ints(g["grid"][0]) == c["grid"], c
+        if c["abort"]:
+            n_abort += 1
+            assert rc != 0 and "field" not in g, c
+            continue
+        assert rc == 0, (c, err)
+        f = ints(g["field"][0])
+        assert f[0] == c["defined_on"] and f[1:7] == c["internal"] and f[7:13] == c["whole"], c
+        if c["num_halos"] is not None:
+            assert f[13] == c["num_halos"]
+        assert ints(g["shape"][0]) == c["shape"]
+        assert [ints(h)[1:] for h in g.get("halo", [])] == c["halos"]
+    assert n_abort == 54
+
+
+def test_fortran_model_and_gather_match_reference(exe):
+    gold = load_golden("ref_model")
+    for m in gold["model"]:
+        _, g, _ = exe("ftest_dump.exe", "model", m["nx"], m["ny"], m["fill"])
+        assert ints(g["grid"][0]) == m["grid"] and ints(g["internal"][0]) == m["internal"]
+        assert float(g["checksum"][0][0]) == m["checksum"]
+        assert [float(x) for x in g["xt"][0]] == m["xt"] and [float(x) for x in g["yt"][0]] == m["yt"]
+    for m in gold["gather"]:
+        _, g, _ = exe("ftest_dump.exe", "gather", m["nx"], m["ny"])
+        assert [float(x) for x in g["corner"][0]] == m["corner"]
+        assert float(g["checksum"][0][0]) == m["checksum"]
+        assert ints(g["gather_shape"][0]) == m["gather_shape"] and int(g["gather_mismatch"][0][0]) == 0
+
+
+@pytest.mark.parametrize("nx,ny,nranks", R.HALO_CASES + [(16, 32, 8), (13, 13, 9)])
+def test_fortran_message_tables_match_oracle(exe, nx, ny, nranks):
+    """every rank's parallel_comms_mod tables after grid_init (RANK/WORLD_SIZE from the
+    environment, dry communicator: no GPU) against the oracle's map_comms"""
+    od, osubs = O.decompose(nx, ny, nranks)
+    for r in range(nranks):
+        _, g, _ = exe("ftest_dump.exe", "comms", nx, ny,
+                      env={"RANK": str(r), "WORLD_SIZE": str(nranks), "DLESM_DRY_COMMS": "1"})
+        c = O.map_comms(od, osubs, nranks, r + 1)
+        ext = O.grid_extents(osubs[r].glob.nx, osubs[r].glob.ny)
+        assert ints(g["rank"][0]) == [r + 1, nranks, ext[0], ext[1]]
+        assert ints(g["counts"][0]) == [c.nsend, c.nrecv]
+        want_s = [[s["dir"], s["dest"], s["isrc"], s["jsrc"], s["ides"], s["jdes"], s["nx"], s["ny"]]
+                  for s in c.sends()]
+        want_r = [[q["dir"], q["src"], q["ides"], q["jdes"], q["nx"], q["ny"]] for q in c.recvs()]
+        assert [ints(s) for s in g.get("send", [])] == want_s
+        assert [ints(q) for q in g.get("recv", [])] == want_r
+        sg = osubs[r].glob
+        assert ints(g["bounds"][0]) == [sg.xstart, sg.xstop, sg.ystart, sg.ystop]
+
+
+@pytest.mark.gpu
+def test_fortran_device_io_and_jacobi_on_gpu(exe):
+    nx, ny, nsteps = 300, 171, 5
+    _, g, _ = exe("ftest_device.exe", nx, ny, nsteps, env={"DL_ESM_ALIGNMENT": "8"})
+    # (1) the reference's device-io scenario, on the real device
+    gold = next(r for r in load_golden("ref_device_io")["runs"] if r["alignment"] == 8)
+    assert [[float(x) for x in row] for row in g["io"]] == gold["rows"]
+    # (2) Jacobi through the Fortran PSy layer == oracle
+    ld, nyy = ints(g["grid"][0])
+    assert (ld, nyy) == O.grid_extents(nx + 2, ny + 2, 8)
+    a = O.hash_field(20261004, nyy, ld, 0, 0, 1, nx + 2, 1, ny + 2)
+    cs0 = O.lib().orc_checksum(a, ld, 2, nx + 1, 2, ny + 1)
+    assert abs(float(g["cs0"][0][0]) - cs0) <= 1e-12 * cs0
+    b = a.copy()
+    for _ in range(nsteps):
+        O.jacobi5(a, b, ld, 2, nx + 1, 2, ny + 1)
+        a, b = b, a
+    cs = O.lib().orc_checksum(a, ld, 2, nx + 1, 2, ny + 1)
+    assert abs(float(g["cs"][0][0]) - cs) <= 1e-12 * cs
+    got = [float(x) for x in g["sample"][0]]
+    assert got == [a[1, 1], a[ny // 2, nx // 2], a[ny, nx]]
