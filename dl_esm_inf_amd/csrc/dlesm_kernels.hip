@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void jacobi5_march(const double *__restrict__ 
 // results.
 // ===========================================================================
 template <int VEC, int R, bool NT>
-__global__ __launch_bounds__(256) void jacobi5_tile(const double *__restrict__ in,
+__global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ in,
                                                     double *__restrict__ out, int ld, int x0, int x1,
                                                     int y0, int y1, int c_first, int nxw, int nbands,
                                                     int band_rows, int gs, int flags)
@@ -230,14 +230,15 @@ __global__ __launch_bounds__(256) void jacobi5_tile(const double *__restrict__ i
         // work on the same gs*R rows at a time, and groups follow each other linearly.
         const int bpg = band_rows;                       // blocks per group (multiple of 8)
         const int g = blockIdx.x / bpg, bg = blockIdx.x % bpg;
-        const int slot = ((bg % 8) * (bpg / 8) + bg / 8) * 4 + (threadIdx.x >> 6);
+        const int slot = ((bg % 8) * (bpg / 8) + bg / 8) * 4 + (threadIdx.x >> 6);   // 256-thread blocks
         xw = slot / gs;
         if (xw >= nxw) return;
         jb = y0 + (g * gs + slot % gs) * R;
         by1 = y1;
     } else {
         const int band = blockIdx.x % nbands;
-        const int w = (blockIdx.x / nbands) * 4 + (threadIdx.x >> 6); // wave-tile number inside the band
+        // wave-tile number inside the band; a block is blockDim.x/64 consecutive tiles
+        const int w = (blockIdx.x / nbands) * (blockDim.x >> 6) + (threadIdx.x >> 6);
         xw = w % nxw;
         const int by0 = y0 + band * band_rows;
         by1 = by0 + band_rows - 1;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256) void jacobi5_tile(const double *__restrict__ i
     if (je > by1) je = by1;
 
     const int c = c_first + xw * 64 + lane;
+    if (c - lane > x1 / VEC) return;                    // an idle padding tile
     const int c_last = x1 / VEC;
     const int c_ld = ld / VEC - 1;
     const int cl = c < c_ld ? c : c_ld;
@@ -287,11 +289,13 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
                         int nbands, int gs, int flags, hipStream_t s)
 {
     if (R != 1 && R != 2 && R != 3 && R != 4 && R != 6 && R != 12 && R != 16) R = 8;
-    const int c_first = x0 / VEC, c_last = x1 / VEC;
-    const int nxw = (c_last - c_first + 64) / 64;       // wave tiles per row
+    // tiles are anchored on a 128-byte line of the row (not on the first interior column), so
+    // every wave access covers whole lines whatever the box: lanes left of x0 are masked
+    const int c_first = (x0 / VEC) & ~(128 / (8 * VEC) - 1), c_last = x1 / VEC;
+    int nxw = (c_last - c_first + 64) / 64;             // wave tiles per row
     const int h = y1 - y0 + 1;
     unsigned grid;
-    int band_rows;
+    int band_rows, tpb = 4;                              // tiles (waves) per block
     if (gs > 0) {
         const int strips = (h + R - 1) / R, groups = (strips + gs - 1) / gs;
         const int bpg = ((nxw * gs + 31) / 32) * 8;      // blocks per group, whole 8-XCD rounds
@@ -303,11 +307,36 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
         if (nbands < 1) nbands = 1;
         band_rows = (h + nbands - 1) / nbands;
         band_rows = (band_rows + R - 1) / R * R;         // whole strips per band
+        if (nbands == 1) {
+            // Blocks go round-robin to the 8 XCDs, so the tile below a given tile runs on the
+            // XCD (blocks per row) mod 8 further on: the re-read of the shared rows is an L2
+            // hit only when that is ~0.  Measured (scripts/pad_probe.py): 32.25 blocks per row
+            // is the sweet spot at 16384^2, 33 blocks per row costs 19 %.  Pick the block size
+            // (2..16 waves) that brings blocks-per-row closest above a multiple of 8, and skew
+            // an exact multiple by one idle tile per row.
+            // Rule fitted to those measurements: blocks per row must sit in [8k, 8k + 1/4];
+            // take the block size that gets there with the fewest idle padding tiles.
+            const int forced = tuning("j5_tpb", 0);
+            int pad = 0;
+            double best = 1e9;
+            for (int cand : {8, 4, 2, 16}) {
+                if (forced && cand != forced) continue;
+                const int period = 8 * cand, slack = cand / 4;
+                if (nxw < period && !forced) continue;        // fewer than 8 blocks per row
+                const int r = nxw % period, p = r <= slack ? 0 : period - r;
+                const double cost = (double)p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : cand == 2 ? 0.03 : 0.04);
+                if (cost < best) { best = cost; tpb = cand; pad = p; }
+            }
+            if (best > 0.25 && !forced) { tpb = 4; pad = 0; } // nothing fits cheaply (narrow boxes)
+            nxw += pad;
+            if (tuning("j5_skew", 1) && nxw >= 128 && nxw % (8 * tpb) == 0) nxw += 1;
+            nxw += tuning("j5_pad_tiles", 0);
+        }
         const long tiles = (long)nxw * (band_rows / R);  // per band
-        grid = (unsigned)(((tiles + 3) / 4) * nbands);
+        grid = (unsigned)(((tiles + tpb - 1) / tpb) * nbands);
     }
 #define DLESM_TILE(RR)                                                                               \
-    hipLaunchKernelGGL((jacobi5_tile<VEC, RR, NT>), dim3(grid), dim3(256), 0, s, in, out, ld, x0, x1, \
+    hipLaunchKernelGGL((jacobi5_tile<VEC, RR, NT>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, x0, x1, \
                        y0, y1, c_first, nxw, nbands, band_rows, gs, flags)
     switch (R) {
     case 1: DLESM_TILE(1); break;
@@ -421,7 +450,10 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
     const bool vec2 = !(variant & 4) && (ld % 2 == 0) && ((uintptr_t)in % 16 == 0) &&
                       ((uintptr_t)out % 16 == 0);
     if (tuning("j5_kernel", 0) == 0) { // XCD band sweep (default)
-        const int R = tuning("j5_tile_rows", 2), nb = tuning("j5_bands", 1), gs = tuning("j5_group", 0);
+        // rows per tile: 2 for 16-byte lanes, 4 for the 8-byte-lane fallback (measured, scripts/size_probe.py)
+        int R = tuning("j5_tile_rows", 0);
+        if (R < 1) R = vec2 ? 2 : 4;
+        const int nb = tuning("j5_bands", 1), gs = tuning("j5_group", 0);
         if (vec2) { if (nt) launch_tile<2, true>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s);
                     else launch_tile<2, false>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s); }
         else { if (nt) launch_tile<1, true>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s);

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Price the distributed Jacobi step on ONE GPU: RCCL send/recv in loop-back (rank 0 is its own
+west/east/south/north/corner neighbour, i.e. a periodic wrap), so that the whole machinery of
+dlesm_jacobi5_step_dm -- frame kernel, side-stream pack + grouped ncclSend/ncclRecv + unpack,
+interior kernel, event join -- runs exactly as it does on 8 GPUs, minus the xGMI hop.
+Reports ms/step of (a) the plain single-tile step, (b) exchange-then-step without overlap,
+(c) the overlapped distributed step, and checks (b) == (c) bit for bit.
+
+    python scripts/dm_overhead.py [--tile 8192] [--steps 50]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def loopback_tables(D, it):
+    t = D._cabi.CommTables()
+    msgs = [  # dir, isrc, jsrc, ides, jdes, nx, ny   (a periodic wrap onto oneself)
+        (2, it.xstop, it.ystart, it.xstart - 1, it.ystart, 1, it.ny),
+        (1, it.xstart, it.ystart, it.xstop + 1, it.ystart, 1, it.ny),
+        (4, it.xstart, it.ystop, it.xstart, it.ystart - 1, it.nx, 1),
+        (3, it.xstart, it.ystart, it.xstart, it.ystop + 1, it.nx, 1),
+        (6, it.xstop, it.ystop, it.xstart - 1, it.ystart - 1, 1, 1),
+        (5, it.xstart, it.ystart, it.xstop + 1, it.ystop + 1, 1, 1),
+        (7, it.xstart, it.ystop, it.xstop + 1, it.ystart - 1, 1, 1),
+        (8, it.xstop, it.ystart, it.xstart - 1, it.ystop + 1, 1, 1),
+    ]
+    t.nsend = t.nrecv = len(msgs)
+    for k, (d_, isrc, jsrc, ides, jdes, nx, ny) in enumerate(msgs):
+        t.dirsend[k] = t.dirrecv[k] = d_
+        t.destination[k] = t.source[k] = 0
+        t.isrcsend[k], t.jsrcsend[k], t.idessend[k], t.jdessend[k] = isrc, jsrc, ides, jdes
+        t.nxsend[k], t.nysend[k] = nx, ny
+        t.isrcrecv[k], t.jsrcrecv[k], t.idesrecv[k], t.jdesrecv[k] = isrc, jsrc, ides, jdes
+        t.nxrecv[k], t.nyrecv[k] = nx, ny
+    return t
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tile", type=int, default=8192)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--out", default="gpurun_out/dm_overhead.json")
+    args = ap.parse_args()
+    import torch
+    import dl_esm_inf_amd as D
+    L = D._cabi.lib()
+    torch.cuda.set_device(0)
+    os.environ["DL_ESM_ALIGNMENT"] = "64"
+    D.parallel_init(0, 1, use_rccl=True)
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    g.decompose(args.tile, args.tile)
+    D.grid_init(g, 1.0, 1.0)
+    F = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(2)]
+    it = F[0].internal
+    tables = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(tables), g.nx, g.ny, C.byref(plan)))
+    s = torch.cuda.Stream()
+    sp = C.c_void_p(s.cuda_stream)
+    box = it.box()
+
+    def init(a, b):
+        D.psy.hash_init(a, 20261004, stream=s)
+        D._cabi.check(L.dlesm_halo_exchange_f64(plan, a.device_ptr, 0, sp))
+        D.copy_field(a, b, stream=s)
+
+    def plain(a, b):
+        D._cabi.check(L.dlesm_stencil5_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *box, sp))
+
+    def serial(a, b):   # stencil, then the exchange of the result on the same stream: no overlap
+        D._cabi.check(L.dlesm_stencil5_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *box, sp))
+        D._cabi.check(L.dlesm_halo_exchange_f64(plan, b.device_ptr, 0, sp))
+
+    def overlapped(a, b):
+        D._cabi.check(L.dlesm_jacobi5_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *box, sp))
+
+    res = {}
+    finals = {}
+    with torch.cuda.stream(s):
+        for name, fn in (("plain", plain), ("serial", serial), ("overlapped", overlapped)):
+            a, b = F[0], F[1]                         # the same two buffers for every mode
+            init(a, b)
+            for _ in range(5):
+                fn(a, b)
+                a, b = b, a
+            init(a, b)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            for _ in range(args.steps):
+                fn(a, b)
+                a, b = b, a
+            e1.record(s)
+            s.synchronize()
+            res[name] = e0.elapsed_time(e1) / args.steps
+            finals[name] = a.data.clone()
+    same = bool(torch.equal(finals["serial"], finals["overlapped"]))
+    cells = args.tile * args.tile
+    out = {"tile": args.tile, "steps": args.steps, "ms_per_step": res,
+           "mcells_per_s": {k: cells / v / 1e3 for k, v in res.items()},
+           "overlapped_equals_serial_bitwise": same,
+           "overlap_efficiency_vs_plain": res["plain"] / res["overlapped"]}
+    print(json.dumps(out, indent=1))
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    json.dump(out, open(args.out, "w"), indent=1)
+    assert same, "overlapped distributed step differs from stencil+exchange"
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,31 @@ probe)
     step probeW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/probe_write -- python3 scripts/pmc_probe.py > $OUT/probe_write.log 2>&1
     python scripts/parse_probe.py $OUT/probe_fetch $OUT/probe_write > $OUT/probe_table.txt 2>&1
     cat $OUT/probe_table.txt ;;
+dm)
+    step dm8192 300 python scripts/dm_overhead.py --tile 8192 --out $OUT/dm_overhead_8192.json > $OUT/dm_overhead_8192.log 2>&1
+    tail -22 $OUT/dm_overhead_8192.log
+    step dm16384 300 python scripts/dm_overhead.py --tile 16384 --out $OUT/dm_overhead_16384.json > $OUT/dm_overhead_16384.log 2>&1
+    tail -22 $OUT/dm_overhead_16384.log ;;
+dmprof)
+    rm -rf $OUT/dm_prof
+    step dmprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dm_prof -- python3 scripts/dm_overhead.py --tile ${DM_TILE:-16384} --steps 20 --out $OUT/dm_overhead_prof.json > $OUT/dm_prof.log 2>&1
+    python scripts/parse_rocprof.py stats $OUT/dm_prof $OUT/dm_prof_summary.md | cut -c1-170 | tail -14 ;;
+configs)
+    : > $OUT/configs.jsonl
+    for cfg in "4096 64" "8192 64" "16384 64" "16384 1" "4096 1"; do
+        set -- $cfg
+        step "cfg$1a$2" 300 python bench.py --tile $1 --alignment $2 --steps 100 --warmup 10 --cpu-seconds 4 >> $OUT/configs.jsonl 2>> $OUT/configs.err
+    done
+    python - <<'PYEOF'
+import json
+for l in open("gpurun_out/configs.jsonl"):
+    if not l.startswith("{"): continue
+    d = json.loads(l)
+    c = d["cpu_baseline"] or {}
+    print(d["config"]["tile"], d["config"]["DL_ESM_ALIGNMENT"], d["config"]["ld"], d["value"], d["hbm_gbs_per_gpu"],
+          d["roofline"]["frac"], c.get("value"), c.get("single_core_value"))
+PYEOF
+    ;;
 tune)
     # TUNE_ARGS: the --grid ... arguments of scripts/sweep_tune.py
     step tune 500 python scripts/sweep_tune.py ${TUNE_ARGS} --out $OUT/sweep_tune.json > $OUT/sweep_tune.log 2>&1
