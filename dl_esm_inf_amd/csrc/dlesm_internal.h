@@ -47,6 +47,15 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
 int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop,
                           int ystart, int ystop, hipStream_t s);
 
+// block shape (waves per workgroup, padded tiles per row) of a linear tile sweep
+void choose_block_shape(int *nxw_io, int *tpb_out);
+int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart, int ystop, int ring);
+// shallow-water step, register-tiled linear sweep (dlesm_shallow.hip); 0-based inclusive box
+void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,
+                         const double *u, const double *v, const double *p, const double *uold,
+                         const double *vold, const double *pold, double *unew, double *vnew,
+                         double *pnew, hipStream_t s);
+
 } // namespace dlesm
 
 struct dlesm_field {

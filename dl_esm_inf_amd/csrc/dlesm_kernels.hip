@@ -284,6 +284,33 @@ __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ 
     }
 }
 
+// Block shape of a linear tile sweep.  Workgroups go round-robin to the 8 XCDs, so the tile
+// below a given tile runs on the XCD (blocks per row) mod 8 further on, and the re-read of the
+// rows they share is an L2 hit only when that is ~0.  Rule fitted to measurements
+// (scripts/pad_probe.py, scripts/size_probe.py): blocks per row must sit in [8k, 8k + 1/4];
+// take the block size (2..16 waves) that gets there with the fewest idle padding tiles per
+// row; an exact multiple is skewed by one idle tile for wide rows.
+void choose_block_shape(int *nxw_io, int *tpb_out)
+{
+    int nxw = *nxw_io, tpb = 4, pad = 0;
+    const int forced = tuning("j5_tpb", 0);
+    double best = 1e9;
+    for (int cand : {8, 4, 2, 16}) {
+        if (forced && cand != forced) continue;
+        const int period = 8 * cand, slack = cand / 4;
+        if (nxw < period && !forced) continue;        // fewer than 8 blocks per row
+        const int r = nxw % period, p = r <= slack ? 0 : period - r;
+        const double cost = (double)p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : cand == 2 ? 0.03 : 0.04);
+        if (cost < best) { best = cost; tpb = cand; pad = p; }
+    }
+    if (best > 0.25 && !forced) { tpb = 4; pad = 0; } // nothing fits cheaply (narrow boxes)
+    nxw += pad;
+    if (tuning("j5_skew", 1) && nxw >= 128 && nxw % (8 * tpb) == 0) nxw += 1;
+    nxw += tuning("j5_pad_tiles", 0);
+    *nxw_io = nxw;
+    *tpb_out = tpb;
+}
+
 template <int VEC, bool NT>
 static void launch_tile(const double *in, double *out, int ld, int x0, int x1, int y0, int y1, int R,
                         int nbands, int gs, int flags, hipStream_t s)
@@ -314,23 +341,7 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
             // is the sweet spot at 16384^2, 33 blocks per row costs 19 %.  Pick the block size
             // (2..16 waves) that brings blocks-per-row closest above a multiple of 8, and skew
             // an exact multiple by one idle tile per row.
-            // Rule fitted to those measurements: blocks per row must sit in [8k, 8k + 1/4];
-            // take the block size that gets there with the fewest idle padding tiles.
-            const int forced = tuning("j5_tpb", 0);
-            int pad = 0;
-            double best = 1e9;
-            for (int cand : {8, 4, 2, 16}) {
-                if (forced && cand != forced) continue;
-                const int period = 8 * cand, slack = cand / 4;
-                if (nxw < period && !forced) continue;        // fewer than 8 blocks per row
-                const int r = nxw % period, p = r <= slack ? 0 : period - r;
-                const double cost = (double)p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : cand == 2 ? 0.03 : 0.04);
-                if (cost < best) { best = cost; tpb = cand; pad = p; }
-            }
-            if (best > 0.25 && !forced) { tpb = 4; pad = 0; } // nothing fits cheaply (narrow boxes)
-            nxw += pad;
-            if (tuning("j5_skew", 1) && nxw >= 128 && nxw % (8 * tpb) == 0) nxw += 1;
-            nxw += tuning("j5_pad_tiles", 0);
+            choose_block_shape(&nxw, &tpb);
         }
         const long tiles = (long)nxw * (band_rows / R);  // per band
         grid = (unsigned)(((tiles + tpb - 1) / tpb) * nbands);
@@ -377,8 +388,8 @@ __global__ __launch_bounds__(256) void jacobi5_frame(const double *__restrict__ 
     }
 }
 
-static int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
-                     int ring)
+int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+              int ring)
 {
     if (ld < 1 || ny < 1) return fail(DLESM_EINVAL, "%s: array extents %dx%d", who, ld, ny);
     if (xstart - ring < 1 || xstop + ring > ld || ystart - ring < 1 || ystop + ring > ny)
@@ -636,8 +647,21 @@ extern "C" int dlesm_shallow_step_f64(const dlesm_sw_params *q, int ld, int ny, 
                       pnew != u && pnew != v && pnew != p,
                   "shallow step: outputs alias the 3x3-read inputs");
     const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
+    bool aligned = ld % 2 == 0;
+    for (const double *f : {u, v, p, uold, vold, pold, (const double *)unew, (const double *)vnew,
+                            (const double *)pnew})
+        aligned = aligned && ((uintptr_t)f % 16 == 0);
+    // sw_kernel: 1 (default) = direct form, 62.7 % of HBM peak at 8192^2; 0 = register-tiled
+    // sweep of dlesm_shallow.hip, 59.6 % so far (profiles/r01_shallow_bench.json)
+    if (aligned && tuning("sw_kernel", 1) == 0) {
+        launch_shallow_tile(*q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold,
+                            unew, vnew, pnew, (hipStream_t)stream);
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
+    // odd leading dimension: direct form, neighbours through L1/L2
     dim3 block(256), grid((nx + 255) / 256, nyb);
-    DLESM_REQUIRE(nyb <= 65535 * 1024, "box too tall");
+    DLESM_REQUIRE(nyb <= 65535, "box too tall for the direct kernel");
     hipLaunchKernelGGL(shallow_step_direct, grid, block, 0, (hipStream_t)stream, *q, ld, xstart - 1,
                        xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold, unew, vnew, pnew);
     DLESM_HIP_TRY(hipGetLastError());

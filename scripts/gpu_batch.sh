@@ -61,6 +61,9 @@ dm)
     tail -22 $OUT/dm_overhead_8192.log
     step dm16384 300 python scripts/dm_overhead.py --tile 16384 --out $OUT/dm_overhead_16384.json > $OUT/dm_overhead_16384.log 2>&1
     tail -22 $OUT/dm_overhead_16384.log ;;
+shallow)
+    step shallow 400 python scripts/shallow_bench.py --out $OUT/shallow_bench.json > $OUT/shallow_bench.log 2>&1
+    grep -v amdgpu.ids $OUT/shallow_bench.log | tail -8 ;;
 dmprof)
     rm -rf $OUT/dm_prof
     step dmprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dm_prof -- python3 scripts/dm_overhead.py --tile ${DM_TILE:-16384} --steps 20 --out $OUT/dm_overhead_prof.json > $OUT/dm_prof.log 2>&1

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: GOcean shallow-water u/v/h update, 8192x8192 fp64, one MI355X.
+Times the fused step (72 B/cell algorithmic) for the register-tiled kernel (R = 1, 2) and the
+direct-load kernel, leapfrog buffer rotation between steps, and the CPU oracle on a bounded sample.
+
+    python scripts/shallow_bench.py [--tile 8192] [--steps 40]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tile", type=int, default=8192)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--out", default="gpurun_out/shallow_bench.json")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import dl_esm_inf_amd as D
+    L = D._cabi.lib()
+    torch.cuda.set_device(0)
+    os.environ["DL_ESM_ALIGNMENT"] = "64"
+    D.parallel_init(0, 1)
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    g.decompose(args.tile, args.tile)
+    D.grid_init(g, 1.0, 1.0)
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    s = torch.cuda.Stream()
+    F = {}
+    with torch.cuda.stream(s):
+        for k, name in enumerate(["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]):
+            f = D.r2d_field(g, pts[name[0]])
+            D.psy.hash_init(f, 20261004 + k, stream=s)
+            if name[0] == "p":
+                f.data.add_(1.0)
+            else:
+                f.data.sub_(0.5)
+            F[name] = f
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
+    cells = args.tile * args.tile
+    res = {}
+    with torch.cuda.stream(s):
+        for label, kern, rows in (("tile R=2", 0, 2), ("tile R=1", 0, 1), ("direct", 1, 2), ("tile R=2 again", 0, 2)):
+            L.dlesm_set_tuning(b"sw_kernel", kern)
+            L.dlesm_set_tuning(b"sw_tile_rows", rows)
+            cur = [F["u"], F["v"], F["p"]]
+            old = [F["uold"], F["vold"], F["pold"]]
+            new = [F["unew"], F["vnew"], F["pnew"]]
+            ts = []
+            for rnd in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+                for _ in range(args.steps):
+                    D.psy.invoke_shallow_step(prm, *cur, *old, *new, stream=s)
+                    old, cur, new = cur, new, old          # leapfrog rotation
+                e1.record(s)
+                s.synchronize()
+                if rnd:
+                    ts.append(e0.elapsed_time(e1) / args.steps)
+            ms = min(ts)
+            res[label] = {"ms_per_step": ms, "mcells_per_s": cells / ms / 1e3, "gbs_72B": 72.0 * cells / ms / 1e6,
+                          "frac_of_8TBs": 72.0 * cells / ms / 1e6 / 8000.0}
+            print(f"{label:16s} {ms:.4f} ms/step  {cells / ms / 1e3:9.0f} Mcells/s  {72.0 * cells / ms / 1e6:6.0f} GB/s "
+                  f"({72.0 * cells / ms / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+    out = {"tile": args.tile, "ld": g.nx, "steps": args.steps, "algorithmic_bytes_per_cell": 72, "gpu": res}
+    if not args.no_cpu:
+        import oracle_lib as O
+        n = min(args.tile, 4096)                              # bounded CPU sample: n x n cells
+        ld, ny = O.grid_extents(n + 2, n + 2, 64)
+        rng = np.random.default_rng(0)
+        H = [rng.random((ny, ld)) + (1.0 if k % 3 == 2 else -0.5) for k in range(6)]
+        scratch = [np.zeros((ny, ld)) for _ in range(7)]
+        op = O.SwParams(prm.fsdx, prm.fsdy, prm.tdts8, prm.tdtsdx, prm.tdtsdy)
+        O.lib().orc_sw_step(C.byref(op), ld, 2, n + 1, 2, n + 1, *H, *scratch)
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 6.0:
+            O.lib().orc_sw_step(C.byref(op), ld, 2, n + 1, 2, n + 1, *H, *scratch)
+            reps += 1
+        dt = time.perf_counter() - t0
+        out["cpu_oracle_1core"] = {"mcells_per_s": n * n * reps / dt / 1e6, "sample": f"{reps} steps of {n}x{n}"}
+        print(f"CPU oracle (1 core, un-fused GOcean kernel sequence): {n * n * reps / dt / 1e6:.1f} Mcells/s", flush=True)
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    json.dump(out, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
