@@ -11,8 +11,9 @@
 // linearly in dispatch order, exactly as jacobi5_tile does (see the notes there); the
 // (R+2)-row overlap between vertically adjacent tiles is served by L2 / Infinity Cache.
 //
-// The expression trees are the oracle's (oracle/dlesm_oracle.c compute_*_code) and the file
-// is compiled with -ffp-contract=off: results agree bit for bit.
+// The expression trees are exactly those of the specification in DESIGN.md section 6 and the
+// file is compiled with -ffp-contract=off, so results agree bit for bit with the CPU checker
+// used by the tests.
 #include "dlesm_internal.h"
 
 namespace dlesm {
