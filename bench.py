@@ -125,6 +125,30 @@ def main():
 
     step = D.psy.invoke_jacobi5_dm if world > 1 else D.psy.invoke_jacobi5
 
+    # N > 1: before timing anything, three overlapped distributed steps must reproduce, bit for
+    # bit on every rank, three plain "stencil, then halo exchange" steps from the same state
+    selfcheck = None
+    if world > 1:
+        x1, y1 = D.r2d_field(grid, D.GO_T_POINTS), D.r2d_field(grid, D.GO_T_POINTS)
+        x2, y2 = D.r2d_field(grid, D.GO_T_POINTS), D.r2d_field(grid, D.GO_T_POINTS)
+        with torch.cuda.stream(stream):
+            for f in (x1, y1, x2, y2):
+                D.copy_field(a, f, stream=stream)
+            for _ in range(3):
+                D.psy.invoke_jacobi5_dm(y1, x1, stream=stream)
+                x1, y1 = y1, x1
+                D.psy.invoke_jacobi5(y2, x2, stream=stream)
+                y2.halo_exchange(1, stream=stream)
+                x2, y2 = y2, x2
+        stream.synchronize()
+        ok = torch.tensor([1 if torch.equal(x1.data, x2.data) else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        selfcheck = bool(int(ok[0]))
+        del x1, y1, x2, y2
+        torch.cuda.empty_cache()
+        if not selfcheck:
+            raise SystemExit("bench.py: overlapped distributed step differs from stencil + exchange")
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -178,7 +202,7 @@ def main():
                    "global": [args.tile * P, args.tile * Q], "DL_ESM_ALIGNMENT": args.alignment,
                    "ld": grid.nx, "halo_exchange": "rccl send/recv, overlapped" if world > 1 else "none (1 tile)"},
         "hbm_gbs_per_gpu": round(achieved, 1),
-        "checksum": checksum,
+        "checksum": checksum, "dm_step_equals_stencil_plus_exchange": selfcheck,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "jacobi5_tile<2,2>", "launch_ms": round(launch_ms, 5),

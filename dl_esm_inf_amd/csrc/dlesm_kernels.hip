@@ -294,10 +294,15 @@ void choose_block_shape(int *nxw_io, int *tpb_out)
 {
     int nxw = *nxw_io, tpb = 4, pad = 0;
     const int forced = tuning("j5_tpb", 0);
+    if (!tuning("j5_autoshape", 1)) {                 // experiments: plain shape, no padding
+        *tpb_out = (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) ? forced : 4;
+        *nxw_io = nxw + tuning("j5_pad_tiles", 0);
+        return;
+    }
     double best = 1e9;
     for (int cand : {8, 4, 2, 16}) {
         if (forced && cand != forced) continue;
-        const int period = 8 * cand, slack = cand / 4;
+        const int period = 8 * cand, slack = 3 * cand / 8;   // up to 3/8 of a block past 8k
         if (nxw < period && !forced) continue;        // fewer than 8 blocks per row
         const int r = nxw % period, p = r <= slack ? 0 : period - r;
         const double cost = (double)p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : cand == 2 ? 0.03 : 0.04);
@@ -651,9 +656,9 @@ extern "C" int dlesm_shallow_step_f64(const dlesm_sw_params *q, int ld, int ny, 
     for (const double *f : {u, v, p, uold, vold, pold, (const double *)unew, (const double *)vnew,
                             (const double *)pnew})
         aligned = aligned && ((uintptr_t)f % 16 == 0);
-    // sw_kernel: 1 (default) = direct form, 62.7 % of HBM peak at 8192^2; 0 = register-tiled
-    // sweep of dlesm_shallow.hip, 59.6 % so far (profiles/r01_shallow_bench.json)
-    if (aligned && tuning("sw_kernel", 1) == 0) {
+    // sw_kernel: 0 (default) = register-tiled sweep of dlesm_shallow.hip, 73.7 % of HBM peak at
+    // 8192^2; 1 = direct form, 62 % (scripts/shallow_probe.py, profiles/r01_shallow_*.txt)
+    if (aligned && tuning("sw_kernel", 0) == 0) {
         launch_shallow_tile(*q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold,
                             unew, vnew, pnew, (hipStream_t)stream);
         DLESM_HIP_TRY(hipGetLastError());

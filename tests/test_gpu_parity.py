@@ -368,4 +368,4 @@ def test_shallow_step_matches_oracle(D, nx, ny, alignment, sw_kernel, sw_rows):
         err = np.max(np.abs(got - want[n]) / np.maximum(np.abs(want[n]), 1e-300))
         assert err <= 1e-12, (n, err)
         assert np.array_equal(got, want[n]), (n, "not bit-exact", err)
-    _set_tuning(D, sw_kernel=1, sw_tile_rows=2)
+    _set_tuning(D, sw_kernel=0, sw_tile_rows=2)
