@@ -1,0 +1,76 @@
+!> A GOcean-style application on the MI355X library: algorithm layer in plain Fortran with
+!! the dl_esm_inf API (grid_type, r2d_field, halo_exchange, field_checksum), PSy layer =
+!! the HIP launch wrappers of dlesm_psy_mod.  5-point Jacobi ping-pong on a T field.
+!!
+!!   jacobi_app.exe [N] [NSTEPS]              (default 4096 100; DL_ESM_ALIGNMENT honoured)
+!! One process per GPU: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT in the environment (e.g.
+!!   for r in 0 1; do RANK=$r WORLD_SIZE=2 LOCAL_RANK=$r MASTER_PORT=29400 ./jacobi_app.exe & done).
+!! With more than one rank the global domain is (N*P) x (N*Q) so that every rank owns N x N.
+program jacobi_app
+  use iso_c_binding
+  use kind_params_mod
+  use parallel_mod
+  use grid_mod
+  use field_mod
+  use gocean_mod
+  use dlesm_psy_mod
+  implicit none
+  character(len=32) :: arg
+  integer :: n, nsteps, i, p, q, nr
+  integer(8) :: t0, t1, rate
+  type(grid_type), target :: model_grid
+  type(r2d_field), target :: a, b
+  real(go_wp) :: cs, secs
+
+  n = 4096;  nsteps = 100
+  if (command_argument_count() >= 1) then
+     call get_command_argument(1, arg);  read(arg, *) n
+  end if
+  if (command_argument_count() >= 2) then
+     call get_command_argument(2, arg);  read(arg, *) nsteps
+  end if
+
+  call gocean_initialise()
+  nr = get_num_ranks()
+  p = int(sqrt(real(nr)))
+  do while (mod(nr, p) /= 0)
+     p = p - 1
+  end do
+  q = nr / p
+
+  model_grid = grid_type(GO_ARAKAWA_C, (/GO_BC_EXTERNAL, GO_BC_EXTERNAL, GO_BC_NONE/), GO_OFFSET_NE)
+  call model_grid%decompose(n * p, n * q)
+  call grid_init(model_grid, 1.0_go_wp, 1.0_go_wp)
+  a = r2d_field(model_grid, GO_T_POINTS)
+  b = r2d_field(model_grid, GO_T_POINTS)
+
+  ! ---- PSy layer --------------------------------------------------------------------
+  call invoke_hash_init(a, 20261004_c_int64_t)   ! includes the fixed boundary ring
+  call invoke_copy(b, a)
+  call a%halo_exchange(1)
+  call model_write_log("('initial checksum = ',E24.16)", field_checksum(a))
+
+  call device_sync()
+  call system_clock(t0, rate)
+  do i = 1, nsteps
+     if (mod(i, 2) == 1) then
+        call invoke_jacobi5_dm(b, a)      ! exchange of the result hidden behind the interior
+     else
+        call invoke_jacobi5_dm(a, b)
+     end if
+  end do
+  call device_sync()
+  call system_clock(t1)
+  secs = real(t1 - t0, go_wp) / real(rate, go_wp)
+
+  if (mod(nsteps, 2) == 1) then
+     cs = field_checksum(b)
+  else
+     cs = field_checksum(a)
+  end if
+  call model_write_log("('final checksum   = ',E24.16)", cs)
+  call model_write_log("('Mcells/s (all ranks) = ',F14.1)", &
+       real(n, go_wp) * real(n, go_wp) * real(nr, go_wp) * real(nsteps, go_wp) / secs / 1.0e6_go_wp)
+  call free_field(a);  call free_field(b)
+  call gocean_finalise()
+end program jacobi_app
