@@ -6,8 +6,37 @@
 !! One process per GPU: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT in the environment (e.g.
 !!   for r in 0 1; do RANK=$r WORLD_SIZE=2 LOCAL_RANK=$r MASTER_PORT=29400 ./jacobi_app.exe & done).
 !! With more than one rank the global domain is (N*P) x (N*Q) so that every rank owns N x N.
+!> The kernel as a GOcean kernel module: metadata type (what PSyclone reads at code-generation
+!! time: access modes, grid-point types, the 5-point stencil, iteration space) + the pointwise
+!! code.  On MI355X the PSy layer launches the HIP implementation of exactly this kernel
+!! (invoke_jacobi5 / invoke_jacobi5_dm) instead of looping over jacobi5_code.
+module jacobi5_mod
+  use kind_params_mod
+  use kernel_mod
+  use argument_mod
+  use grid_mod
+  implicit none
+  type, extends(kernel_type) :: jacobi5
+     type(go_arg), dimension(2) :: meta_args =                      &
+          (/ go_arg(GO_WRITE, GO_CT, GO_POINTWISE),                  & ! out
+             go_arg(GO_READ,  GO_CT, go_stencil(010, 101, 010)) /)     ! in: W, E, S, N neighbours
+     integer :: ITERATES_OVER = GO_INTERNAL_PTS
+     integer :: index_offset = GO_OFFSET_ANY
+   contains
+     procedure, nopass :: code => jacobi5_code
+  end type jacobi5
+contains
+  subroutine jacobi5_code(ji, jj, out, in)
+    integer, intent(in) :: ji, jj
+    real(go_wp), dimension(:,:), intent(out) :: out
+    real(go_wp), dimension(:,:), intent(in) :: in
+    out(ji, jj) = 0.25_go_wp * ((in(ji-1, jj) + in(ji+1, jj)) + (in(ji, jj-1) + in(ji, jj+1)))
+  end subroutine jacobi5_code
+end module jacobi5_mod
+
 program jacobi_app
   use iso_c_binding
+  use jacobi5_mod, only: jacobi5
   use kind_params_mod
   use parallel_mod
   use grid_mod

@@ -27,11 +27,6 @@ case $what in
 tests)
     step tests 1000 python -m pytest tests -m gpu -q -x --timeout=600 > $OUT/gpu_tests.log 2>&1
     tail -15 $OUT/gpu_tests.log ;;
-sweep)
-    step sweep64 300 python scripts/sweep_j5.py --out $OUT/sweep_a64.json > $OUT/sweep_a64.log 2>&1
-    head -12 $OUT/sweep_a64.log
-    step sweep1 200 python scripts/sweep_j5.py --alignment 1 --variants 0,1 --rows 16,64,256 --out $OUT/sweep_a1.json > $OUT/sweep_a1.log 2>&1
-    head -8 $OUT/sweep_a1.log ;;
 prof)
     rm -rf $OUT/prof_stats
     step prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/prof_stats.log 2>&1
@@ -47,9 +42,6 @@ bench)
     cat $OUT/bench.json ;;
 smoke)
     step smoke 200 python __graft_entry__.py smoke ;;
-sweep2)
-    step sweep2 400 python scripts/sweep_j5.py --variants ${SWEEP_VARIANTS:-0,2} --rows ${SWEEP_ROWS:-0,8,16,264,265,270,300,530} --unroll ${SWEEP_UNROLL:-2,4,8} --out $OUT/sweep2.json > $OUT/sweep2.log 2>&1
-    head -${SWEEP_HEAD:-30} $OUT/sweep2.log ;;
 probe)
     rm -rf $OUT/probe_fetch $OUT/probe_write
     step probeF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/probe_fetch -- python3 scripts/pmc_probe.py > $OUT/probe_fetch.log 2>&1
