@@ -48,7 +48,7 @@ module dlesm_psy_mod
   private
 
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
-  public :: shallow_params, c_sw_params, device_sync
+  public :: shallow_params, c_sw_params, device_sync, grid_to_device
 
 contains
 
@@ -120,6 +120,38 @@ contains
                                 c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_shallow_step: ' // dlesm_error_text())
   end subroutine invoke_shallow_step
+
+  !> Device mirrors of the grid properties a kernel may request through its metadata
+  !! (GO_GRID_MASK_T, GO_GRID_DX_T, GO_GRID_AREA_T, ... argument_mod): fills the `*_device`
+  !! pointers of grid_type (reference grid_mod.f90:104-150) with HBM copies of the host arrays.
+  !! Idempotent; arrays keep the field layout (grid%nx x grid%ny, column-major).
+  subroutine grid_to_device(grid)
+    type(grid_type), intent(inout), target :: grid
+    integer(c_size_t) :: nb
+    nb = int(grid%nx, c_size_t) * int(grid%ny, c_size_t) * 8_c_size_t
+    if (.not. c_associated(grid%tmask_device) .and. allocated(grid%tmask)) then
+       if (hipMalloc(grid%tmask_device, nb / 2) /= 0) call gocean_stop('grid_to_device: hipMalloc failed')
+       if (hipMemcpy(grid%tmask_device, c_loc(grid%tmask), nb / 2, 1_c_int) /= 0) &
+            call gocean_stop('grid_to_device: upload failed')
+    end if
+    call mirror(grid%dx_t, grid%dx_t_device);  call mirror(grid%dy_t, grid%dy_t_device)
+    call mirror(grid%dx_u, grid%dx_u_device);  call mirror(grid%dy_u, grid%dy_u_device)
+    call mirror(grid%dx_v, grid%dx_v_device);  call mirror(grid%dy_v, grid%dy_v_device)
+    call mirror(grid%dx_f, grid%dx_f_device);  call mirror(grid%dy_f, grid%dy_f_device)
+    call mirror(grid%area_t, grid%area_t_device);  call mirror(grid%area_u, grid%area_u_device)
+    call mirror(grid%area_v, grid%area_v_device)
+    call mirror(grid%gphiu, grid%gphiu_device);  call mirror(grid%gphiv, grid%gphiv_device)
+    call mirror(grid%gphif, grid%gphif_device)
+    call mirror(grid%xt, grid%xt_device);  call mirror(grid%yt, grid%yt_device)
+  contains
+    subroutine mirror(host, dev)
+      real(go_wp), allocatable, target, intent(in) :: host(:,:)
+      type(c_ptr), intent(inout) :: dev
+      if (c_associated(dev) .or. .not. allocated(host)) return
+      if (hipMalloc(dev, nb) /= 0) call gocean_stop('grid_to_device: hipMalloc failed')
+      if (hipMemcpy(dev, c_loc(host), nb, 1_c_int) /= 0) call gocean_stop('grid_to_device: upload failed')
+    end subroutine mirror
+  end subroutine grid_to_device
 
   !> The `copy` kernel of infrastructure_mod over all points
   subroutine invoke_copy(out, in)

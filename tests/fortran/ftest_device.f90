@@ -43,6 +43,9 @@ program ftest_device
      write(*, '("G: io ",20f5.1)') test_field%data(:, i)
   end do
 
+  ! ---- (1b) device mirrors of the grid properties ------------------------------
+  call check_mirrors(io_grid)
+
   ! ---- (2) Jacobi through the PSy layer --------------------------------------
   model_grid = grid_type(GO_ARAKAWA_C, (/GO_BC_EXTERNAL, GO_BC_EXTERNAL, GO_BC_NONE/), GO_OFFSET_NE)
   call model_grid%decompose(nx, ny)
@@ -73,6 +76,25 @@ program ftest_device
   call gocean_finalise()
 
 contains
+
+  subroutine check_mirrors(g)
+    type(grid_type), intent(inout), target :: g
+    real(go_wp), allocatable, target :: back(:,:)
+    integer, allocatable, target :: mback(:,:)
+    integer :: nbad
+    call grid_to_device(g)
+    call grid_to_device(g)                       ! idempotent
+    allocate(back(g%nx, g%ny), mback(g%nx, g%ny))
+    nbad = 0
+    rc = hipMemcpy(c_loc(back), g%xt_device, int(g%nx, c_size_t) * int(g%ny, c_size_t) * 8_c_size_t, 2_c_int)
+    nbad = nbad + count(back /= g%xt) + rc
+    rc = hipMemcpy(c_loc(back), g%area_t_device, int(g%nx, c_size_t) * int(g%ny, c_size_t) * 8_c_size_t, 2_c_int)
+    nbad = nbad + count(back /= g%area_t) + rc
+    rc = hipMemcpy(c_loc(mback), g%tmask_device, int(g%nx, c_size_t) * int(g%ny, c_size_t) * 4_c_size_t, 2_c_int)
+    nbad = nbad + count(mback(2:6, 2:6) /= g%tmask(2:6, 2:6)) + rc
+    if (.not. c_associated(g%gphif_device) .or. .not. c_associated(g%dy_v_device)) nbad = nbad + 1
+    write(*, '("G: mirrors ",I0)') nbad
+  end subroutine check_mirrors
 
   !> multiply the device copy by two without touching the host copy: t = get; t*2; put
   subroutine double_on_device(f)

@@ -124,6 +124,8 @@ def test_fortran_device_io_and_jacobi_on_gpu(exe):
     # (1) the reference's device-io scenario, on the real device
     gold = next(r for r in load_golden("ref_device_io")["runs"] if r["alignment"] == 8)
     assert [[float(x) for x in row] for row in g["io"]] == gold["rows"]
+    # (1b) grid-property device mirrors (grid%*_device) hold the host arrays
+    assert int(g["mirrors"][0][0]) == 0
     # (2) Jacobi through the Fortran PSy layer == oracle
     ld, nyy = ints(g["grid"][0])
     assert (ld, nyy) == O.grid_extents(nx + 2, ny + 2, 8)
