@@ -371,3 +371,45 @@ def test_shallow_step_matches_oracle(D, nx, ny, alignment, sw_kernel, sw_rows):
         assert err <= 1e-12, (n, err)
         assert np.array_equal(got, want[n]), (n, "not bit-exact", err)
     _set_tuning(D, sw_kernel=0, sw_tile_rows=2)
+
+
+@pytest.mark.parametrize("nx,ny", [(1, 1), (2, 2), (1, 6), (6, 1), (3, 3), (130, 5), (5, 130), (257, 64)])
+def test_distributed_step_on_small_and_ragged_boxes(D, nx, ny):
+    """dlesm_jacobi5_step_dm (frame + side-stream exchange + interior) == stencil followed by the
+    halo exchange of the result, for degenerate boxes too (1 cell, 1 row, 1 column, no interior);
+    RCCL in loop-back with all eight directions (scripts/dm_overhead.py tables)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dm_overhead import loopback_tables
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    g = _grid(D, nx, ny, 2)
+    a, b, c = (D.r2d_field(g, D.GO_T_POINTS) for _ in range(3))
+    it = a.internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    D.psy.hash_init(a, SEED + 3)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, a.device_ptr, 0, None))
+    D.copy_field(a, b)
+    D.copy_field(a, c)
+    x, y, z = a, b, c
+    for _ in range(3):
+        D._cabi.check(L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), None))
+        torch.cuda.synchronize()
+        D.psy.invoke_jacobi5(z, x)
+        D._cabi.check(L.dlesm_halo_exchange_f64(plan, z.device_ptr, 0, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(y.get_data(), z.get_data())
+        # and both equal the oracle: stencil, then the same exchange on the host
+        hx = x.get_data()
+        want = hx.copy()
+        O.jacobi5(hx, want, g.nx, *it.box())
+        oc = O.Comms()
+        C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+        assert O.exchange_all([want], [g.nx], [oc]) == 0
+        assert np.array_equal(y.get_data(), want)
+        x, y = y, x
+        D.copy_field(x, z)
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
