@@ -56,6 +56,13 @@ dm)
 shallow)
     step shallow 400 python scripts/shallow_bench.py --out $OUT/shallow_bench.json > $OUT/shallow_bench.log 2>&1
     grep -v amdgpu.ids $OUT/shallow_bench.log | tail -8 ;;
+shallowpmc)
+    rm -rf $OUT/swpmc_fetch $OUT/swpmc_write $OUT/sw_prof
+    step swF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/swpmc_fetch -- python3 scripts/shallow_bench.py --steps 3 --no-cpu --out $OUT/sw_tmp.json > $OUT/swpmc_fetch.log 2>&1
+    step swW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/swpmc_write -- python3 scripts/shallow_bench.py --steps 3 --no-cpu --out $OUT/sw_tmp.json > $OUT/swpmc_write.log 2>&1
+    python scripts/parse_rocprof.py pmc $OUT/swpmc_fetch $OUT/swpmc_write "shallow 8192x8192/A64" $OUT/traffic_shallow.json shallow_tile 2>&1 | tail -12
+    step swP 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sw_prof -- python3 scripts/shallow_bench.py --steps 10 --no-cpu --out $OUT/sw_tmp.json > $OUT/sw_prof.log 2>&1
+    python scripts/parse_rocprof.py stats $OUT/sw_prof $OUT/sw_prof_summary.md | cut -c1-170 | tail -8 ;;
 dmprof)
     rm -rf $OUT/dm_prof
     step dmprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dm_prof -- python3 scripts/dm_overhead.py --tile ${DM_TILE:-16384} --steps 20 --out $OUT/dm_overhead_prof.json > $OUT/dm_prof.log 2>&1
