@@ -72,10 +72,49 @@ program ftest_device
   end if
   write(*, '("G: cs ",ES24.16E3)') cs
   write(*, '("G: sample ",3(ES24.16E3,1x))') h(2, 2), h(nx/2 + 1, ny/2 + 1), h(nx + 1, ny + 1)
+
+  ! ---- (3) one shallow-water step through the PSy layer ------------------------
+  call shallow_step(model_grid)
   call free_field(a);  call free_field(b);  call free_field(test_field)
   call gocean_finalise()
 
 contains
+
+  !> u, v, p and their old copies from the counter hash (seeds 1..6, p shifted to [1,2), u, v to
+  !! [-0.5,0.5)), new fields preset to 9: one fused step, checksums and a sample printed
+  subroutine shallow_step(g)
+    type(grid_type), intent(in), target :: g
+    type(r2d_field), target :: f(9)
+    integer :: k, ptype(9)
+    real(go_wp), pointer :: d(:,:)
+    ptype = (/ GO_U_POINTS, GO_V_POINTS, GO_T_POINTS, GO_U_POINTS, GO_V_POINTS, GO_T_POINTS, &
+               GO_U_POINTS, GO_V_POINTS, GO_T_POINTS /)
+    do k = 1, 9
+       f(k) = r2d_field(g, ptype(k))
+    end do
+    do k = 1, 6
+       call invoke_hash_init(f(k), int(k, c_int64_t))
+       d => f(k)%get_data()
+       if (ptype(k) == GO_T_POINTS) then
+          d = d + 1.0_go_wp
+       else
+          d = d - 0.5_go_wp
+       end if
+       call f(k)%write_to_device()
+    end do
+    do k = 7, 9
+       call set_field(f(k), 9.0_go_wp)
+    end do
+    call invoke_shallow_step(shallow_params(1.0e5_go_wp, 1.0e5_go_wp, 90.0_go_wp), &
+                             f(1), f(2), f(3), f(4), f(5), f(6), f(7), f(8), f(9))
+    do k = 7, 9
+       d => f(k)%get_data()
+       write(*, '("G: sw ",I0,1x,3(ES24.16E3,1x))') k, field_checksum(f(k)), d(2, 2), d(nx + 1, ny + 1)
+    end do
+    do k = 1, 9
+       call free_field(f(k))
+    end do
+  end subroutine shallow_step
 
   subroutine check_mirrors(g)
     type(grid_type), intent(inout), target :: g

@@ -140,3 +140,19 @@ def test_fortran_device_io_and_jacobi_on_gpu(exe):
     assert abs(float(g["cs"][0][0]) - cs) <= 1e-12 * cs
     got = [float(x) for x in g["sample"][0]]
     assert got == [a[1, 1], a[ny // 2, nx // 2], a[ny, nx]]
+    # (3) one fused shallow-water step launched from Fortran == oracle
+    import ctypes as C
+    H = []
+    for k in range(1, 7):
+        f = O.hash_field(k, nyy, ld, 0, 0, 1, nx + 2, 1, ny + 2)
+        f[:ny + 2, :nx + 2] += 1.0 if k % 3 == 0 else -0.5
+        H.append(f)
+    outs = [np.full((nyy, ld), 9.0) for _ in range(3)]
+    scratch = [np.zeros((nyy, ld)) for _ in range(4)]
+    tdt = 180.0
+    prm = O.SwParams(4.0 / 1.0e5, 4.0 / 1.0e5, tdt / 8.0, tdt / 1.0e5, tdt / 1.0e5)
+    O.lib().orc_sw_step(C.byref(prm), ld, 2, nx + 1, 2, ny + 1, *H, *scratch, *outs)
+    for row, want in zip(g["sw"], outs):
+        cs_w = O.lib().orc_checksum(want, ld, 2, nx + 1, 2, ny + 1)
+        assert abs(float(row[1]) - cs_w) <= 1e-12 * cs_w
+        assert [float(row[2]), float(row[3])] == [want[1, 1], want[ny, nx]]
