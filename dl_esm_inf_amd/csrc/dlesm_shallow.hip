@@ -160,12 +160,16 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     int nxw = (c_last - cb + 62) / 62, tpb = 4;          // 62 output chunks per wave tile
     choose_block_shape(&nxw, &tpb);
     if (tpb > 8) tpb = 8;                                // the kernel is bounded to 512 threads
-    const int R = tuning("sw_tile_rows", 2) == 1 ? 1 : 2;
+    int R = tuning("sw_tile_rows", 2);
+    if (R != 1 && R != 3) R = 2;
     const int h = y1 - y0 + 1, strips = (h + R - 1) / R;
     const long tiles = (long)nxw * strips;
     const unsigned grid = (unsigned)((tiles + tpb - 1) / tpb);
     if (R == 1)
         hipLaunchKernelGGL(shallow_tile<1>, dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw,
+                           u, v, p, uold, vold, pold, unew, vnew, pnew);
+    else if (R == 3)
+        hipLaunchKernelGGL(shallow_tile<3>, dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw,
                            u, v, p, uold, vold, pold, unew, vnew, pnew);
     else
         hipLaunchKernelGGL(shallow_tile<2>, dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw,

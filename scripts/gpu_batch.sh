@@ -12,12 +12,12 @@ export TMPDIR=/tmp
 
 step() { # name timeout cmd...
     local name=$1 t=$2; shift 2
-    echo "=== [$name] $(date +%T) : $*"
+    echo "=== [$name] $(date +%T) : $*" >&2
     timeout -k 10 "$t" "$@"
     local rc=$?
-    echo "=== [$name] rc=$rc"
+    echo "=== [$name] rc=$rc" >&2
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then
-        echo "=== [$name] TIMED OUT - stopping the batch"; exit 99
+        echo "=== [$name] TIMED OUT - stopping the batch" >&2; exit 99
     fi
     return $rc
 }

@@ -50,7 +50,8 @@ def main():
     cells = args.tile * args.tile
     res = {}
     with torch.cuda.stream(s):
-        for label, kern, rows in (("tile R=2", 0, 2), ("tile R=1", 0, 1), ("direct", 1, 2), ("tile R=2 again", 0, 2)):
+        for label, kern, rows in (("tile R=2", 0, 2), ("tile R=1", 0, 1), ("tile R=3", 0, 3), ("direct", 1, 2),
+                                  ("tile R=2 again", 0, 2)):
             L.dlesm_set_tuning(b"sw_kernel", kern)
             L.dlesm_set_tuning(b"sw_tile_rows", rows)
             cur = [F["u"], F["v"], F["p"]]

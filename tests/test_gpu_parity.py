@@ -338,7 +338,7 @@ def test_halo_exchange_loopback_on_one_gpu(D):
 @pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (5, 4, 2), (64, 48, 8), (300, 70, 64), (257, 129, None),
                                              (1, 1, 2), (123, 3, 2), (124, 5, 2), (125, 2, 2), (1000, 37, 64),
                                              (8000, 9, 64)])
-@pytest.mark.parametrize("sw_kernel,sw_rows", [(0, 2), (0, 1), (1, 2)])
+@pytest.mark.parametrize("sw_kernel,sw_rows", [(0, 2), (0, 1), (0, 3), (1, 2)])
 def test_shallow_step_matches_oracle(D, nx, ny, alignment, sw_kernel, sw_rows):
     import torch
     _set_tuning(D, sw_kernel=sw_kernel, sw_tile_rows=sw_rows)
