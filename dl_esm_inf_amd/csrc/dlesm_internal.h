@@ -8,13 +8,10 @@
 #include <cstdint>
 #include <cstdio>
 
+#include "dlesm_error.h"
 #include "dlesm_hip.h"
 
 namespace dlesm {
-
-// thread-local error text behind dlesm_last_error()
-int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
-void clear_error();
 
 #define DLESM_HIP_TRY(expr)                                                                 \
     do {                                                                                    \

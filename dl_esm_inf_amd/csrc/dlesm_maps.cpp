@@ -13,7 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "dlesm_internal.h"
+#include "dlesm_error.h"   // no HIP here: this file also builds stand-alone (tests/sanitize_maps.cpp)
 
 using dlesm::fail;
 
