@@ -68,7 +68,8 @@ struct dlesm_halo_plan {
     int n_spack = 0, n_rpack = 0;
     Strip *d_spack = nullptr, *d_rpack = nullptr; // device tables
     double *sendbuf = nullptr, *recvbuf = nullptr;
-    long sendbuf_len = 0, recvbuf_len = 0;
+    long sendbuf_len = 0, recvbuf_len = 0;   // doubles per field
+    int buf_fields = 0;                      // fields the buffers currently have room for
     int max_strip = 0;
 };
 
@@ -145,6 +146,8 @@ extern "C" int dlesm_comm_finalize(void)
 extern "C" int dlesm_comm_rank(void) { return g_rank; }
 extern "C" int dlesm_comm_size(void) { return g_size; }
 
+static int ensure_buffers(dlesm_halo_plan *p, int nfields);
+
 static bool by_peer_dir(const Msg &a, const Msg &b)
 {
     return a.peer != b.peer ? a.peer < b.peer : a.dir < b.dir;
@@ -203,8 +206,10 @@ extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny
     }
     // persistent buffers: allocated once, unlike recvBuff which the reference
     // reallocates on every exchange (pcomms:1574-1592,1852)
-    if (p->sendbuf_len) DLESM_HIP_TRY(hipMalloc((void **)&p->sendbuf, p->sendbuf_len * sizeof(double)));
-    if (p->recvbuf_len) DLESM_HIP_TRY(hipMalloc((void **)&p->recvbuf, p->recvbuf_len * sizeof(double)));
+    if ((rc = ensure_buffers(p, 1))) {
+        dlesm_halo_plan_destroy(p);
+        return rc;
+    }
     *out = p;
     return DLESM_OK;
 }
@@ -234,44 +239,80 @@ static bool dir_enabled(unsigned mask, int dir)
     }
 }
 
-static int exchange_on(dlesm_halo_plan *p, double *f, unsigned mask, hipStream_t s)
+// Pack buffers hold one slot set per field of a multi-field exchange.
+static int ensure_buffers(dlesm_halo_plan *p, int nfields)
+{
+    if (nfields <= p->buf_fields) return DLESM_OK;
+    DLESM_HIP_TRY(hipDeviceSynchronize());               // nobody may still be using the old ones
+    if (p->sendbuf) DLESM_HIP_TRY(hipFree(p->sendbuf));
+    if (p->recvbuf) DLESM_HIP_TRY(hipFree(p->recvbuf));
+    p->sendbuf = p->recvbuf = nullptr;
+    if (p->sendbuf_len) DLESM_HIP_TRY(hipMalloc((void **)&p->sendbuf, (size_t)nfields * p->sendbuf_len * sizeof(double)));
+    if (p->recvbuf_len) DLESM_HIP_TRY(hipMalloc((void **)&p->recvbuf, (size_t)nfields * p->recvbuf_len * sizeof(double)));
+    p->buf_fields = nfields;
+    return DLESM_OK;
+}
+
+// The exchange of `nf` fields of the plan's shape in ONE grouped launch.  Between a pair of
+// ranks messages match in issue order: field-major, then ascending direction code, on both sides.
+static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsigned mask, hipStream_t s)
 {
     const bool any = !p->sends.empty() || !p->recvs.empty();
     if (!any) return DLESM_OK; // serial run: nothing to do (pcomms:1546)
     DLESM_REQUIRE(g_comm != nullptr, "halo exchange before dlesm_comm_init");
-    if (p->n_spack) {
-        int gx = (p->max_strip + 255) / 256;
-        if (gx > 64) gx = 64;
-        hipLaunchKernelGGL(pack_strips, dim3(gx, p->n_spack), dim3(256), 0, s, f, p->ld, p->d_spack, p->sendbuf);
-    }
+    if (int rc = ensure_buffers(p, nf)) return rc;
+    int gx = (p->max_strip + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (p->n_spack)
+        for (int k = 0; k < nf; k++)
+            hipLaunchKernelGGL(pack_strips, dim3(gx, p->n_spack), dim3(256), 0, s, fields[k], p->ld, p->d_spack,
+                               p->sendbuf + (size_t)k * p->sendbuf_len);
     DLESM_NCCL_TRY(ncclGroupStart());
-    for (const Msg &m : p->recvs) {
-        if (!dir_enabled(mask, m.dir)) continue;
-        double *dst = m.off >= 0 ? p->recvbuf + m.off : f + (size_t)m.j0 * p->ld + m.i0;
-        DLESM_NCCL_TRY(ncclRecv(dst, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
-    }
-    for (const Msg &m : p->sends) {
-        if (!dir_enabled(mask, m.dir)) continue;
-        const double *src = m.off >= 0 ? p->sendbuf + m.off : f + (size_t)m.j0 * p->ld + m.i0;
-        DLESM_NCCL_TRY(ncclSend(src, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
-    }
-    DLESM_NCCL_TRY(ncclGroupEnd());
-    if (p->n_rpack) {
-        int gx = (p->max_strip + 255) / 256;
-        if (gx > 64) gx = 64;
-        // a masked-out direction leaves its halo untouched: unpack only what arrived
-        if (mask == 0) {
-            hipLaunchKernelGGL(unpack_strips, dim3(gx, p->n_rpack), dim3(256), 0, s, f, p->ld, p->d_rpack, p->recvbuf);
-        } else {
-            for (const Msg &m : p->recvs) {
-                if (m.off < 0 || !dir_enabled(mask, m.dir)) continue;
-                hipLaunchKernelGGL(unpack_one, dim3(gx, 1), dim3(256), 0, s, f, p->ld,
-                                   Strip{m.i0, m.j0, m.nx, m.ny, m.off}, p->recvbuf);
-            }
+    for (int k = 0; k < nf; k++) {
+        double *f = fields[k];
+        for (const Msg &m : p->recvs) {
+            if (!dir_enabled(mask, m.dir)) continue;
+            double *dst = m.off >= 0 ? p->recvbuf + (size_t)k * p->recvbuf_len + m.off : f + (size_t)m.j0 * p->ld + m.i0;
+            DLESM_NCCL_TRY(ncclRecv(dst, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
+        }
+        for (const Msg &m : p->sends) {
+            if (!dir_enabled(mask, m.dir)) continue;
+            const double *src = m.off >= 0 ? p->sendbuf + (size_t)k * p->sendbuf_len + m.off : f + (size_t)m.j0 * p->ld + m.i0;
+            DLESM_NCCL_TRY(ncclSend(src, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
         }
     }
+    DLESM_NCCL_TRY(ncclGroupEnd());
+    if (p->n_rpack)
+        for (int k = 0; k < nf; k++) {
+            const double *rb = p->recvbuf + (size_t)k * p->recvbuf_len;
+            // a masked-out direction leaves its halo untouched: unpack only what arrived
+            if (mask == 0) {
+                hipLaunchKernelGGL(unpack_strips, dim3(gx, p->n_rpack), dim3(256), 0, s, fields[k], p->ld, p->d_rpack, rb);
+            } else {
+                for (const Msg &m : p->recvs) {
+                    if (m.off < 0 || !dir_enabled(mask, m.dir)) continue;
+                    hipLaunchKernelGGL(unpack_one, dim3(gx, 1), dim3(256), 0, s, fields[k], p->ld,
+                                       Strip{m.i0, m.j0, m.nx, m.ny, m.off}, rb);
+                }
+            }
+        }
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
+}
+
+static int exchange_on(dlesm_halo_plan *p, double *f, unsigned mask, hipStream_t s)
+{
+    double *one[1] = {f};
+    return exchange_on(p, one, 1, mask, s);
+}
+
+extern "C" int dlesm_halo_exchange_multi_f64(dlesm_halo_plan *p, double *const *fields, int nfields,
+                                             unsigned dirs_mask, void *stream)
+{
+    DLESM_REQUIRE(p != nullptr && fields != nullptr && nfields >= 1 && nfields <= 16, "bad arguments");
+    for (int k = 0; k < nfields; k++) DLESM_REQUIRE(fields[k] != nullptr, "null field %d", k);
+    if (int rc = ensure_device()) return rc;
+    return exchange_on(p, fields, nfields, dirs_mask & 0xFu, (hipStream_t)stream);
 }
 
 extern "C" int dlesm_halo_exchange_f64(dlesm_halo_plan *p, double *field, unsigned dirs_mask, void *stream)
@@ -303,6 +344,46 @@ extern "C" int dlesm_jacobi5_step_dm(dlesm_halo_plan *p, const double *in, doubl
     // 3. ... while the interior streams through HBM on the caller's stream
     if (int rc = launch_stencil5(in, out, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, s)) return rc;
     // 4. join: the next step reads out's halos
+    DLESM_HIP_TRY(hipStreamWaitEvent(s, g_ev_comm, 0));
+    return DLESM_OK;
+}
+
+// Distributed shallow-water step: the one-cell frame of unew/vnew/pnew first (four thin boxes),
+// then ONE grouped exchange of the three new fields on the side stream while the interior is
+// computed on the caller's stream; join.  The new fields leave with valid depth-1 halos
+// (corners included: the 3x3 footprint needs them).
+extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *q, int ld, int ny, int xstart,
+                                     int xstop, int ystart, int ystop, const double *u, const double *v,
+                                     const double *pf, const double *uold, const double *vold,
+                                     const double *pold, double *unew, double *vnew, double *pnew,
+                                     void *stream)
+{
+    DLESM_REQUIRE(p != nullptr && q != nullptr, "null pointer");
+    DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
+    if (int rc = ensure_device()) return rc;
+    hipStream_t s = (hipStream_t)stream, side = side_stream();
+    auto box = [&](int xs, int xe, int ys, int ye) {
+        return dlesm_shallow_step_f64(q, ld, ny, xs, xe, ys, ye, u, v, pf, uold, vold, pold, unew, vnew, pnew, s);
+    };
+    const bool comms = !p->sends.empty() || !p->recvs.empty();
+    if (!comms) return box(xstart, xstop, ystart, ystop);
+    if (!g_ev_frame) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_frame, hipEventDisableTiming));
+    if (!g_ev_comm) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_comm, hipEventDisableTiming));
+    // 1. frame: south row, north row, west column, east column (empty boxes are no-ops)
+    if (int rc = box(xstart, xstop, ystart, ystart)) return rc;
+    if (ystop > ystart)
+        if (int rc = box(xstart, xstop, ystop, ystop)) return rc;
+    if (int rc = box(xstart, xstart, ystart + 1, ystop - 1)) return rc;
+    if (xstop > xstart)
+        if (int rc = box(xstop, xstop, ystart + 1, ystop - 1)) return rc;
+    DLESM_HIP_TRY(hipEventRecord(g_ev_frame, s));
+    // 2. grouped exchange of the three new fields on the side stream ...
+    DLESM_HIP_TRY(hipStreamWaitEvent(side, g_ev_frame, 0));
+    double *fields[3] = {unew, vnew, pnew};
+    if (int rc = exchange_on(p, fields, 3, 0, side)) return rc;
+    DLESM_HIP_TRY(hipEventRecord(g_ev_comm, side));
+    // 3. ... behind the interior
+    if (int rc = box(xstart + 1, xstop - 1, ystart + 1, ystop - 1)) return rc;
     DLESM_HIP_TRY(hipStreamWaitEvent(s, g_ev_comm, 0));
     return DLESM_OK;
 }

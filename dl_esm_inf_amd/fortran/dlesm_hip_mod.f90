@@ -230,6 +230,23 @@ module dlesm_hip_mod
        integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
        integer(c_int) :: rc
      end function
+     function dlesm_halo_exchange_multi_f64(plan, fields, nfields, dirs_mask, stream) &
+          bind(C, name="dlesm_halo_exchange_multi_f64") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: plan, stream
+       type(c_ptr), intent(in) :: fields(*)
+       integer(c_int), value :: nfields, dirs_mask
+       integer(c_int) :: rc
+     end function
+     function dlesm_shallow_step_dm(plan, params, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
+          uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_step_dm") result(rc)
+       import :: c_int, c_ptr, c_sw_params
+       type(c_ptr), value :: plan
+       type(c_sw_params), intent(in) :: params
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
+       integer(c_int) :: rc
+     end function
      function dlesm_global_sum_f64(val) bind(C, name="dlesm_global_sum_f64") result(rc)
        import :: c_int, c_double
        real(c_double), intent(inout) :: val

@@ -48,6 +48,7 @@ module dlesm_psy_mod
   private
 
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
+  public :: invoke_shallow_step_dm, halo_exchange_multi
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
 
 contains
@@ -120,6 +121,51 @@ contains
                                 c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_shallow_step: ' // dlesm_error_text())
   end subroutine invoke_shallow_step
+
+  !> Distributed shallow-water step: u, v, p must have valid halos; unew, vnew, pnew leave with
+  !! theirs, exchanged in ONE grouped RCCL launch that runs behind the interior sweep.
+  subroutine invoke_shallow_step_dm(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)
+    use parallel_comms_mod, only: halo_plan_for
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(c_sw_params), intent(in) :: prm
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew
+    integer(c_int) :: rc
+    if (.not. DIST_MEM_ENABLED) then
+       call invoke_shallow_step(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)
+       return
+    end if
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    rc = dlesm_shallow_step_dm(halo_plan_for(p%grid%nx, p%grid%ny), prm, &
+                               int(p%grid%nx, c_int), int(p%grid%ny, c_int), &
+                               int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                               int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                               field_device_data(u), field_device_data(v), field_device_data(p), &
+                               field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                               field_device_data(unew), field_device_data(vnew), field_device_data(pnew), &
+                               c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_dm: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_dm
+
+  !> halo_exchange(1) of several fields of one grid in a single grouped RCCL launch
+  subroutine halo_exchange_multi(f1, f2, f3)
+    use parallel_comms_mod, only: halo_plan_for
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(r2d_field), intent(inout), target :: f1, f2
+    type(r2d_field), intent(inout), target, optional :: f3
+    type(c_ptr) :: ptrs(3)
+    integer(c_int) :: rc, n
+    if (.not. DIST_MEM_ENABLED) return
+    call need_device(f1);  call need_device(f2)
+    ptrs(1) = field_device_data(f1);  ptrs(2) = field_device_data(f2);  n = 2
+    if (present(f3)) then
+       call need_device(f3)
+       ptrs(3) = field_device_data(f3);  n = 3
+    end if
+    rc = dlesm_halo_exchange_multi_f64(halo_plan_for(f1%grid%nx, f1%grid%ny), ptrs, n, 0_c_int, c_null_ptr)
+    if (rc /= 0) call gocean_stop('halo_exchange_multi: ' // dlesm_error_text())
+  end subroutine halo_exchange_multi
 
   !> Device mirrors of the grid properties a kernel may request through its metadata
   !! (GO_GRID_MASK_T, GO_GRID_DX_T, GO_GRID_AREA_T, ... argument_mod): fills the `*_device`

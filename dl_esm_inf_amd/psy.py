@@ -41,6 +41,26 @@ def invoke_shallow_step(params, u, v, p, uold, vold, pold, unew, vnew, pnew, str
                                              pnew.device_ptr, _stream_ptr(stream)))
 
 
+def invoke_shallow_step_dm(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
+    """distributed form: frame of the new fields, one grouped exchange of all three behind the
+    interior; unew, vnew, pnew leave with valid halos"""
+    g, it = p.grid, p.internal
+    plan = grid_mod.halo_plan(g)
+    check(_cabi.lib().dlesm_shallow_step_dm(plan, C.byref(params), g.nx, g.ny, it.xstart, it.xstop,
+                                            it.ystart, it.ystop, u.device_ptr, v.device_ptr,
+                                            p.device_ptr, uold.device_ptr, vold.device_ptr,
+                                            pold.device_ptr, unew.device_ptr, vnew.device_ptr,
+                                            pnew.device_ptr, _stream_ptr(stream)))
+
+
+def halo_exchange_multi(fields, stream=None):
+    """halo_exchange(1) of several fields of one grid in a single grouped RCCL launch"""
+    g = fields[0].grid
+    arr = (C.c_void_p * len(fields))(*[f.device_ptr.value for f in fields])
+    check(_cabi.lib().dlesm_halo_exchange_multi_f64(grid_mod.halo_plan(g), arr, len(fields), 0,
+                                                    _stream_ptr(stream)))
+
+
 def hash_init(fld, seed, box=None, stream=None):
     """synthetic initial condition on `box` (default: the field's whole region), a function of
     the GLOBAL cell index so that every decomposition produces the same global field"""

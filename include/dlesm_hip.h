@@ -246,6 +246,11 @@ int dlesm_halo_plan_destroy(dlesm_halo_plan *plan);
 int dlesm_halo_exchange_f64(dlesm_halo_plan *plan, double *field, unsigned dirs_mask,
                             void *stream);
 
+/* The same for several fields of the plan's shape at once: ONE grouped launch for all of them
+ * (what a time step that updates u, v and p needs).  At most 16 fields. */
+int dlesm_halo_exchange_multi_f64(dlesm_halo_plan *plan, double *const *fields, int nfields,
+                                  unsigned dirs_mask, void *stream);
+
 /* One distributed Jacobi time step with the exchange hidden behind the
  * interior: frame(out) on `stream`, then [exchange(out) on the library's side
  * stream] || [interior(out) on `stream`], joined on `stream`.  On return
@@ -254,6 +259,15 @@ int dlesm_halo_exchange_f64(dlesm_halo_plan *plan, double *field, unsigned dirs_
 int dlesm_jacobi5_step_dm(dlesm_halo_plan *plan, const double *in, double *out,
                           int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                           void *stream);
+
+/* The distributed form of dlesm_shallow_step_f64: frame of unew/vnew/pnew, then one grouped
+ * exchange of the three new fields on the side stream behind the interior.  u, v, p must have
+ * valid halos; unew, vnew, pnew leave with valid halos (corners included). */
+int dlesm_shallow_step_dm(dlesm_halo_plan *plan, const dlesm_sw_params *params, int ld, int ny,
+                          int xstart, int xstop, int ystart, int ystop,
+                          const double *u, const double *v, const double *p,
+                          const double *uold, const double *vold, const double *pold,
+                          double *unew, double *vnew, double *pnew, void *stream);
 
 /* global_sum, parallel_utils_mod.f90:230-238: in-place sum of one host double
  * over all ranks (synchronous). */

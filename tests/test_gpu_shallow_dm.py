@@ -1,0 +1,85 @@
+"""GPU test (-m gpu): the distributed shallow-water step and the multi-field grouped exchange, with
+RCCL in loop-back on one GPU (rank 0 is its own eight neighbours), against the oracle's step
+followed by the oracle's exchange of the three new fields."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+@pytest.fixture(scope="module")
+def D():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    import dl_esm_inf_amd as d
+    torch.cuda.set_device(0)
+    d.parallel_init(0, 1, use_rccl=True)
+    return d
+
+
+@pytest.mark.parametrize("nx,ny,alignment", [(1, 1, 2), (2, 3, 2), (5, 1, 2), (1, 7, 2), (40, 33, 8), (257, 66, 64),
+                                             (130, 9, None)])
+def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment):
+    import torch
+    from dm_overhead import loopback_tables
+    L = D._cabi.lib()
+    if alignment is None:
+        os.environ.pop("DL_ESM_ALIGNMENT", None)
+    else:
+        os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    g.decompose(nx, ny)
+    D.grid_init(g, 1.0, 1.0)
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    F = {n: D.r2d_field(g, pts[n[0]]) for n in names}
+    it = F["p"].internal
+    # the loop-back plan replaces the (empty) serial tables of this grid
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    g._halo_plan = plan
+    for k, n in enumerate(names[:6]):
+        D.psy.hash_init(F[n], 100 + k)
+        F[n].data.add_(1.0 if n[0] == "p" else -0.5)
+    for n in names[6:]:
+        D.set_field(F[n], 9.0)
+    D.psy.halo_exchange_multi([F["u"], F["v"], F["p"]])        # inputs with wrapped halos
+    torch.cuda.synchronize()
+    H = {n: F[n].get_data() for n in names}
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
+
+    # oracle: the multi-field exchange just done, then step + exchange of the new fields
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    ref_in = {}
+    for k, n in enumerate(names[:3]):
+        f = O.hash_field(100 + k, g.ny, g.nx, 0, 0, 1, nx + 2, 1, ny + 2)
+        f += 1.0 if n == "p" else -0.5
+        assert O.exchange_all([f], [g.nx], [oc]) == 0
+        ref_in[n] = f
+        assert np.array_equal(H[n], f), n
+    want = {n: np.full((g.ny, g.nx), 9.0) for n in names[6:]}
+    scratch = [np.zeros((g.ny, g.nx)) for _ in range(4)]
+    op = O.SwParams(prm.fsdx, prm.fsdy, prm.tdts8, prm.tdtsdx, prm.tdtsdy)
+    O.lib().orc_sw_step(C.byref(op), g.nx, *it.box(), ref_in["u"], ref_in["v"], ref_in["p"],
+                        H["uold"], H["vold"], H["pold"], *scratch, want["unew"], want["vnew"], want["pnew"])
+    for n in names[6:]:
+        assert O.exchange_all([want[n]], [g.nx], [oc]) == 0
+
+    D.psy.invoke_shallow_step_dm(prm, *[F[n] for n in names])
+    torch.cuda.synchronize()
+    for n in names[6:]:
+        assert np.array_equal(F[n].get_data(), want[n]), n
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+    g._halo_plan = None
