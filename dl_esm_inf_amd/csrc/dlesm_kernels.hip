@@ -331,6 +331,59 @@ __global__ __launch_bounds__(1024) void jacobi5_tile62(const double *__restrict_
     }
 }
 
+// LDS-staged form (j5_kernel = 2, the comparison point for "stage the tile and its halo ring in
+// LDS"): a workgroup of 64*T lanes stages rows jb-1..je+1 of a 128*T-column tile, plus the two
+// ring columns, in LDS (row pitch 2*blockDim+4 doubles, interior chunks 16-byte aligned at
+// index 2), then every lane reads its five operands from LDS.  Same expression tree, same
+// results; what it buys over the register form is a taller tile (R up to 16: (R+2)/R re-read)
+// at the price of a barrier and of LDS round trips.  Measured: see DESIGN.md section 5.1.
+template <int R>
+__global__ __launch_bounds__(1024) void jacobi5_lds(const double *__restrict__ in,
+                                                   double *__restrict__ out, int ld, int x0, int x1,
+                                                   int y0, int y1, int c_first, int nxb)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) double tile[];
+    const int tid = threadIdx.x, nt = blockDim.x, pitch = 2 * nt + 4;
+    const int xb = blockIdx.x % nxb, jb = y0 + (blockIdx.x / nxb) * R;
+    if (jb > y1) return;                                 // block-uniform exits only
+    int je = jb + R - 1;
+    if (je > y1) je = y1;
+    const int c = c_first + xb * nt + tid, c_last = x1 / 2, c_ld = ld / 2 - 1;
+    if (c - tid > c_last) return;                        // idle padding block
+    const int cl = c < c_ld ? c : c_ld;
+    const bool m0 = c <= c_last && c * 2 >= x0 && c * 2 <= x1;
+    const bool m1 = c <= c_last && c * 2 + 1 >= x0 && c * 2 + 1 <= x1;
+    int ecol = -1, eidx = 0;
+    if (tid == 0 && m0) { ecol = c * 2 - 1; eidx = 1; }
+    if (tid == nt - 1 && m1) { ecol = c * 2 + 2; eidx = 2 * nt + 2; }
+    const double *pin = in + (size_t)cl * 2;
+#pragma unroll
+    for (int u = 0; u < R + 2; u++) {
+        int jj = jb - 1 + u;
+        if (jj > je + 1) jj = je + 1;
+        *(d2 *)(tile + u * pitch + 2 + 2 * tid) = *(const d2 *)(pin + (size_t)jj * ld);
+        if (ecol >= 0) tile[u * pitch + eidx] = in[(size_t)jj * ld + ecol];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < R; u++) {
+        if (jb + u <= je) {
+            const double *row = tile + (u + 1) * pitch + 2 + 2 * tid;
+            const d2 mid = *(const d2 *)row, south = *(const d2 *)(row - pitch), north = *(const d2 *)(row + pitch);
+            const double west = row[-1], east = row[2];
+            const double o0 = 0.25 * ((west + mid.y) + (south.x + north.x));
+            const double o1 = 0.25 * ((mid.x + east) + (south.y + north.y));
+            double *po = out + (size_t)(jb + u) * ld + (size_t)c * 2;
+            if (m0 && m1) *(d2 *)po = d2{o0, o1};
+            else {
+                if (m0) po[0] = o0;
+                if (m1) po[1] = o1;
+            }
+        }
+    }
+}
+
 // Block shape of a linear tile sweep.  Workgroups go round-robin to the 8 XCDs, so the tile
 // below a given tile runs on the XCD (blocks per row) mod 8 further on, and the re-read of the
 // rows they share is an L2 hit only when that is ~0.  Rule fitted to measurements
@@ -537,6 +590,28 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
                     else launch_tile<2, false>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s); }
         else { if (nt) launch_tile<1, true>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s);
                else launch_tile<1, false>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s); }
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
+    if (tuning("j5_kernel", 0) == 2 && vec2) { // LDS-staged comparison kernel
+        int tpb = tuning("j5_tpb", 4), R = tuning("j5_tile_rows", 8);
+        if (tpb != 1 && tpb != 2 && tpb != 4 && tpb != 8 && tpb != 16) tpb = 4;
+        if (R != 2 && R != 4 && R != 16) R = 8;
+        while ((size_t)(R + 2) * (128 * tpb + 4) * sizeof(double) > 65536) tpb /= 2;   // 64 KiB of LDS per group
+        const int nt = 64 * tpb, c_first = (x0 / 2) & ~7, c_last = x1 / 2;
+        int nxb = (c_last - c_first + nt) / nt;
+        if (tuning("j5_autoshape", 1) && nxb > 8) nxb = (nxb + 7) & ~7;   // tile below: same XCD
+        nxb += tuning("j5_pad_tiles", 0);
+        const unsigned grid = (unsigned)((long)nxb * ((y1 - y0 + R) / R));
+        const size_t lds = (size_t)(R + 2) * (2 * nt + 4) * sizeof(double);
+#define DLESM_LDS(RR) hipLaunchKernelGGL(jacobi5_lds<RR>, dim3(grid), dim3(nt), lds, s, in, out, ld, x0, x1, y0, y1, c_first, nxb)
+        switch (R) {
+        case 2: DLESM_LDS(2); break;
+        case 4: DLESM_LDS(4); break;
+        case 16: DLESM_LDS(16); break;
+        default: DLESM_LDS(8); break;
+        }
+#undef DLESM_LDS
         DLESM_HIP_TRY(hipGetLastError());
         return DLESM_OK;
     }
