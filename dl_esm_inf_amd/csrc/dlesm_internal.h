@@ -44,6 +44,10 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
 int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop,
                           int ystart, int ystop, hipStream_t s);
 
+// two fused Jacobi steps (dlesm_jacobi_x2.hip); 1-based inclusive output and intermediate boxes
+int launch_stencil5_x2(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart,
+                       int ystop, int exstart, int exstop, int eystart, int eystop, hipStream_t s);
+
 // block shape (waves per workgroup, padded tiles per row) of a linear tile sweep
 void choose_block_shape(int *nxw_io, int *tpb_out);
 int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart, int ystop, int ring);

@@ -17,6 +17,16 @@ def invoke_jacobi5(out_fld, in_fld, stream=None):
                                          _stream_ptr(stream)))
 
 
+def invoke_jacobi5_x2(out_fld, in_fld, ebox=None, stream=None):
+    """TWO Jacobi steps in one sweep: out = J(t) on out_fld%internal, t = J(in) on `ebox`
+    (default: the same box, i.e. a fixed boundary ring) and in elsewhere"""
+    g, it = out_fld.grid, out_fld.internal
+    e = ebox if ebox is not None else it.box()
+    check(_cabi.lib().dlesm_stencil5_x2_f64(in_fld.device_ptr, out_fld.device_ptr, g.nx, g.ny,
+                                            it.xstart, it.xstop, it.ystart, it.ystop, *e,
+                                            _stream_ptr(stream)))
+
+
 def invoke_jacobi5_dm(out_fld, in_fld, stream=None):
     """distributed step: frame, then exchange(out) hidden behind the interior"""
     g, it = out_fld.grid, out_fld.internal

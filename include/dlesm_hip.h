@@ -183,6 +183,17 @@ int dlesm_transfer_sync(void);
 int dlesm_stencil5_f64(const double *in, double *out, int ld, int ny,
                        int xstart, int xstop, int ystart, int ystop, void *stream);
 
+/* TWO Jacobi steps in one sweep (temporal blocking; SURVEY section 8 f.4 -- an extension,
+ * the reference stops at MAX_HALO_DEPTH = 1, parallel_comms_mod.f90:48):
+ *   t   = J(in) on the intermediate box (exstart:exstop, eystart:eystop), in elsewhere
+ *   out = J(t)  on the box (xstart:xstop, ystart:ystop)
+ * bit-identical to two dlesm_stencil5_f64 calls through a buffer that equals `in` outside the
+ * intermediate box.  One tile: intermediate box = box (fixed boundary ring).  Distributed:
+ * the box grown by one cell towards each neighbouring tile, `in` holding depth-2 halos. */
+int dlesm_stencil5_x2_f64(const double *in, double *out, int ld, int ny,
+                          int xstart, int xstop, int ystart, int ystop,
+                          int exstart, int exstop, int eystart, int eystop, void *stream);
+
 /* Shallow-water u/v/h update: reads u,v,p (3x3 footprint)
  * and uold,vold,pold, writes unew,vnew,pnew on the box. */
 typedef struct dlesm_sw_params {
