@@ -37,6 +37,12 @@ def parse():
     ap.add_argument("--alignment", type=int, default=64, help="DL_ESM_ALIGNMENT for the run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--fused", type=int, default=1,
+                    help="1 GPU only: advance this many time steps per launch (2..4, temporal blocking); "
+                         "the headline run keeps 1 = one sweep per time step")
+    ap.add_argument("--no-temporal-blocking", action="store_true", help="skip the secondary fused-steps figure")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
+                    help="experiments: dlesm_set_tuning(KEY, INT) before the run (repeatable)")
     ap.add_argument("--rows", type=int, default=None, help="tuning: rows per strip")
     ap.add_argument("--variant", type=int, default=None, help="tuning: kernel variant bits")
     return ap.parse_args()
@@ -64,7 +70,7 @@ def cpu_baseline(host_in, ld, box, budget_s):
             O.jacobi5(host_in_t, out, ld, xs, xe, ys, ye, threads=nthr)
             sweeps += 1
             dt = time.perf_counter() - t0
-            if dt > budget_s * share or sweeps >= 50:
+            if dt > budget_s * share or sweeps >= 2000:
                 break
         res[label] = (cells * sweeps / dt / 1e6, sweeps, dt)
     return {
@@ -74,6 +80,42 @@ def cpu_baseline(host_in, ld, box, budget_s):
                   f"{xe - xs + 1}x{ye - ys + 1} tile: {res['all'][1]} sweeps in {res['all'][2]:.1f}s "
                   f"with {threads} OpenMP threads, {res['one'][1]} sweeps in {res['one'][2]:.1f}s on 1 core",
     }
+
+
+def temporal_blocking(D, torch, grid, a, stream, steps, tile, T=4):
+    """Secondary figure (never `value`): the same time steps advanced T per sweep by the fused
+    kernel (dlesm_stencil5_multi_f64).  First T single steps and one fused launch from the same
+    state must agree bit for bit, then steps//T launches are timed with events on the stream."""
+    x, y, z = (D.r2d_field(grid, D.GO_T_POINTS) for _ in range(3))
+    with torch.cuda.stream(stream):
+        for f in (x, y, z):
+            D.copy_field(a, f, stream=stream)            # same fixed boundary ring everywhere
+        src, dst = x, y
+        for _ in range(T):
+            D.psy.invoke_jacobi5(dst, src, stream=stream)
+            src, dst = dst, src
+        D.psy.invoke_jacobi5_multi(z, a, T, stream=stream)
+    stream.synchronize()
+    same = bool(torch.equal(src.data, z.data))
+    launches = max(1, steps // T)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            D.psy.invoke_jacobi5_multi(y, x, T, stream=stream)
+            x, y = y, x
+        e0.record(stream)
+        for _ in range(launches):
+            D.psy.invoke_jacobi5_multi(y, x, T, stream=stream)
+            x, y = y, x
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    cells = tile * tile
+    return {"fused_steps": T, "value": round(cells * T / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s",
+            "steps": launches * T, "ms_per_launch": round(ms, 5), "ms_per_step": round(ms / T, 5),
+            "hbm_gbs": round(BYTES_PER_CELL * cells / (ms * 1e-3) / 1e9, 1),
+            "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells,
+            "bit_identical_to_single_steps": same, "kernel": f"jacobi5xt_tile<{T},8,dpp>"}
 
 
 def main():
@@ -101,6 +143,9 @@ def main():
         L.dlesm_set_tuning(b"j5_rows", args.rows)
     if args.variant is not None:
         L.dlesm_set_tuning(b"j5_variant", args.variant)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        L.dlesm_set_tuning(k.encode(), int(v))     # returns the previous value
     os.environ["DL_ESM_ALIGNMENT"] = str(args.alignment)
     D.parallel_init(rank, world)
 
@@ -124,6 +169,14 @@ def main():
     stream.synchronize()
 
     step = D.psy.invoke_jacobi5_dm if world > 1 else D.psy.invoke_jacobi5
+    fused = args.fused
+    if fused != 1:
+        if world > 1 or fused not in (2, 3, 4) or args.steps % fused:
+            raise SystemExit("bench.py --fused T: 1 GPU, T in 2..4, --steps a multiple of T")
+
+        def step(o, i, stream=None):                         # noqa: F811  (one launch = `fused` time steps)
+            D.psy.invoke_jacobi5_multi(o, i, fused, stream=stream)
+    launches, warm_launches = args.steps // fused, -(-args.warmup // fused)
 
     # N > 1: before timing anything, three overlapped distributed steps must reproduce, bit for
     # bit on every rank, three plain "stencil, then halo exchange" steps from the same state
@@ -156,7 +209,7 @@ def main():
         torch.cuda.synchronize()
 
     with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
+        for _ in range(warm_launches):
             step(b, a, stream=stream)
             a, b = b, a
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -164,7 +217,7 @@ def main():
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         e0.record(stream)
-        for _ in range(args.steps):
+        for _ in range(launches):
             step(b, a, stream=stream)
             a, b = b, a
         e1.record(stream)
@@ -180,14 +233,14 @@ def main():
 
     cells_step = args.tile * args.tile * world
     value = cells_step * args.steps / wall / 1e6
-    launch_ms = ev_ms / args.steps
-    achieved = BYTES_PER_CELL * args.tile * args.tile / (launch_ms * 1e-3) / 1e9   # per GPU, GB/s
+    launch_ms = ev_ms / launches
+    achieved =BYTES_PER_CELL * args.tile * args.tile / (launch_ms * 1e-3) / 1e9   # per GPU, GB/s
     traffic = None
     tj = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-measured HBM bytes per launch
     if os.path.exists(tj):
         try:
             rec = json.load(open(tj))
-            key = f"{args.tile}x{args.tile}/A{args.alignment}"
+            key = f"{args.tile}x{args.tile}/A{args.alignment}" + (f"/fused{fused}" if fused > 1 else "")
             traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -205,9 +258,16 @@ def main():
         "checksum": checksum, "dm_step_equals_stencil_plus_exchange": selfcheck,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "jacobi5_tile<2,2>", "launch_ms": round(launch_ms, 5),
+                     "kernel": "jacobi5_tile<2,2>" if fused == 1 else f"jacobi5xt_tile<{fused},8,dpp>",
+                     "launch_ms": round(launch_ms, 5),
                      "algorithmic_bytes_per_launch": BYTES_PER_CELL * args.tile * args.tile},
     }
+    if fused > 1:
+        out["config"]["fused_steps_per_launch"] = fused
+        out["roofline"]["note"] = (f"one launch advances {fused} time steps; bytes are per launch, so Mcells/s "
+                                   f"exceeds what 16 B/cell/step allows at this bandwidth")
+    elif world == 1 and not args.no_temporal_blocking:
+        out["temporal_blocking"] = temporal_blocking(D, torch, grid, a, stream, args.steps, args.tile)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         host = a.get_data()
         out["cpu_baseline"] = cpu_baseline(host, grid.nx, it.box(), args.cpu_seconds)

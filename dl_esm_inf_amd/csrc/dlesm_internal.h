@@ -38,18 +38,48 @@ __host__ __device__ inline size_t lin(int ld, int ji, int jj)
     return (size_t)(jj - 1) * (size_t)ld + (size_t)(ji - 1);
 }
 
+// Whole-wave shifts by one lane on the VALU (DPP wave_shr:1 / wave_shl:1 of the GFX9 family)
+// instead of ds_bpermute through the LDS pipe: from_lower(x) is lane-1's x, from_upper(x) is
+// lane+1's x, without occupying the one LDS unit the 4 SIMDs of a CU share.  The lane that has
+// no source (lane 0 / lane 63) gets 0.0 with DPP (bound_ctrl, no copy of the old value needed)
+// and its own x with the shuffle: callers must not use that lane's result.
+template <bool DPP>
+__device__ __forceinline__ double from_lower(double x)
+{
+    if constexpr (DPP) {
+        const int lo = __double2loint(x), hi = __double2hiint(x);
+        return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true),
+                                __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true));
+    } else {
+        return __shfl_up(x, 1);
+    }
+}
+template <bool DPP>
+__device__ __forceinline__ double from_upper(double x)
+{
+    if constexpr (DPP) {
+        const int lo = __double2loint(x), hi = __double2hiint(x);
+        return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x130, 0xf, 0xf, true),
+                                __builtin_amdgcn_mov_dpp(lo, 0x130, 0xf, 0xf, true));
+    } else {
+        return __shfl_down(x, 1);
+    }
+}
+
 // shared by the frame/interior split of the distributed step (dlesm_halo.hip)
 int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, int xstop,
                     int ystart, int ystop, hipStream_t s);
 int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop,
                           int ystart, int ystop, hipStream_t s);
 
-// two fused Jacobi steps (dlesm_jacobi_x2.hip); 1-based inclusive output and intermediate boxes
-int launch_stencil5_x2(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart,
-                       int ystop, int exstart, int exstop, int eystart, int eystop, hipStream_t s);
+// nsteps fused Jacobi steps (dlesm_jacobi_x2.hip); 1-based inclusive output box, last stage box,
+// grow flags -- see dlesm_stencil5_multi_f64
+int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nsteps, int xstart, int xstop,
+                          int ystart, int ystop, int exstart, int exstop, int eystart, int eystop, int gw,
+                          int ge, int gs, int gn, hipStream_t s);
 
 // block shape (waves per workgroup, padded tiles per row) of a linear tile sweep
-void choose_block_shape(int *nxw_io, int *tpb_out);
+void choose_block_shape(int *nxw_io, int *tpb_out, int prefer = 0);
 int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart, int ystop, int ring);
 // shallow-water step, register-tiled linear sweep (dlesm_shallow.hip); 0-based inclusive box
 void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,

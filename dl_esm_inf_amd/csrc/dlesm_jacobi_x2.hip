@@ -1,74 +1,127 @@
-// Two Jacobi-5 time steps in one sweep (temporal blocking).
+// T Jacobi-5 time steps in one sweep (temporal blocking), T = 2, 3, 4.
 //
-//   t(i,j)   = J(in)(i,j)   for (i,j) in the intermediate box E,   in(i,j) elsewhere
-//   out(i,j) = J(t)(i,j)    for (i,j) in the output box B
+//   t_0 = in
+//   t_s(i,j) = J(t_{s-1})(i,j)  for (i,j) in the stage box E_s,  t_{s-1}(i,j) elsewhere   (s = 1..T-1)
+//   out(i,j) = J(t_{T-1})(i,j)  for (i,j) in the output box B
 //
-// with J(f)(i,j) = 0.25*((f(i-1,j)+f(i+1,j)) + (f(i,j-1)+f(i,j+1))), i.e. exactly two
-// dlesm_stencil5_f64 calls through a ping-pong buffer whose cells outside E equal `in`'s
-// (one GPU: E = B, the fixed boundary ring; distributed: E = B grown by one cell towards
-// every neighbouring tile, `in` carrying depth-2 halos).  The intermediate never touches
-// memory: 16 B per cell for TWO steps instead of 32.  Same expression tree per step as the
-// single-step kernel, so the result is bit-identical to two single steps.
+// with J(f)(i,j) = 0.25*((f(i-1,j)+f(i+1,j)) + (f(i,j-1)+f(i,j+1))), i.e. exactly T
+// dlesm_stencil5_f64 calls through ping-pong buffers that start as copies of `in`.
+// One tile: every E_s is the tile's box (the boundary ring stays fixed).  Distributed: E_s is
+// the tile's box grown by T-s cells towards every neighbouring tile, `in` carrying depth-T
+// halos.  The intermediates never touch memory: 16 B per cell for T steps instead of 16*T.
+// Same expression tree per step as the single-step kernel, so the result is bit-identical to
+// T single steps.
 //
-// Wave tile: 64 lanes x 2 doubles x (R+4) input rows -> (R+2) intermediate rows for all 64
-// lanes -> R output rows for lanes 1..62; lanes 0 and 63 are halo lanes (their inner
-// intermediate column is valid and feeds lane 1 / 62 by shuffle).  Row-major linear sweep
-// and block-shape rule as in jacobi5_tile.
+// Wave tile: 64 lanes x 2 doubles x (R+2T) input rows; stage s produces R+2(T-s) rows in place
+// in registers, a column narrower on each side than the stage before, so ceil(T/2) lanes on
+// each side of the wave are halo lanes and 64-2*ceil(T/2) lanes store R output rows.  West/east
+// operands are whole-wave shifts by one lane (DPP on the VALU, or ds_bpermute).  Row-major
+// linear sweep and block-shape rule as in jacobi5_tile.
 #include <algorithm>
 
 #include "dlesm_internal.h"
 
 namespace dlesm {
 
-template <int R>
-__global__ __launch_bounds__(1024) void jacobi5x2_tile(const double *__restrict__ in,
-                                                      double *__restrict__ out, int ld, int ny, int x0,
-                                                      int x1, int y0, int y1, int ex0, int ex1, int ey0,
-                                                      int ey1, int cb, int nxw)
+struct XtBoxes {           // 0-based inclusive
+    int x0, x1, y0, y1;     // output box B
+    int ex0, ex1, ey0, ey1; // last intermediate box E_{T-1}
+    int gw, ge, gs, gn;     // 0/1: E_s = E_{T-1} grown by (T-1-s) cells on that side
+};
+
+typedef double xt_d2 __attribute__((ext_vector_type(2)));
+
+// Stages 1..T-1 in place on the register rows.  SEL: the wave touches the edge of a stage box,
+// so every value is selected between J(previous stage) and the previous stage itself; waves
+// wholly inside the last stage box (almost all of them) skip the selects.  `q` is 0.25, passed
+// at run time so that the scaling is one full-rate v_mul_f64 (a literal becomes v_ldexp_f64).
+template <int T, int R, bool DPP, bool SEL>
+__device__ __forceinline__ void xt_stages(xt_d2 (&v)[R + 2 * T], const XtBoxes &b, int c, int jb, double q)
 {
-    typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int s = 1; s < T; s++) {
+        // after this stage v[u] holds t_s on row jb-(T-s)+u
+        const int g = T - 1 - s;
+        const int sx0 = b.ex0 - b.gw * g, sx1 = b.ex1 + b.ge * g, sy0 = b.ey0 - b.gs * g, sy1 = b.ey1 + b.gn * g;
+        const bool c0 = 2 * c >= sx0 && 2 * c <= sx1, c1 = 2 * c + 1 >= sx0 && 2 * c + 1 <= sx1;
+#pragma unroll
+        for (int u = 0; u < R + 2 * (T - s); u++) {
+            const xt_d2 mid = v[u + 1];
+            const double west = from_lower<DPP>(mid.y), east = from_upper<DPP>(mid.x);
+            const double tx = q * ((west + mid.y) + (v[u].x + v[u + 2].x));
+            const double ty = q * ((mid.x + east) + (v[u].y + v[u + 2].y));
+            if constexpr (SEL) {
+                const int jt = jb - (T - s) + u;
+                const bool rowin = jt >= sy0 && jt <= sy1;
+                v[u].x = (rowin && c0) ? tx : mid.x;
+                v[u].y = (rowin && c1) ? ty : mid.y;
+            } else {
+                v[u].x = tx;
+                v[u].y = ty;
+            }
+        }
+    }
+}
+
+// W: waves per SIMD the register allocation must leave room for (occupancy against VGPRs)
+template <int T, int R, bool DPP, int W>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(W, 8)))
+void jacobi5xt_tile(const double *__restrict__ in, double *__restrict__ out, int ld, int ny, XtBoxes b,
+                    int cb, int nxw, int nband, double q)
+{
+    typedef xt_d2 d2;
+    constexpr int H = (T + 1) / 2;                      // halo lanes per side
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int xw = w % nxw;
-    const int jb = y0 + (w / nxw) * R;
-    if (jb > y1) return;
+    int xw, strip;
+    if (nband > 0) {
+        // XCD column bands: workgroups are dealt round-robin to the 8 XCDs, so XCD k = blockIdx % 8
+        // takes tile columns [k*nband, (k+1)*nband) of EVERY strip, strip after strip.  The rows a
+        // strip shares with the strip below ((R+2T) loaded per R stored) were then fetched by the
+        // same XCD one strip earlier and are hits in ITS L2, whatever the row length; all 8 XCDs
+        // work on the same strip at the same time, so memory is still swept linearly.
+        const int wi = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        strip = wi / nband;
+        xw = (blockIdx.x & 7) * nband + wi % nband;
+        if (xw >= nxw) return;
+    } else {
+        const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        xw = w % nxw;
+        strip = w / nxw;
+    }
+    const int jb = b.y0 + strip * R;
+    if (jb > b.y1) return;
     int je = jb + R - 1;
-    if (je > y1) je = y1;
-    const int c = cb + xw * 62 - 1 + lane;
-    if (c - lane + 1 > x1 / 2) return;                  // idle padding tile
+    if (je > b.y1) je = b.y1;
+    const int c_w = cb + xw * (64 - 2 * H) - H;          // chunk of lane 0 (wave-uniform)
+    const int c = c_w + lane;
+    if (c_w + H > b.x1 / 2) return;                     // idle padding tile
     const int c_ld = ld / 2 - 1;
     const int cl = c < 0 ? 0 : (c > c_ld ? c_ld : c);
-    const bool ol = lane >= 1 && lane <= 62 && c <= c_ld;
-    const bool m0 = ol && 2 * c >= x0 && 2 * c <= x1;
-    const bool m1 = ol && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
-    const bool e0 = 2 * c >= ex0 && 2 * c <= ex1;       // intermediate computed (else copied) here
-    const bool e1 = 2 * c + 1 >= ex0 && 2 * c + 1 <= ex1;
+    const bool ol = lane >= H && lane <= 63 - H && c <= c_ld;
+    const bool m0 = ol && 2 * c >= b.x0 && 2 * c <= b.x1;
+    const bool m1 = ol && 2 * c + 1 >= b.x0 && 2 * c + 1 <= b.x1;
     const double *pin = in + (size_t)cl * 2;
-    d2 r[R + 4];
+    d2 v[R + 2 * T];
 #pragma unroll
-    for (int u = 0; u < R + 4; u++) {
-        int jj = jb - 2 + u;
-        if (jj > je + 2) jj = je + 2;                   // short last strip: loaded again, never used
+    for (int u = 0; u < R + 2 * T; u++) {
+        int jj = jb - T + u;
+        if (jj > je + T) jj = je + T;                   // short last strip: loaded again, never used
         jj = jj < 0 ? 0 : (jj > ny - 1 ? ny - 1 : jj);  // rows outside the array feed discarded values only
-        r[u] = *(const d2 *)(pin + (size_t)jj * ld);
+        v[u] = *(const d2 *)(pin + (size_t)jj * ld);
     }
-    d2 t[R + 2];
-#pragma unroll
-    for (int u = 0; u < R + 2; u++) {
-        const int jt = jb - 1 + u;
-        const double west = __shfl_up(r[u + 1].y, 1), east = __shfl_down(r[u + 1].x, 1);
-        const double tx = 0.25 * ((west + r[u + 1].y) + (r[u].x + r[u + 2].x));
-        const double ty = 0.25 * ((r[u + 1].x + east) + (r[u].y + r[u + 2].y));
-        const bool rowin = jt >= ey0 && jt <= ey1;
-        t[u].x = (rowin && e0) ? tx : r[u + 1].x;
-        t[u].y = (rowin && e1) ? ty : r[u + 1].y;
-    }
+    // every column of the wave and every intermediate row it computes inside the LAST (smallest)
+    // stage box: no value is ever "carried", the selects can go
+    const bool inner = 2 * c_w >= b.ex0 && 2 * (c_w + 63) + 1 <= b.ex1 && jb - (T - 1) >= b.ey0 &&
+                       jb + R - 1 + (T - 1) <= b.ey1;
+    if (inner) xt_stages<T, R, DPP, false>(v, b, c, jb, q);
+    else xt_stages<T, R, DPP, true>(v, b, c, jb, q);
 #pragma unroll
     for (int u = 0; u < R; u++) {
-        const double west = __shfl_up(t[u + 1].y, 1), east = __shfl_down(t[u + 1].x, 1);
+        const d2 mid = v[u + 1];
+        const double west = from_lower<DPP>(mid.y), east = from_upper<DPP>(mid.x);
         if (jb + u <= je) {
-            const double o0 = 0.25 * ((west + t[u + 1].y) + (t[u].x + t[u + 2].x));
-            const double o1 = 0.25 * ((t[u + 1].x + east) + (t[u].y + t[u + 2].y));
+            const double o0 = q * ((west + mid.y) + (v[u].x + v[u + 2].x));
+            const double o1 = q * ((mid.x + east) + (v[u].y + v[u + 2].y));
             double *po = out + (size_t)(jb + u) * ld + (size_t)c * 2;
             if (m0 && m1) *(d2 *)po = d2{o0, o1};
             else {
@@ -79,71 +132,111 @@ __global__ __launch_bounds__(1024) void jacobi5x2_tile(const double *__restrict_
     }
 }
 
-// One cell per thread, neighbours through L1/L2: used when the arrays do not meet the 16-byte
-// lane conditions of the tile kernel.  0-based inclusive boxes.
+// Two steps, one cell per thread, neighbours through L1/L2: used when the arrays do not meet the
+// 16-byte lane conditions of the tile kernel.  0-based inclusive boxes.
 __global__ __launch_bounds__(256) void jacobi5x2_direct(const double *__restrict__ in,
                                                         double *__restrict__ out, int ld, int x0, int x1,
                                                         int y0, int y1, int ex0, int ex1, int ey0, int ey1)
 {
     const int i = x0 + blockIdx.x * blockDim.x + threadIdx.x, j = y0 + blockIdx.y;
     if (i > x1 || j > y1) return;
-    auto T = [&](int ii, int jj) -> double {
+    auto T1 = [&](int ii, int jj) -> double {
         const size_t o = (size_t)jj * ld + ii;
         if (ii < ex0 || ii > ex1 || jj < ey0 || jj > ey1) return in[o];
         return 0.25 * ((in[o - 1] + in[o + 1]) + (in[o - ld] + in[o + ld]));
     };
-    out[(size_t)j * ld + i] = 0.25 * ((T(i - 1, j) + T(i + 1, j)) + (T(i, j - 1) + T(i, j + 1)));
+    out[(size_t)j * ld + i] = 0.25 * ((T1(i - 1, j) + T1(i + 1, j)) + (T1(i, j - 1) + T1(i, j + 1)));
 }
 
-int launch_stencil5_x2(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart,
-                       int ystop, int exstart, int exstop, int eystart, int eystop, hipStream_t s)
+template <int T, bool DPP>
+static void launch_xt(const double *in, double *out, int ld, int ny, const XtBoxes &b, int R, hipStream_t s)
 {
+    constexpr int OL = 64 - 2 * ((T + 1) / 2);
+    const int cb = b.x0 / 2, c_last = b.x1 / 2;
+    int nxw = (c_last - cb + OL) / OL, tpb = 4, nband = 0;
+    // measured best at 16384^2 (profiles/r01_sweep_fused.txt): 4, 6, 8 rows for T = 2, 3, 4
+    if (R != 2 && R != 4 && R != 6 && R != 8) R = T == 2 ? 4 : (T == 3 ? 6 : 8);
+    const int W = tuning("j5xt_waves", 2);
+    const int strips = (b.y1 - b.y0 + R) / R;
+    unsigned grid;
+    if (tuning("j5xt_order", 0) == 1 && nxw >= 16) {    // XCD column bands (measured: no gain)
+        nband = (nxw + 7) / 8;
+        tpb = tuning("j5_tpb", 0);
+        if (tpb != 1 && tpb != 2 && tpb != 4 && tpb != 8) tpb = 4;
+        grid = (unsigned)(8 * (((long)nband * strips + tpb - 1) / tpb));
+    } else {
+        choose_block_shape(&nxw, &tpb, nxw >= 64 ? 4 : 0);   // wide rows: 4 waves per group measured best
+        if (tpb > 8) tpb = 8;                           // launch bound of the kernel: 512 lanes
+        grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
+    }
+#define DLESM_XTW(RR, WW)                                                                                       \
+    hipLaunchKernelGGL((jacobi5xt_tile<T, RR, DPP, WW>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, ny, b, \
+                       cb, nxw, nband, 0.25)
+#define DLESM_XT(RR)                                                                                          \
+    do {                                                                                                      \
+        if (W >= 4) DLESM_XTW(RR, 4);                                                                         \
+        else if (W == 3) DLESM_XTW(RR, 3);                                                                    \
+        else DLESM_XTW(RR, 2);                                                                                \
+    } while (0)
+    switch (R) {
+    case 2: DLESM_XT(2); break;
+    case 4: DLESM_XT(4); break;
+    case 6: DLESM_XT(6); break;
+    default: DLESM_XT(8); break;
+    }
+#undef DLESM_XT
+#undef DLESM_XTW
+}
+
+// 1-based inclusive boxes: output box, last intermediate box, and per side (W,E,S,N) whether the
+// earlier intermediate boxes grow by one cell per stage on that side
+int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nsteps, int xstart, int xstop,
+                          int ystart, int ystop, int exstart, int exstop, int eystart, int eystop, int gw,
+                          int ge, int gs, int gn, hipStream_t s)
+{
+    DLESM_REQUIRE(nsteps >= 2 && nsteps <= 4, "fused Jacobi steps: nsteps = %d (2..4 supported)", nsteps);
+    DLESM_REQUIRE((gw | ge | gs | gn | 1) == 1, "fused Jacobi steps: grow flags must be 0 or 1");
     if (xstop < xstart || ystop < ystart) return DLESM_OK; // empty box: a zero-trip loop nest
-    if (int rc = check_box("dlesm_stencil5_x2_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
-    DLESM_REQUIRE(in != nullptr && out != nullptr && in != out, "stencil5_x2: null or aliased arrays");
+    if (int rc = check_box("fused Jacobi steps", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    DLESM_REQUIRE(in != nullptr && out != nullptr && in != out, "fused Jacobi steps: null or aliased arrays");
     const bool empty_e = exstop < exstart || eystop < eystart;
+    const int g = nsteps - 2;                            // growth of the first intermediate box
     if (!empty_e)
-        if (int rc = check_box("dlesm_stencil5_x2_f64 (intermediate box)", ld, ny, exstart, exstop, eystart,
-                               eystop, 1))
+        if (int rc = check_box("fused Jacobi steps (first intermediate box)", ld, ny, exstart - gw * g,
+                               exstop + ge * g, eystart - gs * g, eystop + gn * g, 1))
             return rc;
-    const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
-    int ex0 = exstart - 1, ex1 = exstop - 1, ey0 = eystart - 1, ey1 = eystop - 1;
-    if (empty_e) { ex0 = ey0 = 1; ex1 = ey1 = 0; }
-    // 16-byte lanes need the last column any lane may need (ex1 + 1, x1 + 1) inside the last
-    // whole 2-column chunk of a row, and 16-byte aligned bases
-    const int last = std::max(x1, ex1) + 1;
+    XtBoxes b{xstart - 1, xstop - 1, ystart - 1, ystop - 1, exstart - 1, exstop - 1, eystart - 1, eystop - 1,
+              gw, ge, gs, gn};
+    if (empty_e) { b.ex0 = b.ey0 = 1; b.ex1 = b.ey1 = 0; b.gw = b.ge = b.gs = b.gn = 0; }
+    // 16-byte lanes need the last column any lane may read inside the last whole 2-column chunk
+    // of a row, and 16-byte aligned bases
+    const int last = std::max(b.x1, b.ex1 + b.ge * g) + 1;
     const bool vec2 = !(tuning("j5_variant", 0) & 4) && last <= 2 * (ld / 2) - 1 && ((uintptr_t)in % 16 == 0) &&
                       ((uintptr_t)out % 16 == 0);
     if (!vec2) {
-        dim3 grid((unsigned)((x1 - x0 + 256) / 256), (unsigned)(y1 - y0 + 1));
-        // grid.y is limited to 65535 rows per launch
-        for (int yb = y0; yb <= y1; yb += 65535) {
-            const int ye = std::min(y1, yb + 65534);
+        DLESM_REQUIRE(nsteps == 2, "fused Jacobi steps: %d steps need 16-byte aligned arrays with the east ring "
+                                   "column inside the last even column pair", nsteps);
+        dim3 grid((unsigned)((b.x1 - b.x0 + 256) / 256), 1);
+        for (int yb = b.y0; yb <= b.y1; yb += 65535) {   // grid.y is limited to 65535 rows per launch
+            const int ye = std::min(b.y1, yb + 65534);
             grid.y = (unsigned)(ye - yb + 1);
-            hipLaunchKernelGGL(jacobi5x2_direct, grid, dim3(256), 0, s, in, out, ld, x0, x1, yb, ye, ex0, ex1, ey0,
-                               ey1);
+            hipLaunchKernelGGL(jacobi5x2_direct, grid, dim3(256), 0, s, in, out, ld, b.x0, b.x1, yb, ye, b.ex0, b.ex1,
+                               b.ey0, b.ey1);
         }
         DLESM_HIP_TRY(hipGetLastError());
         return DLESM_OK;
     }
-    int R = tuning("j5x2_tile_rows", 4);
-    if (R != 2 && R != 3 && R != 6 && R != 8) R = 4;
-    const int cb = x0 / 2, c_last = x1 / 2;
-    int nxw = (c_last - cb + 62) / 62, tpb = 4;
-    choose_block_shape(&nxw, &tpb);
-    const int strips = (y1 - y0 + R) / R;
-    const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
-#define DLESM_X2(RR)                                                                                        \
-    hipLaunchKernelGGL(jacobi5x2_tile<RR>, dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, ny, x0, x1, y0, y1, \
-                       ex0, ex1, ey0, ey1, cb, nxw)
-    switch (R) {
-    case 2: DLESM_X2(2); break;
-    case 3: DLESM_X2(3); break;
-    case 6: DLESM_X2(6); break;
-    case 8: DLESM_X2(8); break;
-    default: DLESM_X2(4); break;
-    }
-#undef DLESM_X2
+    const int R = tuning("j5xt_rows", 0);
+    const bool dpp = tuning("j5xt_dpp", 1);
+#define DLESM_T(TT)                                                             \
+    do {                                                                        \
+        if (dpp) launch_xt<TT, true>(in, out, ld, ny, b, R, s);                 \
+        else launch_xt<TT, false>(in, out, ld, ny, b, R, s);                    \
+    } while (0)
+    if (nsteps == 2) DLESM_T(2);
+    else if (nsteps == 3) DLESM_T(3);
+    else DLESM_T(4);
+#undef DLESM_T
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -156,6 +249,17 @@ extern "C" int dlesm_stencil5_x2_f64(const double *in, double *out, int ld, int 
 {
     dlesm::clear_error();
     if (int rc = dlesm::ensure_device()) return rc;
-    return dlesm::launch_stencil5_x2(in, out, ld, ny, xstart, xstop, ystart, ystop, exstart, exstop, eystart,
-                                     eystop, (hipStream_t)stream);
+    return dlesm::launch_stencil5_multi(in, out, ld, ny, 2, xstart, xstop, ystart, ystop, exstart, exstop,
+                                        eystart, eystop, 0, 0, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int dlesm_stencil5_multi_f64(const double *in, double *out, int ld, int ny, int nsteps, int xstart,
+                                        int xstop, int ystart, int ystop, int exstart, int exstop,
+                                        int eystart, int eystop, int grow_w, int grow_e, int grow_s,
+                                        int grow_n, void *stream)
+{
+    dlesm::clear_error();
+    if (int rc = dlesm::ensure_device()) return rc;
+    return dlesm::launch_stencil5_multi(in, out, ld, ny, nsteps, xstart, xstop, ystart, ystop, exstart, exstop,
+                                        eystart, eystop, grow_w, grow_e, grow_s, grow_n, (hipStream_t)stream);
 }

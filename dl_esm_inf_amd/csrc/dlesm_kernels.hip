@@ -390,10 +390,11 @@ __global__ __launch_bounds__(1024) void jacobi5_lds(const double *__restrict__ i
 // (scripts/pad_probe.py, scripts/size_probe.py): blocks per row must sit in [8k, 8k + 1/4];
 // take the block size (2..16 waves) that gets there with the fewest idle padding tiles per
 // row; an exact multiple is skewed by one idle tile for wide rows.
-void choose_block_shape(int *nxw_io, int *tpb_out)
+void choose_block_shape(int *nxw_io, int *tpb_out, int prefer)
 {
     int nxw = *nxw_io, tpb = 4, pad = 0;
-    const int forced = tuning("j5_tpb", 0);
+    int forced = tuning("j5_tpb", 0);
+    if (!forced && tuning("j5_autoshape", 1)) forced = prefer;   // the caller's measured block size
     if (!tuning("j5_autoshape", 1)) {                 // experiments: plain shape, no padding
         *tpb_out = (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) ? forced : 4;
         *nxw_io = nxw + tuning("j5_pad_tiles", 0);

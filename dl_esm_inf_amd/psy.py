@@ -27,6 +27,16 @@ def invoke_jacobi5_x2(out_fld, in_fld, ebox=None, stream=None):
                                             _stream_ptr(stream)))
 
 
+def invoke_jacobi5_multi(out_fld, in_fld, nsteps, ebox=None, grow=(0, 0, 0, 0), stream=None):
+    """nsteps (2..4) Jacobi steps in one sweep over out_fld%internal; `ebox` is the last stage
+    box (default: the same box, a fixed boundary ring), `grow` the (W, E, S, N) flags"""
+    g, it = out_fld.grid, out_fld.internal
+    e = ebox if ebox is not None else it.box()
+    check(_cabi.lib().dlesm_stencil5_multi_f64(in_fld.device_ptr, out_fld.device_ptr, g.nx, g.ny, nsteps,
+                                               it.xstart, it.xstop, it.ystart, it.ystop, *e, *grow,
+                                               _stream_ptr(stream)))
+
+
 def invoke_jacobi5_dm(out_fld, in_fld, stream=None):
     """distributed step: frame, then exchange(out) hidden behind the interior"""
     g, it = out_fld.grid, out_fld.internal

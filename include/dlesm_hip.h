@@ -194,6 +194,19 @@ int dlesm_stencil5_x2_f64(const double *in, double *out, int ld, int ny,
                           int xstart, int xstop, int ystart, int ystop,
                           int exstart, int exstop, int eystart, int eystop, void *stream);
 
+/* nsteps (2..4) Jacobi steps in one sweep:
+ *   t_0 = in;  t_s = J(t_{s-1}) on the stage box E_s, t_{s-1} elsewhere (s = 1..nsteps-1);
+ *   out = J(t_{nsteps-1}) on the box.
+ * (exstart:exstop, eystart:eystop) is the LAST stage box E_{nsteps-1}; E_s is that box grown by
+ * (nsteps-1-s) cells on every side whose grow_* flag is 1 (W, E, S, N = towards lower i, higher
+ * i, lower j, higher j).  One tile: stage box = box, flags 0.  A tile with neighbours: stage
+ * box = box grown by 1 towards each neighbour, flag 1 there, `in` holding depth-nsteps halos.
+ * Bit-identical to nsteps dlesm_stencil5_f64 calls. */
+int dlesm_stencil5_multi_f64(const double *in, double *out, int ld, int ny, int nsteps,
+                             int xstart, int xstop, int ystart, int ystop,
+                             int exstart, int exstop, int eystart, int eystop,
+                             int grow_w, int grow_e, int grow_s, int grow_n, void *stream);
+
 /* Shallow-water u/v/h update: reads u,v,p (3x3 footprint)
  * and uold,vold,pold, writes unew,vnew,pnew on the box. */
 typedef struct dlesm_sw_params {

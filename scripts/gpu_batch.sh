@@ -37,6 +37,14 @@ pmc)
     step pmcF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
     step pmcW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
     python scripts/parse_rocprof.py pmc $OUT/pmc_fetch $OUT/pmc_write "16384x16384/A64" $OUT/traffic.json 2>&1 | tail -12 ;;
+pmcx4)   # HBM traffic of the fused 4-step kernel
+    rm -rf $OUT/pmcx4_fetch $OUT/pmcx4_write
+    step pmcx4F 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcx4_fetch -- python3 bench.py --fused 4 --steps 20 --warmup 4 --no-cpu-baseline > $OUT/pmcx4_fetch.log 2>&1
+    step pmcx4W 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcx4_write -- python3 bench.py --fused 4 --steps 20 --warmup 4 --no-cpu-baseline > $OUT/pmcx4_write.log 2>&1
+    python scripts/parse_rocprof.py pmc $OUT/pmcx4_fetch $OUT/pmcx4_write "16384x16384/A64/fused4" $OUT/traffic.json jacobi5xt_ 2>&1 | tail -12 ;;
+benchx4)
+    step benchx4 400 python bench.py --fused 4 --no-cpu-baseline > $OUT/bench_fused4.json 2> $OUT/bench_fused4.err
+    cat $OUT/bench_fused4.json ;;
 bench)
     step bench 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
     cat $OUT/bench.json ;;
@@ -90,6 +98,13 @@ tune)
 membench)
     step membench 300 ./build/membench > $OUT/membench.log 2>&1
     cat $OUT/membench.log ;;
+pmcmulti)   # one counter per pass, default bench (single-step kernel + the fused-4 secondary leg)
+    rm -rf $OUT/pmcmulti
+    for cnt in ${PMC_LIST:-VALUBusy MemUnitStalled TCC_HIT_sum TCC_MISS_sum MeanOccupancyPerActiveCU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU TCP_TCC_READ_REQ_sum}; do
+        step pmc_$cnt 200 rocprofv3 --pmc $cnt --output-format csv -d $OUT/pmcmulti/$cnt -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/pmcmulti_$cnt.log 2>&1
+    done
+    python scripts/pmc_table.py $OUT/pmcmulti jacobi5_tile jacobi5xt_tile > $OUT/pmcmulti_table.txt 2>&1
+    cat $OUT/pmcmulti_table.txt ;;
 counters)
     step counters 120 rocprofv3 -L > $OUT/counters.txt 2>&1
     grep -c . $OUT/counters.txt ;;

@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-DEFAULTS = dict(j5x2_tile_rows=4, j5_autoshape=1, j5_kernel=0,j5_tile_rows=0, j5_bands=1, j5_group=0, j5_tpb=0, j5_skew=1, j5_pad_tiles=0, j5_variant=0, j5_rows=0, j5_unroll=4)
+DEFAULTS = dict(j5xt_rows=0, j5xt_dpp=1, j5xt_order=0, j5_autoshape=1, j5_kernel=0,j5_tile_rows=0, j5_bands=1, j5_group=0, j5_tpb=0, j5_skew=1, j5_pad_tiles=0, j5_variant=0, j5_rows=0, j5_unroll=4)
 
 
 def expand(grid):
@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--grid", action="append", required=True)
-    ap.add_argument("--x2", action="store_true", help="time the fused two-step kernel (one launch = 2 steps)")
+    ap.add_argument("--fused", type=int, default=1, help="time the fused kernel (one launch = this many steps)")
     ap.add_argument("--out", type=str, default="gpurun_out/sweep_tune.json")
     args = ap.parse_args()
     import torch
@@ -60,7 +60,10 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(s)
                 for _ in range(args.reps):
-                    (D.psy.invoke_jacobi5_x2 if args.x2 else D.psy.invoke_jacobi5)(b, a, stream=s)
+                    if args.fused > 1:
+                        D.psy.invoke_jacobi5_multi(b, a, args.fused, stream=s)
+                    else:
+                        D.psy.invoke_jacobi5(b, a, stream=s)
                     a, b = b, a
                 e1.record(s)
                 s.synchronize()

@@ -1,6 +1,6 @@
-"""GPU tests (-m gpu): two fused Jacobi steps (dlesm_stencil5_x2_f64) against two applications of
-the oracle's single step through a ping-pong buffer, bit for bit; and, at full size, against two
-single GPU steps."""
+"""GPU tests (-m gpu): 2, 3 and 4 fused Jacobi steps (dlesm_stencil5_x2_f64 / _multi_f64) against
+the same number of applications of the oracle's single step through ping-pong buffers, bit for
+bit; and, at full size, against single GPU steps."""
 import os
 
 import numpy as np
@@ -35,89 +35,134 @@ def _grid(D, nx, ny, alignment):
     return g
 
 
-def _oracle_x2(hin, ld, box, ebox):
-    """t = J(in) on ebox (in elsewhere); out = J(t) on box (left at -7 elsewhere)"""
+def _oracle_multi(hin, ld, nsteps, box, ebox, grow=(0, 0, 0, 0)):
+    """t_s = J(t_{s-1}) on E_s (t_{s-1} elsewhere), E_s = ebox grown by (nsteps-1-s)*grow;
+    out = J(t_{nsteps-1}) on box (left at -7 elsewhere)"""
     t = hin.copy()
-    if ebox[0] <= ebox[1] and ebox[2] <= ebox[3]:
-        O.jacobi5(hin, t, ld, *ebox)
+    for s in range(1, nsteps):
+        k = nsteps - 1 - s
+        e = (ebox[0] - grow[0] * k, ebox[1] + grow[1] * k, ebox[2] - grow[2] * k, ebox[3] + grow[3] * k)
+        nxt = t.copy()
+        if ebox[0] <= ebox[1] and ebox[2] <= ebox[3]:
+            O.jacobi5(t, nxt, ld, *e)
+        t = nxt
     want = np.full_like(hin, -7.0)
     O.jacobi5(t, want, ld, *box)
     return want
 
 
 CASES = [(1, 1, None), (2, 3, 2), (4, 10, None), (10, 4, 8), (5, 5, 8), (64, 64, 64), (61, 67, None), (61, 67, 2),
-         (123, 9, 2), (124, 9, 2), (125, 9, 2), (247, 31, 64), (248, 31, 64), (249, 31, 64), (255, 130, 64),
-         (256, 256, None), (511, 70, 4), (1021, 33, 64), (1500, 200, 64), (1500, 200, None), (4096, 300, 64)]
-TUNES = [dict(), dict(j5x2_tile_rows=2), dict(j5x2_tile_rows=3, j5_tpb=2), dict(j5x2_tile_rows=6, j5_tpb=8),
-         dict(j5x2_tile_rows=8), dict(j5_variant=4)]
-DEFAULTS = dict(j5x2_tile_rows=4, j5_tpb=0, j5_variant=0)
+         (119, 9, 2), (120, 9, 2), (121, 9, 2), (123, 9, 2), (124, 9, 2), (125, 9, 2), (247, 31, 64), (248, 31, 64),
+         (249, 31, 64), (255, 130, 64), (256, 256, None), (511, 70, 4), (1021, 33, 64), (1500, 200, 64),
+         (1500, 200, None), (4096, 300, 64), (1930, 37, 2), (2500, 40, 64), (3001, 21, None)]
+TUNES = [dict(), dict(j5xt_rows=2, j5xt_dpp=0), dict(j5xt_rows=8, j5_tpb=8), dict(j5xt_rows=4, j5_tpb=2, j5xt_dpp=0),
+         dict(j5xt_order=1), dict(j5xt_order=1, j5xt_rows=4, j5_tpb=8), dict(j5xt_order=1, j5xt_rows=2, j5_tpb=2),
+         dict(j5_variant=4)]
+DEFAULTS = dict(j5xt_rows=0, j5xt_dpp=1, j5xt_order=0, j5_tpb=0, j5_variant=0)
+
+
+def _tune(D, kw):
+    for k, v in kw.items():
+        D._cabi.lib().dlesm_set_tuning(k.encode(), v)
 
 
 @pytest.mark.parametrize("nx,ny,alignment", CASES)
+@pytest.mark.parametrize("nsteps", [2, 3, 4])
 @pytest.mark.parametrize("tune", TUNES, ids=lambda t: "-".join(f"{k}{v}" for k, v in t.items()) or "default")
-def test_fused_two_steps_bit_exact(D, nx, ny, alignment, tune):
-    L = D._cabi.lib()
-    for k, v in {**DEFAULTS, **tune}.items():
-        L.dlesm_set_tuning(k.encode(), v)
+def test_fused_steps_bit_exact(D, nx, ny, alignment, nsteps, tune):
+    if tune.get("j5_variant") == 4 and nsteps > 2:
+        pytest.skip("the one-cell-per-thread fallback exists for two steps only")
+    _tune(D, {**DEFAULTS, **tune})
     try:
         g = _grid(D, nx, ny, alignment)
         a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
         D.psy.hash_init(a, SEED)
         D.set_field(b, -7.0)
-        D.psy.invoke_jacobi5_x2(b, a)
+        if nsteps == 2 and not tune:
+            D.psy.invoke_jacobi5_x2(b, a)
+        else:
+            D.psy.invoke_jacobi5_multi(b, a, nsteps)
         hin, got = a.get_data(), b.get_data()
         box = b.internal.box()
-        want = _oracle_x2(hin, g.nx, box, box)
+        want = _oracle_multi(hin, g.nx, nsteps, box, box)
         assert np.array_equal(got, want), np.argwhere(got != want)[:5]
     finally:
-        for k, v in DEFAULTS.items():
-            L.dlesm_set_tuning(k.encode(), v)
+        _tune(D, DEFAULTS)
 
 
-def test_fused_sub_boxes_and_grown_intermediate_box(D):
-    """the forms the distributed step uses: thin output boxes with the full intermediate box,
-    an intermediate box grown by one cell on some sides (depth-2 halos), empty boxes"""
+@pytest.mark.parametrize("nsteps", [2, 3, 4])
+def test_fused_sub_boxes_and_grown_stage_boxes(D, nsteps):
+    """the forms the distributed step uses: thin output boxes with the tile's stage boxes, stage
+    boxes grown towards some sides (deep halos), empty boxes; refusals"""
     L = D._cabi.lib()
     import torch
-    g = _grid(D, 302, 91, 2)            # 306 x 94 array; cells 3..302 x 3..91 play the tile interior
+    g = _grid(D, 308, 97, 2)            # 312 x 100 array; cells 5..304 x 5..94 play the tile interior
     a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
     D.psy.hash_init(a, SEED, box=D._cabi.Region(0, 0, 1, g.nx, 1, g.ny))
     hin = a.get_data()
-    assert g.nx >= 304 and g.ny >= 93
-    full = (3, 302, 3, 91)              # interior of a tile with depth-2 halos
+    assert g.nx >= 309 and g.ny >= 99
+    full = (5, 304, 5, 94)
+    allg = (4, 305, 4, 95)              # last stage box of a tile with neighbours on every side
     cases = [
-        (full, full), (full, (2, 303, 2, 92)), (full, (2, 302, 3, 92)), (full, (3, 303, 2, 91)),
-        ((3, 4, 3, 91), (2, 303, 2, 92)), ((301, 302, 3, 91), (2, 303, 2, 92)),
-        ((3, 302, 3, 4), (2, 303, 2, 92)), ((3, 302, 90, 91), (2, 302, 2, 92)),
-        ((5, 300, 5, 89), (2, 303, 2, 92)), ((17, 17, 40, 40), full), ((40, 39, 3, 91), full),
-        (full, (10, 9, 3, 91)), ((3, 302, 50, 49), full),
+        (full, full, (0, 0, 0, 0)), (full, allg, (1, 1, 1, 1)), (full, (4, 304, 5, 95), (1, 0, 0, 1)),
+        (full, (5, 305, 4, 94), (0, 1, 1, 0)),
+        ((5, 8, 5, 94), allg, (1, 1, 1, 1)), ((301, 304, 5, 94), allg, (1, 1, 1, 1)),
+        ((5, 304, 5, 8), allg, (1, 1, 1, 1)), ((5, 304, 91, 94), (4, 304, 4, 95), (1, 0, 1, 1)),
+        ((9, 300, 9, 90), allg, (1, 1, 1, 1)), ((17, 17, 40, 40), full, (0, 0, 0, 0)),
+        ((40, 39, 5, 94), full, (0, 0, 0, 0)), (full, (10, 9, 5, 94), (0, 0, 0, 0)), ((5, 304, 50, 49), full, (1, 1, 1, 1)),
     ]
-    for box, ebox in cases:
+    for box, ebox, grow in cases:
+        D.set_field(b, -7.0)
+        D._cabi.check(L.dlesm_stencil5_multi_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, nsteps, *box, *ebox, *grow,
+                                                 None))
+        torch.cuda.synchronize()
+        want = _oracle_multi(hin, g.nx, nsteps, box, ebox, grow)
+        got = b.get_data()
+        assert np.array_equal(got, want), (box, ebox, grow, np.argwhere(got != want)[:5])
+    # boxes whose stencil ring leaves the array are refused, so are aliased arrays and bad step counts
+    k = nsteps - 2
+    bad = [((1, 10, 5, 10), full, (0, 0, 0, 0)), (full, (2 + k - 1, 305, 4, 95), (1, 1, 1, 1)),
+           (full, (4, g.nx - k, 4, 95), (1, 1, 1, 1)), (full, allg, (2, 0, 0, 0))]
+    for box, ebox, grow in bad:
+        rc = L.dlesm_stencil5_multi_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, nsteps, *box, *ebox, *grow, None)
+        assert rc == D._cabi.EINVAL, (box, ebox, grow)
+    assert L.dlesm_stencil5_multi_f64(a.device_ptr, a.device_ptr, g.nx, g.ny, nsteps, *full, *full, 0, 0, 0, 0,
+                                      None) == D._cabi.EINVAL
+    for n in (0, 1, 5):
+        assert L.dlesm_stencil5_multi_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, n, *full, *full, 0, 0, 0, 0,
+                                          None) == D._cabi.EINVAL
+
+
+def test_x2_entry_with_explicit_intermediate_box(D):
+    L = D._cabi.lib()
+    g = _grid(D, 302, 91, 2)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    D.psy.hash_init(a, SEED, box=D._cabi.Region(0, 0, 1, g.nx, 1, g.ny))
+    hin = a.get_data()
+    full = (3, 302, 3, 91)
+    for box, ebox in [(full, full), (full, (2, 303, 2, 92)), ((3, 4, 3, 91), (2, 303, 2, 92)),
+                      ((5, 300, 5, 89), (2, 303, 2, 92)), (full, (10, 9, 3, 91))]:
         D.set_field(b, -7.0)
         D._cabi.check(L.dlesm_stencil5_x2_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *box, *ebox, None))
-        torch.cuda.synchronize()
-        want = _oracle_x2(hin, g.nx, box, ebox)
-        got = b.get_data()
-        assert np.array_equal(got, want), (box, ebox, np.argwhere(got != want)[:5])
-    # boxes whose stencil ring leaves the array are refused
-    for box, ebox in [((1, 10, 3, 10), full), (full, (1, 303, 2, 92)), (full, (2, g.nx, 2, 92))]:
-        rc = L.dlesm_stencil5_x2_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *box, *ebox, None)
-        assert rc == D._cabi.EINVAL
-    assert L.dlesm_stencil5_x2_f64(a.device_ptr, a.device_ptr, g.nx, g.ny, *full, *full, None) == D._cabi.EINVAL
+        want = _oracle_multi(hin, g.nx, 2, box, ebox)
+        assert np.array_equal(b.get_data(), want), (box, ebox)
+    assert L.dlesm_stencil5_x2_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *full, 1, 303, 2, 92, None) == D._cabi.EINVAL
 
 
 @pytest.mark.parametrize("n,alignment", [(4096, 64), (8192, None), (16384, 64)])
-def test_fused_equals_two_single_steps_full_size(D, n, alignment):
+def test_fused_equals_single_steps_full_size(D, n, alignment):
     import torch
     g = _grid(D, n, n, alignment)
-    a, b, c = (D.r2d_field(g, D.GO_T_POINTS) for _ in range(3))
+    a, p, q, c = (D.r2d_field(g, D.GO_T_POINTS) for _ in range(4))
     D.psy.hash_init(a, SEED)
-    D.copy_field(a, b)
-    D.copy_field(a, c)
-    D.psy.invoke_jacobi5(b, a)          # b = J(a), ring of b = ring of a
-    two = D.r2d_field(g, D.GO_T_POINTS)
-    D.copy_field(a, two)
-    D.psy.invoke_jacobi5(two, b)        # two = J(J(a))
-    D.psy.invoke_jacobi5_x2(c, a)
-    torch.cuda.synchronize()
-    assert torch.equal(two.data, c.data)
+    for f in (p, q, c):
+        D.copy_field(a, f)              # same fixed ring everywhere
+    src, dst = a, p
+    for nsteps in (1, 2, 3, 4):
+        if nsteps > 1:
+            D.psy.invoke_jacobi5_multi(c, a, nsteps)
+        D.psy.invoke_jacobi5(dst, src)  # dst = J^nsteps(a)
+        torch.cuda.synchronize()
+        if nsteps > 1:
+            assert torch.equal(dst.data, c.data), nsteps
+        src, dst = dst, (q if dst is p else p)
