@@ -87,6 +87,8 @@ PROTOTYPES = {
     "dlesm_iprocmap": (_i, [C.POINTER(Decomp), C.POINTER(Subdomain), _i, _i, _i]),
     "dlesm_map_comms": (_i, [C.POINTER(Decomp), C.POINTER(Subdomain), _i, _i,
                              C.POINTER(CommTables)]),
+    "dlesm_map_comms_depth": (_i, [C.POINTER(Decomp), C.POINTER(Subdomain), _i, _i, _i,
+                                   C.POINTER(CommTables)]),
     "dlesm_last_error": (C.c_char_p, []),
     "dlesm_version": (_i, []),
     "dlesm_device_count": (_i, []),
@@ -120,6 +122,7 @@ PROTOTYPES = {
     "dlesm_halo_exchange_f64": (_i, [_vp, _vp, C.c_uint, _vp]),
     "dlesm_halo_exchange_multi_f64": (_i, [_vp, C.POINTER(_vp), _i, C.c_uint, _vp]),
     "dlesm_jacobi5_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dlesm_jacobi5_multi_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_shallow_step_dm": (_i, [_vp, C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_global_sum_f64": (_i, [C.POINTER(_d)]),
     "dlesm_gather_f64": (_i, [_vp, _vp, _i]),

@@ -348,6 +348,67 @@ extern "C" int dlesm_jacobi5_step_dm(dlesm_halo_plan *p, const double *in, doubl
     return DLESM_OK;
 }
 
+// Distributed form of the fused steps (temporal blocking across tiles): `in` holds valid
+// depth-nsteps halos, the plan was built from depth-nsteps tables (dlesm_map_comms_depth).
+// Stage boxes grow towards every side that has a neighbour; the nsteps-deep frame of `out` is
+// computed first (thin boxes along the neighbour sides), its exchange runs on the side stream
+// behind the interior, and `out` leaves with valid depth-nsteps halos: ONE exchange per nsteps
+// time steps, nsteps times deeper.
+extern "C" int dlesm_jacobi5_multi_step_dm(dlesm_halo_plan *p, const double *in, double *out, int ld, int ny,
+                                           int nsteps, int xstart, int xstop, int ystart, int ystop,
+                                           void *stream)
+{
+    DLESM_REQUIRE(p != nullptr && in != nullptr && out != nullptr, "null pointer");
+    DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
+    DLESM_REQUIRE(nsteps >= 2 && nsteps <= 4, "fused distributed step: nsteps = %d (2..4 supported)", nsteps);
+    if (int rc = ensure_device()) return rc;
+    hipStream_t s = (hipStream_t)stream, side = side_stream();
+    const int T = nsteps;
+    int hasW = 0, hasE = 0, hasS = 0, hasN = 0;
+    for (const Msg &m : p->recvs) { // a receive filed under Iminus comes from the west neighbour, ...
+        const bool xdir = m.dir == DLESM_IMINUS || m.dir == DLESM_IPLUS;
+        const bool ydir = m.dir == DLESM_JMINUS || m.dir == DLESM_JPLUS;
+        if (!xdir && !ydir) continue;
+        DLESM_REQUIRE((xdir ? m.nx : m.ny) == T, "the plan exchanges depth-%d halos, the fused step needs depth %d",
+                      xdir ? m.nx : m.ny, T);
+        if (m.dir == DLESM_IMINUS) hasW = 1;
+        if (m.dir == DLESM_IPLUS) hasE = 1;
+        if (m.dir == DLESM_JMINUS) hasS = 1;
+        if (m.dir == DLESM_JPLUS) hasN = 1;
+    }
+    const int exs = xstart - hasW, exe = xstop + hasE, eys = ystart - hasS, eye = ystop + hasN;
+    auto box = [&](int xs, int xe, int ys, int ye) {
+        return launch_stencil5_multi(in, out, ld, ny, T, xs, xe, ys, ye, exs, exe, eys, eye, hasW, hasE, hasS, hasN, s);
+    };
+    const bool comms = !p->sends.empty() || !p->recvs.empty();
+    if (!comms) return box(xstart, xstop, ystart, ystop);
+    if (!g_ev_frame) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_frame, hipEventDisableTiming));
+    if (!g_ev_comm) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_comm, hipEventDisableTiming));
+    const int ix0 = xstart + hasW * T, ix1 = xstop - hasE * T, iy0 = ystart + hasS * T, iy1 = ystop - hasN * T;
+    if (ix1 < ix0 || iy1 < iy0) { // the tile is all frame: no interior to hide the exchange behind
+        if (int rc = box(xstart, xstop, ystart, ystop)) return rc;
+        return exchange_on(p, out, 0, s);
+    }
+    // 1. frame: the T-deep strips along the sides that have a neighbour
+    if (hasS)
+        if (int rc = box(xstart, xstop, ystart, iy0 - 1)) return rc;
+    if (hasN)
+        if (int rc = box(xstart, xstop, iy1 + 1, ystop)) return rc;
+    if (hasW)
+        if (int rc = box(xstart, ix0 - 1, iy0, iy1)) return rc;
+    if (hasE)
+        if (int rc = box(ix1 + 1, xstop, iy0, iy1)) return rc;
+    DLESM_HIP_TRY(hipEventRecord(g_ev_frame, s));
+    // 2. exchange of out's frame on the side stream ...
+    DLESM_HIP_TRY(hipStreamWaitEvent(side, g_ev_frame, 0));
+    if (int rc = exchange_on(p, out, 0, side)) return rc;
+    DLESM_HIP_TRY(hipEventRecord(g_ev_comm, side));
+    // 3. ... behind the interior
+    if (int rc = box(ix0, ix1, iy0, iy1)) return rc;
+    DLESM_HIP_TRY(hipStreamWaitEvent(s, g_ev_comm, 0));
+    return DLESM_OK;
+}
+
 // Distributed shallow-water step: the one-cell frame of unew/vnew/pnew first (four thin boxes),
 // then ONE grouped exchange of the three new fields on the side stream while the interior is
 // computed on the caller's stream; join.  The new fields leave with valid depth-1 halos

@@ -330,3 +330,89 @@ extern "C" int dlesm_map_comms(const dlesm_decomp *d, const dlesm_subdomain *sub
                            DLESM_MAXCOMM);
     return DLESM_OK;
 }
+
+// Depth-d tables (an extension: the reference stops at MAX_HALO_DEPTH = 1,
+// parallel_comms_mod.f90:48,220-222).  Same neighbours, directions and order as above;
+// strips are d cells deep and sit directly against the internal region, corners are d x d.
+// Needs a decomposition whose halo width is >= d and tiles at least d cells wide and high.
+extern "C" int dlesm_map_comms_depth(const dlesm_decomp *d, const dlesm_subdomain *subs, int nranks,
+                                     int rank1, int depth, dlesm_comm_tables *t)
+{
+    if (!d || !subs || !t) return fail(DLESM_EINVAL, "null pointer");
+    const int P = d->nx, Q = d->ny;
+    if (P < 1 || Q < 1 || P * Q != d->ndomains || nranks != d->ndomains)
+        return fail(DLESM_EINVAL, "map_comms_depth: %d ranks for a %dx%d mesh of %d subdomains", nranks, P,
+                    Q, d->ndomains);
+    if (rank1 < 1 || rank1 > nranks) return fail(DLESM_EINVAL, "map_comms_depth: rank %d of %d", rank1, nranks);
+    if (depth < 1) return fail(DLESM_EINVAL, "map_comms_depth: depth %d", depth);
+    if (!is_tile_mesh(d, subs))
+        return fail(DLESM_EINVAL, "map_comms_depth: decomposition is not a regular mesh of non-empty tiles");
+    for (int k = 0; k < nranks; k++) {
+        const dlesm_region &in = subs[k].internal;
+        if (in.xstart - 1 < depth || in.ystart - 1 < depth)
+            return fail(DLESM_EINVAL, "map_comms_depth: halo width %d of the decomposition is less than depth %d",
+                        (in.xstart < in.ystart ? in.xstart : in.ystart) - 1, depth);
+        if (in.nx < depth || in.ny < depth)
+            return fail(DLESM_EINVAL, "map_comms_depth: tile %d is %dx%d, smaller than depth %d", k, in.nx, in.ny,
+                        depth);
+    }
+    for (int *p = &t->dirsend[0]; p < &t->nyrecv[0] + DLESM_MAXCOMM; p++) *p = -999;
+    t->nsend = t->nrecv = 0;
+    TableWriter w{t};
+    const int r = rank1 - 1, ix = r % P, iy = r / P, n = depth;
+    const dlesm_region &me = subs[r].internal;
+    const int wdt = me.nx, hgt = me.ny;
+    const bool hasW = ix > 0, hasE = ix < P - 1, hasS = iy > 0, hasN = iy < Q - 1;
+    // low/high strips of a tile's internal region and of its halo, as first index
+    auto lo_in = [](int start) { return start; };
+    auto hi_in = [n](int stop) { return stop - n + 1; };
+    auto lo_halo = [n](int start) { return start - n; };
+    auto hi_halo = [](int stop) { return stop + 1; };
+    // Where a strip ends at the edge of the domain it also carries the boundary-ring cell next to
+    // it: a stage box grown into the halo reads the ring cells that lie under the NEIGHBOUR's
+    // tile, and the neighbour is the one that holds them (in its own whole region).
+    const int bS = hasS ? 0 : 1, bN = hasN ? 0 : 1, bW = hasW ? 0 : 1, bE = hasE ? 0 : 1;
+    if (hasW) {
+        const dlesm_region &o = subs[r - 1].internal;
+        w.send(DLESM_IPLUS, r - 1, lo_in(me.xstart), me.ystart - bS, hi_halo(o.xstop), o.ystart - bS, n, hgt + bS + bN);
+        w.recv(DLESM_IMINUS, r - 1, hi_in(o.xstop), o.ystart - bS, lo_halo(me.xstart), me.ystart - bS, n, hgt + bS + bN);
+    }
+    if (hasE) {
+        const dlesm_region &o = subs[r + 1].internal;
+        w.send(DLESM_IMINUS, r + 1, hi_in(me.xstop), me.ystart - bS, lo_halo(o.xstart), o.ystart - bS, n, hgt + bS + bN);
+        w.recv(DLESM_IPLUS, r + 1, lo_in(o.xstart), o.ystart - bS, hi_halo(me.xstop), me.ystart - bS, n, hgt + bS + bN);
+    }
+    if (hasS) {
+        const dlesm_region &o = subs[r - P].internal;
+        w.send(DLESM_JPLUS, r - P, me.xstart - bW, lo_in(me.ystart), o.xstart - bW, hi_halo(o.ystop), wdt + bW + bE, n);
+        w.recv(DLESM_JMINUS, r - P, o.xstart - bW, hi_in(o.ystop), me.xstart - bW, lo_halo(me.ystart), wdt + bW + bE, n);
+    }
+    if (hasN) {
+        const dlesm_region &o = subs[r + P].internal;
+        w.send(DLESM_JMINUS, r + P, me.xstart - bW, hi_in(me.ystop), o.xstart - bW, lo_halo(o.ystart), wdt + bW + bE, n);
+        w.recv(DLESM_JPLUS, r + P, o.xstart - bW, lo_in(o.ystart), me.xstart - bW, hi_halo(me.ystop), wdt + bW + bE, n);
+    }
+    if (hasW && hasS) {
+        const dlesm_region &o = subs[r - P - 1].internal;
+        w.send(DLESM_IPLUSJPLUS, r - P - 1, lo_in(me.xstart), lo_in(me.ystart), hi_halo(o.xstop), hi_halo(o.ystop), n, n);
+        w.recv(DLESM_IMINUSJMINUS, r - P - 1, hi_in(o.xstop), hi_in(o.ystop), lo_halo(me.xstart), lo_halo(me.ystart), n, n);
+    }
+    if (hasE && hasN) {
+        const dlesm_region &o = subs[r + P + 1].internal;
+        w.send(DLESM_IMINUSJMINUS, r + P + 1, hi_in(me.xstop), hi_in(me.ystop), lo_halo(o.xstart), lo_halo(o.ystart), n, n);
+        w.recv(DLESM_IPLUSJPLUS, r + P + 1, lo_in(o.xstart), lo_in(o.ystart), hi_halo(me.xstop), hi_halo(me.ystop), n, n);
+    }
+    if (hasW && hasN) {
+        const dlesm_region &o = subs[r + P - 1].internal;
+        w.send(DLESM_IPLUSJMINUS, r + P - 1, lo_in(me.xstart), hi_in(me.ystop), hi_halo(o.xstop), lo_halo(o.ystart), n, n);
+        w.recv(DLESM_IMINUSJPLUS, r + P - 1, hi_in(o.xstop), lo_in(o.ystart), lo_halo(me.xstart), hi_halo(me.ystop), n, n);
+    }
+    if (hasE && hasS) {
+        const dlesm_region &o = subs[r - P + 1].internal;
+        w.send(DLESM_IMINUSJPLUS, r - P + 1, hi_in(me.xstop), lo_in(me.ystart), lo_halo(o.xstart), hi_halo(o.ystop), n, n);
+        w.recv(DLESM_IPLUSJMINUS, r - P + 1, lo_in(o.xstart), hi_in(o.ystop), hi_halo(me.xstop), lo_halo(me.ystart), n, n);
+    }
+    if (w.err) return fail(w.err, "ERROR: Number of separate communications exceeds maximum of %d",
+                           DLESM_MAXCOMM);
+    return DLESM_OK;
+}

@@ -33,6 +33,7 @@ class grid_type:
         self.dx = self.dy = 0.0
         self.comm_tables = None
         self._halo_plan = None
+        self.halo_width = 1
 
     def decompose(self, domainx, domainy, ndomains=None, ndomainx=None, ndomainy=None, halo_width=1):
         """grid_mod.f90:183-211"""
@@ -40,6 +41,7 @@ class grid_type:
                                                 halo_width)
         self.subdomain = self.decomp.subdomains[parallel_mod.get_rank() - 1]
         self.global_nx, self.global_ny = self.decomp.global_nx, self.decomp.global_ny
+        self.halo_width = halo_width
 
 
 def grid_init(grid, dxarg, dyarg, tmask=None):
@@ -62,7 +64,11 @@ def grid_init(grid, dxarg, dyarg, tmask=None):
         if periodic:                                       # grid_mod.f90:559-564
             raise _cabi.GoceanStop(_cabi.EABORT, "map_comms call needs to be implemented for "
                                                  "periodic boundary conditions.")
-        grid.comm_tables = parallel_mod.map_comms(grid.decomp)
+        # halo_width 1: the reference's tables.  A decomposition made with halo_width d > 1 gets
+        # the depth-d extension (what the fused multi-step kernels need); the reference would
+        # call map_comms with HALO_WIDTH_X/Y = 1 here whatever the width (grid_mod.f90:72-73).
+        hw = getattr(grid, "halo_width", 1)
+        grid.comm_tables = parallel_mod.map_comms(grid.decomp, depth=None if hw == 1 else hw)
     else:
         grid.comm_tables = _cabi.CommTables()              # serial: no messages (pcomms:216)
 

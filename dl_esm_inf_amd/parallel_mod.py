@@ -101,9 +101,14 @@ def go_decompose(domainx, domainy, ndomains=None, ndomainx=None, ndomainy=None, 
     return decomposition_type(info, subs)
 
 
-def map_comms(decomp, rank1=None, nranks=None):
-    """map_comms (parallel_comms_mod.f90:178-1172) -> this rank's send/receive tables"""
+def map_comms(decomp, rank1=None, nranks=None, depth=None):
+    """map_comms (parallel_comms_mod.f90:178-1172) -> this rank's send/receive tables.
+    depth=None: the reference's depth-1 tables; depth=d: the depth-d extension
+    (dlesm_map_comms_depth; the reference aborts beyond MAX_HALO_DEPTH = 1)"""
     t = CommTables()
-    check(_cabi.lib().dlesm_map_comms(C.byref(decomp._info), decomp.subdomains,
-                                      nranks or get_num_ranks(), rank1 or get_rank(), C.byref(t)))
+    L, n, r = _cabi.lib(), nranks or get_num_ranks(), rank1 or get_rank()
+    if depth is None:
+        check(L.dlesm_map_comms(C.byref(decomp._info), decomp.subdomains, n, r, C.byref(t)))
+    else:
+        check(L.dlesm_map_comms_depth(C.byref(decomp._info), decomp.subdomains, n, r, depth, C.byref(t)))
     return t

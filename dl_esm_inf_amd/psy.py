@@ -37,6 +37,15 @@ def invoke_jacobi5_multi(out_fld, in_fld, nsteps, ebox=None, grow=(0, 0, 0, 0), 
                                                _stream_ptr(stream)))
 
 
+def invoke_jacobi5_multi_dm(out_fld, in_fld, nsteps, stream=None):
+    """nsteps distributed Jacobi steps with ONE depth-nsteps exchange (hidden behind the interior);
+    the grid must have been decomposed with halo_width = nsteps"""
+    g, it = out_fld.grid, out_fld.internal
+    check(_cabi.lib().dlesm_jacobi5_multi_step_dm(grid_mod.halo_plan(g), in_fld.device_ptr,
+                                                  out_fld.device_ptr, g.nx, g.ny, nsteps, it.xstart,
+                                                  it.xstop, it.ystart, it.ystop, _stream_ptr(stream)))
+
+
 def invoke_jacobi5_dm(out_fld, in_fld, stream=None):
     """distributed step: frame, then exchange(out) hidden behind the interior"""
     g, it = out_fld.grid, out_fld.internal

@@ -124,6 +124,13 @@ int dlesm_iprocmap(const dlesm_decomp *decomp, const dlesm_subdomain *subdomains
 int dlesm_map_comms(const dlesm_decomp *decomp, const dlesm_subdomain *subdomains,
                     int nranks, int rank1, dlesm_comm_tables *tables);
 
+/* Extension (the reference aborts beyond MAX_HALO_DEPTH = 1, parallel_comms_mod.f90:48,
+ * 220-222): tables of a depth-`depth` exchange -- same neighbours, direction codes and order,
+ * strips `depth` cells deep against the internal region, corners depth x depth.  Needs a
+ * decomposition made with halo_width >= depth and tiles at least `depth` wide and high. */
+int dlesm_map_comms_depth(const dlesm_decomp *decomp, const dlesm_subdomain *subdomains,
+                          int nranks, int rank1, int depth, dlesm_comm_tables *tables);
+
 /* ------------------------------------------------------------------------
  * 2. Runtime
  * ---------------------------------------------------------------------- */
@@ -283,6 +290,15 @@ int dlesm_halo_exchange_multi_f64(dlesm_halo_plan *plan, double *const *fields, 
 int dlesm_jacobi5_step_dm(dlesm_halo_plan *plan, const double *in, double *out,
                           int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                           void *stream);
+
+/* nsteps (2..4) distributed Jacobi time steps per call, ONE depth-nsteps exchange per call
+ * (temporal blocking across tiles; dlesm_stencil5_multi_f64 with stage boxes grown towards
+ * every neighbouring tile).  `plan` must come from dlesm_map_comms_depth(depth = nsteps) tables
+ * and `in` must hold valid depth-nsteps halos; `out` leaves with valid depth-nsteps halos.
+ * Bit-identical to nsteps x (dlesm_stencil5_f64 + depth-nsteps exchange). */
+int dlesm_jacobi5_multi_step_dm(dlesm_halo_plan *plan, const double *in, double *out,
+                                int ld, int ny, int nsteps,
+                                int xstart, int xstop, int ystart, int ystop, void *stream);
 
 /* The distributed form of dlesm_shallow_step_f64: frame of unew/vnew/pnew, then one grouped
  * exchange of the three new fields on the side stream behind the interior.  u, v, p must have

@@ -18,17 +18,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def loopback_tables(D, it):
+def loopback_tables(D, it, d=1):
+    """tables of a depth-d exchange in which rank 0 is its own eight neighbours"""
     t = D._cabi.CommTables()
+    xl, xh, yl, yh = it.xstart, it.xstop - d + 1, it.ystart, it.ystop - d + 1   # low / high strips
     msgs = [  # dir, isrc, jsrc, ides, jdes, nx, ny   (a periodic wrap onto oneself)
-        (2, it.xstop, it.ystart, it.xstart - 1, it.ystart, 1, it.ny),
-        (1, it.xstart, it.ystart, it.xstop + 1, it.ystart, 1, it.ny),
-        (4, it.xstart, it.ystop, it.xstart, it.ystart - 1, it.nx, 1),
-        (3, it.xstart, it.ystart, it.xstart, it.ystop + 1, it.nx, 1),
-        (6, it.xstop, it.ystop, it.xstart - 1, it.ystart - 1, 1, 1),
-        (5, it.xstart, it.ystart, it.xstop + 1, it.ystop + 1, 1, 1),
-        (7, it.xstart, it.ystop, it.xstop + 1, it.ystart - 1, 1, 1),
-        (8, it.xstop, it.ystart, it.xstart - 1, it.ystop + 1, 1, 1),
+        (2, xh, yl, it.xstart - d, yl, d, it.ny),
+        (1, xl, yl, it.xstop + 1, yl, d, it.ny),
+        (4, xl, yh, xl, it.ystart - d, it.nx, d),
+        (3, xl, yl, xl, it.ystop + 1, it.nx, d),
+        (6, xh, yh, it.xstart - d, it.ystart - d, d, d),
+        (5, xl, yl, it.xstop + 1, it.ystop + 1, d, d),
+        (7, xl, yh, it.xstop + 1, it.ystart - d, d, d),
+        (8, xh, yl, it.xstart - d, it.ystop + 1, d, d),
     ]
     t.nsend = t.nrecv = len(msgs)
     for k, (d_, isrc, jsrc, ides, jdes, nx, ny) in enumerate(msgs):

@@ -34,11 +34,13 @@ prof)
     python scripts/parse_rocprof.py stats $OUT/prof_stats $OUT/prof_stats_summary.md > /dev/null 2>&1 || echo "parse failed" ;;
 pmc)
     rm -rf $OUT/pmc_fetch $OUT/pmc_write
+    [ -f profiles/traffic.json ] && cp profiles/traffic.json $OUT/traffic.json   # records are merged by key
     step pmcF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
     step pmcW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
     python scripts/parse_rocprof.py pmc $OUT/pmc_fetch $OUT/pmc_write "16384x16384/A64" $OUT/traffic.json 2>&1 | tail -12 ;;
 pmcx4)   # HBM traffic of the fused 4-step kernel
     rm -rf $OUT/pmcx4_fetch $OUT/pmcx4_write
+    [ -f profiles/traffic.json ] && cp profiles/traffic.json $OUT/traffic.json   # records are merged by key
     step pmcx4F 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcx4_fetch -- python3 bench.py --fused 4 --steps 20 --warmup 4 --no-cpu-baseline > $OUT/pmcx4_fetch.log 2>&1
     step pmcx4W 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcx4_write -- python3 bench.py --fused 4 --steps 20 --warmup 4 --no-cpu-baseline > $OUT/pmcx4_write.log 2>&1
     python scripts/parse_rocprof.py pmc $OUT/pmcx4_fetch $OUT/pmcx4_write "16384x16384/A64/fused4" $OUT/traffic.json jacobi5xt_ 2>&1 | tail -12 ;;

@@ -44,6 +44,60 @@ def exchange(field, tables, rank):
             buf.numpy().reshape(m["ny"], m["nx"])
 
 
+def deep_halo_suite(D, nx, ny, depth, rank, world):
+    """The depth-d extension (dlesm_map_comms_depth) and the algorithm of the fused distributed
+    step: (1) after a depth-d exchange every halo cell within d of the tile that lies inside the
+    domain holds the owner's value; (2) d staged oracle steps on the tile -- stage boxes grown
+    by d-s cells towards every neighbour, as dlesm_jacobi5_multi_step_dm does -- reproduce, bit
+    for bit, d oracle steps on the undecomposed domain."""
+    import oracle_lib as O
+    g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
+    g.decompose(nx, ny, halo_width=depth)
+    D.grid_init(g, 1.0, 1.0)
+    sub, t = g.subdomain, g.comm_tables
+    internal, _ = D.field_mod.field_bounds(g, R.GO_T)
+    xs, xe, ys, ye = internal.box()
+    assert xs == depth + 1 and ys == depth + 1
+    G = np.random.default_rng(1234).random((ny + 2, nx + 2))   # [gj, gi], ring at 0 and n+1
+    gx = lambda i: sub.glob.xstart + (i - xs)                  # noqa: E731  local -> global, 1-based
+    gy = lambda j: sub.glob.ystart + (j - ys)                  # noqa: E731
+    f = np.zeros((g.ny, g.nx))
+    for j in range(ys - 1, ye + 2):
+        for i in range(xs - 1, xe + 2):
+            inside = xs <= i <= xe and ys <= j <= ye
+            on_ring = gx(i) in (0, nx + 1) or gy(j) in (0, ny + 1)
+            if inside or on_ring:
+                f[j - 1, i - 1] = G[gy(j), gx(i)]
+    exchange(f, t, rank)
+    errors = 0
+    for j in range(ys - depth, ye + depth + 1):
+        for i in range(xs - depth, xe + depth + 1):
+            if 1 <= gx(i) <= nx and 1 <= gy(j) <= ny and f[j - 1, i - 1] != G[gy(j), gx(i)]:
+                if errors < 3:
+                    print(f"rank {rank}: ERROR depth-{depth} halo cell ({i},{j}) = {f[j - 1, i - 1]}", flush=True)
+                errors += 1
+    # (2) the staged steps against the undecomposed domain
+    want, tmp = G.copy(), G.copy()
+    for _ in range(depth):
+        O.jacobi5(want, tmp, nx + 2, 2, nx + 1, 2, ny + 1)
+        want, tmp = tmp, want
+        tmp[:] = want                                          # same ring in both buffers
+    hasW, hasE = int(sub.glob.xstart > 1), int(sub.glob.xstop < nx)
+    hasS, hasN = int(sub.glob.ystart > 1), int(sub.glob.ystop < ny)
+    cur = f
+    for s in range(1, depth + 1):
+        k = depth - s
+        nxt = cur.copy()
+        O.jacobi5(cur, nxt, g.nx, xs - hasW * k, xe + hasE * k, ys - hasS * k, ye + hasN * k)
+        cur = nxt
+    got = cur[ys - 1:ye, xs - 1:xe]
+    ref = want[sub.glob.ystart:sub.glob.ystop + 1, sub.glob.xstart:sub.glob.xstop + 1]
+    if not np.array_equal(got, ref):
+        print(f"rank {rank}: ERROR staged {depth}-step result differs from the undecomposed domain", flush=True)
+        errors += 1
+    return errors
+
+
 def main():
     nx, ny = int(sys.argv[1]), int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -51,6 +105,12 @@ def main():
     import dl_esm_inf_amd as D
     D.parallel_init(rank, world, use_rccl=False)
     assert D.get_rank() == rank + 1 and D.get_num_ranks() == world
+    if len(sys.argv) > 3:
+        tot = torch.tensor([deep_halo_suite(D, nx, ny, int(sys.argv[3]), rank, world)])
+        dist.all_reduce(tot)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(1 if int(tot[0]) else 0)
     g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
     g.decompose(nx, ny)
     D.grid_init(g, 1.0, 1.0)
