@@ -217,7 +217,10 @@ contains
     if (DIST_MEM_ENABLED .and. periodic) then
        call gocean_stop('map_comms call needs to be implemented for periodic boundary conditions.')
     end if
-    call map_comms(grid%decomp, grid%tmask, .false., (/1, 1/), ierr)
+    ! the reference passes HALO_WIDTH_X/Y = 1 whatever the decomposition (grid_mod.f90:72-73);
+    ! here a decomposition made with halo_width d > 1 gets depth-d tables (see map_comms)
+    call map_comms(grid%decomp, grid%tmask, .false., &
+                   (/grid%subdomain%internal%xstart - 1, grid%subdomain%internal%ystart - 1/), ierr)
     if (ierr /= 0) call gocean_stop('Set-up of communication tables (call to map_comms()) failed.')
   end subroutine grid_init
 

@@ -77,6 +77,15 @@ module dlesm_hip_mod
        integer(c_int), value :: nranks, ia, ja
        integer(c_int) :: owner
      end function
+     function dlesm_map_comms_depth(decomp, subdomains, nranks, rank1, depth, tables) &
+          bind(C, name="dlesm_map_comms_depth") result(rc)
+       import :: c_int, c_decomp, c_subdomain, c_comm_tables
+       type(c_decomp), intent(in) :: decomp
+       type(c_subdomain), intent(in) :: subdomains(*)
+       integer(c_int), value :: nranks, rank1, depth
+       type(c_comm_tables), intent(out) :: tables
+       integer(c_int) :: rc
+     end function
      function dlesm_map_comms(decomp, subdomains, nranks, rank1, tables) &
           bind(C, name="dlesm_map_comms") result(rc)
        import :: c_int, c_decomp, c_subdomain, c_comm_tables
@@ -228,6 +237,22 @@ module dlesm_hip_mod
        import :: c_int, c_ptr
        type(c_ptr), value :: plan, in, out, stream
        integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       integer(c_int) :: rc
+     end function
+     function dlesm_stencil5_multi_f64(in, out, ld, ny, nsteps, xstart, xstop, ystart, ystop, &
+          exstart, exstop, eystart, eystop, grow_w, grow_e, grow_s, grow_n, stream) &
+          bind(C, name="dlesm_stencil5_multi_f64") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: in, out, stream
+       integer(c_int), value :: ld, ny, nsteps, xstart, xstop, ystart, ystop
+       integer(c_int), value :: exstart, exstop, eystart, eystop, grow_w, grow_e, grow_s, grow_n
+       integer(c_int) :: rc
+     end function
+     function dlesm_jacobi5_multi_step_dm(plan, in, out, ld, ny, nsteps, xstart, xstop, ystart, ystop, &
+          stream) bind(C, name="dlesm_jacobi5_multi_step_dm") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: plan, in, out, stream
+       integer(c_int), value :: ld, ny, nsteps, xstart, xstop, ystart, ystop
        integer(c_int) :: rc
      end function
      function dlesm_halo_exchange_multi_f64(plan, fields, nfields, dirs_mask, stream) &

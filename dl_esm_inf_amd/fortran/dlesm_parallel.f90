@@ -265,6 +265,8 @@ module parallel_comms_mod
   private
 
   integer, parameter :: MAX_HALO_DEPTH = 1
+  !> deepest exchange the device layer builds tables for (dlesm_map_comms_depth)
+  integer, parameter :: MAX_DEVICE_HALO_DEPTH = 4
   integer, parameter :: MaxComm = DLESM_MAXCOMM
 
   ! One rank's message lists (reference parallel_comms_mod.f90:52-83); a module-level
@@ -334,7 +336,9 @@ contains
 
     ierr = 0
     if (.not. DIST_MEM_ENABLED) return
-    if (halo_depths(1) > MAX_HALO_DEPTH .or. halo_depths(2) > MAX_HALO_DEPTH) then
+    ! The reference aborts beyond MAX_HALO_DEPTH = 1.  Extension of this layer: equal depths
+    ! 2..MAX_DEVICE_HALO_DEPTH select the deep tables the fused multi-step kernels need.
+    if (halo_depths(1) /= halo_depths(2) .or. halo_depths(1) > MAX_DEVICE_HALO_DEPTH) then
        call parallel_abort('map_comms: specified halo depth exceeds MAX_HALO_DEPTH limit in ' // &
                            'parallel_comms_mod')
     end if
@@ -342,7 +346,12 @@ contains
 
     irank = get_rank()
     call to_c_decomp(decomp, cd, csubs)
-    rc = dlesm_map_comms(cd, csubs, int(get_num_ranks(), c_int), int(irank, c_int), ctables)
+    if (halo_depths(1) > MAX_HALO_DEPTH) then
+       rc = dlesm_map_comms_depth(cd, csubs, int(get_num_ranks(), c_int), int(irank, c_int), &
+                                  int(halo_depths(1), c_int), ctables)
+    else
+       rc = dlesm_map_comms(cd, csubs, int(get_num_ranks(), c_int), int(irank, c_int), ctables)
+    end if
     if (rc == DLESM_ECOMMS) then
        ierr = -12
        return

@@ -48,7 +48,7 @@ module dlesm_psy_mod
   private
 
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
-  public :: invoke_shallow_step_dm, halo_exchange_multi
+  public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
 
 contains
@@ -93,6 +93,37 @@ contains
                                int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_jacobi5_dm: ' // dlesm_error_text())
   end subroutine invoke_jacobi5_dm
+
+  !> nsteps (2..4) Jacobi time steps in one sweep (temporal blocking).  Serial / one tile: the
+  !! boundary ring of `in` stays fixed through all steps.  Distributed (grid decomposed with
+  !! halo_width = nsteps): one depth-nsteps halo exchange per call, hidden behind the interior;
+  !! `in` must hold valid depth-nsteps halos and `out` leaves with them.  Bit-identical to nsteps
+  !! calls of invoke_jacobi5 (+ halo exchanges).
+  subroutine invoke_jacobi5_multi(out, in, nsteps)
+    use parallel_comms_mod, only: halo_plan_for
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(r2d_field), intent(inout), target :: out, in
+    integer, intent(in) :: nsteps
+    integer(c_int) :: rc
+    call need_device(in);  call need_device(out)
+    associate (b => out%internal)
+      if (DIST_MEM_ENABLED) then
+         rc = dlesm_jacobi5_multi_step_dm(halo_plan_for(out%grid%nx, out%grid%ny), field_device_data(in), &
+                                          field_device_data(out), int(out%grid%nx, c_int), &
+                                          int(out%grid%ny, c_int), int(nsteps, c_int), int(b%xstart, c_int), &
+                                          int(b%xstop, c_int), int(b%ystart, c_int), int(b%ystop, c_int), &
+                                          c_null_ptr)
+      else
+         rc = dlesm_stencil5_multi_f64(field_device_data(in), field_device_data(out), &
+                                       int(out%grid%nx, c_int), int(out%grid%ny, c_int), int(nsteps, c_int), &
+                                       int(b%xstart, c_int), int(b%xstop, c_int), int(b%ystart, c_int), &
+                                       int(b%ystop, c_int), int(b%xstart, c_int), int(b%xstop, c_int), &
+                                       int(b%ystart, c_int), int(b%ystop, c_int), 0_c_int, 0_c_int, 0_c_int, &
+                                       0_c_int, c_null_ptr)
+      end if
+    end associate
+    if (rc /= 0) call gocean_stop('invoke_jacobi5_multi: ' // dlesm_error_text())
+  end subroutine invoke_jacobi5_multi
 
   !> Constants of the shallow-water step; tdt = 2*dt (leapfrog)
   function shallow_params(dx, dy, dt) result(p)

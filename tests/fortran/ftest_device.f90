@@ -73,6 +73,9 @@ program ftest_device
   write(*, '("G: cs ",ES24.16E3)') cs
   write(*, '("G: sample ",3(ES24.16E3,1x))') h(2, 2), h(nx/2 + 1, ny/2 + 1), h(nx + 1, ny + 1)
 
+  ! ---- (2b) four fused steps against four single steps --------------------------
+  call fused_check(model_grid)
+
   ! ---- (3) one shallow-water step through the PSy layer ------------------------
   call shallow_step(model_grid)
   call free_field(a);  call free_field(b);  call free_field(test_field)
@@ -115,6 +118,23 @@ contains
        call free_field(f(k))
     end do
   end subroutine shallow_step
+
+  !> invoke_jacobi5_multi(.., 4) must reproduce four invoke_jacobi5 calls bit for bit
+  subroutine fused_check(g)
+    type(grid_type), intent(in), target :: g
+    type(r2d_field), target :: s0, p1, p2, fu
+    real(go_wp), pointer :: h1(:,:), h2(:,:)
+    s0 = r2d_field(g, GO_T_POINTS);  p1 = r2d_field(g, GO_T_POINTS)
+    p2 = r2d_field(g, GO_T_POINTS);  fu = r2d_field(g, GO_T_POINTS)
+    call invoke_hash_init(s0, 4242_c_int64_t)
+    call invoke_copy(p1, s0);  call invoke_copy(p2, s0);  call invoke_copy(fu, s0)
+    call invoke_jacobi5(p1, s0);  call invoke_jacobi5(p2, p1)
+    call invoke_jacobi5(p1, p2);  call invoke_jacobi5(p2, p1)
+    call invoke_jacobi5_multi(fu, s0, 4)
+    h1 => p2%get_data();  h2 => fu%get_data()
+    write(*, '("G: fused4 ",I0,1x,ES24.16E3)') count(h1 /= h2), field_checksum(fu)
+    call free_field(s0);  call free_field(p1);  call free_field(p2);  call free_field(fu)
+  end subroutine fused_check
 
   subroutine check_mirrors(g)
     type(grid_type), intent(inout), target :: g

@@ -1,0 +1,49 @@
+"""GPU test (-m gpu): bench.py's output contract on a small tile, and a 1-rank rehearsal of the
+leg that only runs when N > 1 (the fused distributed step on a halo_width-4 decomposition)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _bench(*flags):
+    # bench.py runs as a child process; this file sorts first so that the pytest process has not
+    # touched the GPU yet when it forks (the GPU boxes refuse an exec from a process that has)
+    import torch
+    assert not torch.cuda.is_initialized(), "run this file before any in-process GPU test"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tile", "2048", "--steps", "8",
+                        "--warmup", "2", "--cpu-seconds", "0.5", *flags], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_and_secondary_legs():
+    d = _bench()
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["unit"] == "Mcells/s" and d["dtype"] == "f64"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    tb = d["temporal_blocking"]
+    assert tb["fused_steps"] == 4 and tb["bit_identical_to_single_steps"] is True and tb["value"] > 0
+    f = _bench("--fused", "4", "--no-cpu-baseline")
+    assert f["config"]["fused_steps_per_launch"] == 4 and f["value"] > 0
+
+
+def test_rehearsal_of_the_multi_gpu_secondary_leg():
+    d = _bench("--force-dm-leg", "--no-cpu-baseline")
+    tb = d["temporal_blocking"]
+    assert "error" not in tb, tb
+    assert tb["halo_depth"] == 4 and tb["bit_identical_to_single_steps_plus_exchange"] is True

@@ -140,6 +140,15 @@ def test_fortran_device_io_and_jacobi_on_gpu(exe):
     assert abs(float(g["cs"][0][0]) - cs) <= 1e-12 * cs
     got = [float(x) for x in g["sample"][0]]
     assert got == [a[1, 1], a[ny // 2, nx // 2], a[ny, nx]]
+    # (2b) invoke_jacobi5_multi(.., 4) == four invoke_jacobi5 calls, and == four oracle steps
+    assert int(g["fused4"][0][0]) == 0
+    a = O.hash_field(4242, nyy, ld, 0, 0, 1, nx + 2, 1, ny + 2)
+    b = a.copy()
+    for _ in range(4):
+        O.jacobi5(a, b, ld, 2, nx + 1, 2, ny + 1)
+        a, b = b, a
+    cs4 = O.lib().orc_checksum(a, ld, 2, nx + 1, 2, ny + 1)
+    assert abs(float(g["fused4"][0][1]) - cs4) <= 1e-12 * cs4
     # (3) one fused shallow-water step launched from Fortran == oracle
     import ctypes as C
     H = []
