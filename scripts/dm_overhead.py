@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--tile", type=int, default=8192)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--out", default="gpurun_out/dm_overhead.json")
+    ap.add_argument("--fused", type=int, default=1, help="T > 1: the fused T-step forms, depth-T halos")
     args = ap.parse_args()
     import torch
     import dl_esm_inf_amd as D
@@ -55,17 +56,19 @@ def main():
     torch.cuda.set_device(0)
     os.environ["DL_ESM_ALIGNMENT"] = "64"
     D.parallel_init(0, 1, use_rccl=True)
+    T = args.fused
     g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
-    g.decompose(args.tile, args.tile)
+    g.decompose(args.tile, args.tile, halo_width=T)
     D.grid_init(g, 1.0, 1.0)
     F = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(2)]
     it = F[0].internal
-    tables = loopback_tables(D, it)
+    tables = loopback_tables(D, it, T)
     plan = C.c_void_p()
     D._cabi.check(L.dlesm_halo_plan_create(C.byref(tables), g.nx, g.ny, C.byref(plan)))
     s = torch.cuda.Stream()
     sp = C.c_void_p(s.cuda_stream)
     box = it.box()
+    ebox = (box[0] - 1, box[1] + 1, box[2] - 1, box[3] + 1)    # last stage box of a tile with 8 neighbours
 
     def init(a, b):
         D.psy.hash_init(a, 20261004, stream=s)
@@ -73,14 +76,21 @@ def main():
         D.copy_field(a, b, stream=s)
 
     def plain(a, b):
-        D._cabi.check(L.dlesm_stencil5_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *box, sp))
+        if T > 1:       # the whole tile in one fused launch, no exchange
+            D._cabi.check(L.dlesm_stencil5_multi_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, T, *box, *ebox,
+                                                     1, 1, 1, 1, sp))
+        else:
+            D._cabi.check(L.dlesm_stencil5_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *box, sp))
 
     def serial(a, b):   # stencil, then the exchange of the result on the same stream: no overlap
-        D._cabi.check(L.dlesm_stencil5_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *box, sp))
+        plain(a, b)
         D._cabi.check(L.dlesm_halo_exchange_f64(plan, b.device_ptr, 0, sp))
 
     def overlapped(a, b):
-        D._cabi.check(L.dlesm_jacobi5_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *box, sp))
+        if T > 1:
+            D._cabi.check(L.dlesm_jacobi5_multi_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, T, *box, sp))
+        else:
+            D._cabi.check(L.dlesm_jacobi5_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *box, sp))
 
     res = {}
     finals = {}
@@ -103,8 +113,8 @@ def main():
             finals[name] = a.data.clone()
     same = bool(torch.equal(finals["serial"], finals["overlapped"]))
     cells = args.tile * args.tile
-    out = {"tile": args.tile, "steps": args.steps, "ms_per_step": res,
-           "mcells_per_s": {k: cells / v / 1e3 for k, v in res.items()},
+    out = {"tile": args.tile, "launches": args.steps, "time_steps_per_launch": T, "ms_per_launch": res,
+           "mcells_per_s": {k: cells * T / v / 1e3 for k, v in res.items()},
            "overlapped_equals_serial_bitwise": same,
            "overlap_efficiency_vs_plain": res["plain"] / res["overlapped"]}
     print(json.dumps(out, indent=1))

@@ -63,6 +63,11 @@ dm)
     tail -22 $OUT/dm_overhead_8192.log
     step dm16384 300 python scripts/dm_overhead.py --tile 16384 --out $OUT/dm_overhead_16384.json > $OUT/dm_overhead_16384.log 2>&1
     tail -22 $OUT/dm_overhead_16384.log ;;
+dmfused)
+    for t in 8192 16384; do
+        step dmf$t 300 python scripts/dm_overhead.py --fused 4 --tile $t --steps 24 --out $OUT/dm_fused4_$t.json > $OUT/dm_fused4_$t.log 2>&1
+        grep -v amdgpu.ids $OUT/dm_fused4_$t.log | tail -20
+    done ;;
 shallow)
     step shallow 400 python scripts/shallow_bench.py --out $OUT/shallow_bench.json > $OUT/shallow_bench.log 2>&1
     grep -v amdgpu.ids $OUT/shallow_bench.log | tail -8 ;;
