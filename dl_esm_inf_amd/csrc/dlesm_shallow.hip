@@ -32,18 +32,21 @@ __device__ __forceinline__ V2 ld2(const double *p)
     return V2{t.x, t.y};
 }
 // value of the column to the east / west of each of the lane's two columns
-__device__ __forceinline__ V2 east(const V2 &a) { return V2{a.y, __shfl_down(a.x, 1)}; }
-__device__ __forceinline__ V2 west(const V2 &a) { return V2{__shfl_up(a.y, 1), a.x}; }
+// (DPP: whole-wave shift on the VALU instead of ds_bpermute, see dlesm_internal.h)
+template <bool DPP> __device__ __forceinline__ V2 east_of(const V2 &a) { return V2{a.y, from_upper<DPP>(a.x)}; }
+template <bool DPP> __device__ __forceinline__ V2 west_of(const V2 &a) { return V2{from_lower<DPP>(a.y), a.x}; }
 
 #define EW(expr_x, expr_y) V2{(expr_x), (expr_y)}
 
-template <int R>
+template <int R, bool DPP>
 __global__ __launch_bounds__(512) void shallow_tile(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
     const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew)
 {
+    auto east = [](const V2 &a) { return east_of<DPP>(a); };
+    auto west = [](const V2 &a) { return west_of<DPP>(a); };
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int xw = w % nxw, strip = w / nxw;
@@ -165,15 +168,20 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     const int h = y1 - y0 + 1, strips = (h + R - 1) / R;
     const long tiles = (long)nxw * strips;
     const unsigned grid = (unsigned)((tiles + tpb - 1) / tpb);
-    if (R == 1)
-        hipLaunchKernelGGL(shallow_tile<1>, dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw,
-                           u, v, p, uold, vold, pold, unew, vnew, pnew);
-    else if (R == 3)
-        hipLaunchKernelGGL(shallow_tile<3>, dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw,
-                           u, v, p, uold, vold, pold, unew, vnew, pnew);
-    else
-        hipLaunchKernelGGL(shallow_tile<2>, dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw,
-                           u, v, p, uold, vold, pold, unew, vnew, pnew);
+    const bool dpp = tuning("sw_dpp", 1);
+#define DLESM_SW(RR)                                                                                           \
+    do {                                                                                                       \
+        if (dpp)                                                                                               \
+            hipLaunchKernelGGL((shallow_tile<RR, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, \
+                               cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew);                          \
+        else                                                                                                   \
+            hipLaunchKernelGGL((shallow_tile<RR, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, \
+                               cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew);                          \
+    } while (0)
+    if (R == 1) DLESM_SW(1);
+    else if (R == 3) DLESM_SW(3);
+    else DLESM_SW(2);
+#undef DLESM_SW
 }
 
 } // namespace dlesm

@@ -23,7 +23,7 @@ with torch.cuda.stream(s):
 prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
 cells = tile * tile
 def run(label, **tune):
-    base = dict(sw_kernel=0, sw_tile_rows=2, j5_autoshape=1, j5_tpb=0, j5_pad_tiles=0, j5_skew=1)
+    base = dict(sw_kernel=0, sw_tile_rows=2, sw_dpp=1, j5_autoshape=1, j5_tpb=0, j5_pad_tiles=0, j5_skew=1)
     base.update(tune)
     for k, v in base.items(): L.dlesm_set_tuning(k.encode(), v)
     cur, old, new = [F["u"], F["v"], F["p"]], [F["uold"], F["vold"], F["pold"]], [F["unew"], F["vnew"], F["pnew"]]
@@ -40,7 +40,10 @@ def run(label, **tune):
     ms = min(ts)
     print(f"{label:44s} {ms:.4f} ms  {72.0*cells/ms/1e6:6.0f} GB/s  {72.0*cells/ms/1e6/80:.1f}%", flush=True)
 run("direct", sw_kernel=1)
-run("tile auto R2")
-run("tile auto R1", sw_tile_rows=1)
-for tpb, pad, R in itertools.product((1, 2, 4, 8), (0, 1, 2, 5), (2, 1)):
-    run(f"tile plain tpb{tpb} pad{pad} R{R}", j5_autoshape=0, j5_tpb=tpb, j5_pad_tiles=pad, sw_tile_rows=R)
+for rep in range(2):
+    for R in (2, 3, 1):
+        run(f"tile auto R{R} dpp", sw_tile_rows=R, sw_dpp=1)
+        run(f"tile auto R{R} bpermute", sw_tile_rows=R, sw_dpp=0)
+if len(sys.argv) > 2:
+    for tpb, pad, R in itertools.product((1, 2, 4, 8), (0, 1, 2, 5), (2, 1)):
+        run(f"tile plain tpb{tpb} pad{pad} R{R}", j5_autoshape=0, j5_tpb=tpb, j5_pad_tiles=pad, sw_tile_rows=R)

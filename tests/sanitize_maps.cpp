@@ -72,6 +72,66 @@ int main()
                         REQUIRE(in ? (o >= 1 && o <= n) : o == 0);
                     }
             }
+    // depth-d tables on halo_width-d decompositions: pairing, patch bounds, and "a halo cell is
+    // written by exactly one message" over the whole depth-d frame that lies inside the domain
+    for (int n : {1, 2, 3, 4, 6, 8, 9, 12})
+        for (int depth = 1; depth <= 4; depth++)
+            for (int nx : {16, 33, 100})
+                for (int ny : {12, 40, 257}) {
+                    std::vector<dlesm_subdomain> subs(n);
+                    dlesm_decomp d;
+                    REQUIRE(dlesm_decompose(nx, ny, n, 0, 0, depth, &d, subs.data()) == 0);
+                    bool small = false;
+                    for (auto &s : subs) small = small || s.internal.nx < depth || s.internal.ny < depth;
+                    std::vector<dlesm_comm_tables> t(n);
+                    for (int r = 1; r <= n; r++) {
+                        int rc = dlesm_map_comms_depth(&d, subs.data(), n, r, depth, &t[r - 1]);
+                        REQUIRE(small ? rc == DLESM_EINVAL : rc == 0);
+                    }
+                    if (small) continue;
+                    for (int r = 0; r < n; r++) {
+                        const dlesm_region &in = subs[r].internal;
+                        const int W = in.nx + 2 * depth, Hh = in.ny + 2 * depth;
+                        std::vector<int> hits((size_t)W * Hh, 0);
+                        for (int k = 0; k < t[r].nrecv; k++) {
+                            for (int j = 0; j < t[r].nyrecv[k]; j++)
+                                for (int i = 0; i < t[r].nxrecv[k]; i++) {
+                                    const int ii = t[r].idesrecv[k] + i, jj = t[r].jdesrecv[k] + j;
+                                    REQUIRE(ii >= 1 && ii <= W && jj >= 1 && jj <= Hh);
+                                    hits[(size_t)(jj - 1) * W + ii - 1]++;
+                                }
+                            const dlesm_comm_tables &p = t[t[r].source[k]];
+                            int m = 0;
+                            for (int q = 0; q < p.nsend; q++)
+                                m += p.destination[q] == r && p.dirsend[q] == t[r].dirrecv[k] &&
+                                     p.nxsend[q] == t[r].nxrecv[k] && p.nysend[q] == t[r].nyrecv[k] &&
+                                     p.idessend[q] == t[r].idesrecv[k] && p.jdessend[q] == t[r].jdesrecv[k];
+                            REQUIRE(m == 1);
+                        }
+                        for (int jj = 1; jj <= Hh; jj++)
+                            for (int ii = 1; ii <= W; ii++) {
+                                const int gi = subs[r].global.xstart + ii - in.xstart;
+                                const int gj = subs[r].global.ystart + jj - in.ystart;
+                                const bool internal = ii >= in.xstart && ii <= in.xstop && jj >= in.ystart && jj <= in.ystop;
+                                const bool in_domain = gi >= 1 && gi <= nx && gj >= 1 && gj <= ny;
+                                const int h = hits[(size_t)(jj - 1) * W + ii - 1];
+                                if (internal) REQUIRE(h == 0);
+                                else if (in_domain) REQUIRE(h == 1);
+                                else REQUIRE(h <= 1);      // ring cells carried along the strips
+                            }
+                    }
+                }
+    {
+        std::vector<dlesm_subdomain> subs(4);
+        dlesm_decomp d;
+        dlesm_comm_tables t;
+        REQUIRE(dlesm_decompose(40, 40, 4, 0, 0, 2, &d, subs.data()) == 0);
+        REQUIRE(dlesm_map_comms_depth(&d, subs.data(), 4, 1, 3, &t) == DLESM_EINVAL);   // halo width 2 < depth 3
+        REQUIRE(dlesm_map_comms_depth(&d, subs.data(), 4, 1, 0, &t) == DLESM_EINVAL);
+        REQUIRE(dlesm_map_comms_depth(&d, subs.data(), 4, 5, 2, &t) == DLESM_EINVAL);
+        REQUIRE(dlesm_map_comms_depth(&d, subs.data(), 3, 1, 2, &t) == DLESM_EINVAL);
+        REQUIRE(dlesm_map_comms_depth(nullptr, subs.data(), 4, 1, 2, &t) == DLESM_EINVAL);
+    }
     // user tilings and rejected arguments
     {
         std::vector<dlesm_subdomain> subs(64);

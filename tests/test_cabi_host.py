@@ -189,6 +189,36 @@ def test_map_comms_matches_survey_probe():
     assert [[s["nx"], s["ny"]] for s in t4.sends()] == g["rank4"]["send_shapes"]
 
 
+@pytest.mark.parametrize("nx,ny,nranks", [(10, 10, 4), (16, 32, 8), (12, 9, 6), (40, 7, 2), (7, 40, 2)])
+def test_map_comms_depth_1_is_the_reference_table_plus_ring_cells(nx, ny, nranks):
+    """the depth-d extension at d = 1 on a halo-width-1 decomposition: same messages, in the same
+    order, as the reference's tables; a strip that ends at the domain edge is one ring cell longer
+    there, and the never-read isrcrecv quirk of the east receive (pcomms:521) is not reproduced"""
+    d = D.go_decompose(nx, ny, ndomains=nranks)
+    for r in range(1, nranks + 1):
+        ref, ext = D.map_comms(d, rank1=r, nranks=nranks), D.map_comms(d, rank1=r, nranks=nranks, depth=1)
+        assert [(m["dir"], m["dest"]) for m in ref.sends()] == [(m["dir"], m["dest"]) for m in ext.sends()]
+        assert [(m["dir"], m["src"]) for m in ref.recvs()] == [(m["dir"], m["src"]) for m in ext.recvs()]
+        for a, b in zip(ref.sends() + ref.recvs(), ext.sends() + ext.recvs()):
+            grow_x, grow_y = b["nx"] - a["nx"], b["ny"] - a["ny"]
+            assert 0 <= grow_x <= 2 and 0 <= grow_y <= 2 and (a["dir"] <= 4 or grow_x == grow_y == 0)
+            assert (a["dir"] in (1, 2) and grow_x == 0) or (a["dir"] in (3, 4) and grow_y == 0) or a["dir"] > 4
+            # destination patch starts where the reference's does, or one ring cell before it
+            assert a["ides"] - b["ides"] in (0, 1) and a["jdes"] - b["jdes"] in (0, 1)
+
+
+def test_map_comms_depth_needs_room():
+    t = _cabi.CommTables()
+    d = D.go_decompose(40, 40, ndomains=4, halo_width=2)
+    assert L.dlesm_map_comms_depth(C.byref(d._info), d.subdomains, 4, 1, 2, C.byref(t)) == 0
+    assert {(m["nx"], m["ny"]) for m in t.sends() if m["dir"] > 4} == {(2, 2)}
+    assert L.dlesm_map_comms_depth(C.byref(d._info), d.subdomains, 4, 1, 3, C.byref(t)) == _cabi.EINVAL
+    assert b"halo width" in L.dlesm_last_error()
+    d = D.go_decompose(8, 3, ndomains=4, ndomainx=4, ndomainy=1, halo_width=4)
+    assert L.dlesm_map_comms_depth(C.byref(d._info), d.subdomains, 4, 1, 4, C.byref(t)) == _cabi.EINVAL
+    assert b"smaller than depth" in L.dlesm_last_error()
+
+
 def test_map_comms_rejects_what_it_cannot_represent():
     d = D.go_decompose(10, 10, ndomains=4)
     t = _cabi.CommTables()

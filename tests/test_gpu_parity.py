@@ -340,10 +340,10 @@ def test_halo_exchange_loopback_on_one_gpu(D):
 @pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (5, 4, 2), (64, 48, 8), (300, 70, 64), (257, 129, None),
                                              (1, 1, 2), (123, 3, 2), (124, 5, 2), (125, 2, 2), (1000, 37, 64),
                                              (8000, 9, 64)])
-@pytest.mark.parametrize("sw_kernel,sw_rows", [(0, 2), (0, 1), (0, 3), (1, 2)])
-def test_shallow_step_matches_oracle(D, nx, ny, alignment, sw_kernel, sw_rows):
+@pytest.mark.parametrize("sw_kernel,sw_rows,sw_dpp", [(0, 2, 1), (0, 1, 1), (0, 3, 1), (0, 2, 0), (0, 3, 0), (1, 2, 1)])
+def test_shallow_step_matches_oracle(D, nx, ny, alignment, sw_kernel, sw_rows, sw_dpp):
     import torch
-    _set_tuning(D, sw_kernel=sw_kernel, sw_tile_rows=sw_rows)
+    _set_tuning(D, sw_kernel=sw_kernel, sw_tile_rows=sw_rows, sw_dpp=sw_dpp)
     g = _grid(D, nx, ny, alignment)
     names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
     pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
@@ -372,7 +372,7 @@ def test_shallow_step_matches_oracle(D, nx, ny, alignment, sw_kernel, sw_rows):
         err = np.max(np.abs(got - want[n]) / np.maximum(np.abs(want[n]), 1e-300))
         assert err <= 1e-12, (n, err)
         assert np.array_equal(got, want[n]), (n, "not bit-exact", err)
-    _set_tuning(D, sw_kernel=0, sw_tile_rows=2)
+    _set_tuning(D, sw_kernel=0, sw_tile_rows=2, sw_dpp=1)
 
 
 @pytest.mark.parametrize("nx,ny", [(1, 1), (2, 2), (1, 6), (6, 1), (3, 3), (130, 5), (5, 130), (257, 64)])
