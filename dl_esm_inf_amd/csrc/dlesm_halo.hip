@@ -360,7 +360,7 @@ extern "C" int dlesm_jacobi5_multi_step_dm(dlesm_halo_plan *p, const double *in,
 {
     DLESM_REQUIRE(p != nullptr && in != nullptr && out != nullptr, "null pointer");
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
-    DLESM_REQUIRE(nsteps >= 2 && nsteps <= 4, "fused distributed step: nsteps = %d (2..4 supported)", nsteps);
+    DLESM_REQUIRE(nsteps >= 2 && nsteps <= 8, "fused distributed step: nsteps = %d (2..8 supported)", nsteps);
     if (int rc = ensure_device()) return rc;
     hipStream_t s = (hipStream_t)stream, side = side_stream();
     const int T = nsteps;

@@ -1,4 +1,4 @@
-// T Jacobi-5 time steps in one sweep (temporal blocking), T = 2, 3, 4.
+// T Jacobi-5 time steps in one sweep (temporal blocking), T = 2..8.
 //
 //   t_0 = in
 //   t_s(i,j) = J(t_{s-1})(i,j)  for (i,j) in the stage box E_s,  t_{s-1}(i,j) elsewhere   (s = 1..T-1)
@@ -63,10 +63,8 @@ __device__ __forceinline__ void xt_stages(xt_d2 (&v)[R + 2 * T], const XtBoxes &
     }
 }
 
-// W: waves per SIMD the register allocation must leave room for (occupancy against VGPRs)
-template <int T, int R, bool DPP, int W>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(W, 8)))
-void jacobi5xt_tile(const double *__restrict__ in, double *__restrict__ out, int ld, int ny, XtBoxes b,
+template <int T, int R, bool DPP>
+__global__ __launch_bounds__(512) void jacobi5xt_tile(const double *__restrict__ in, double *__restrict__ out, int ld, int ny, XtBoxes b,
                     int cb, int nxw, int nband, double q)
 {
     typedef xt_d2 d2;
@@ -154,9 +152,12 @@ static void launch_xt(const double *in, double *out, int ld, int ny, const XtBox
     constexpr int OL = 64 - 2 * ((T + 1) / 2);
     const int cb = b.x0 / 2, c_last = b.x1 / 2;
     int nxw = (c_last - cb + OL) / OL, tpb = 4, nband = 0;
-    // measured best at 16384^2 (profiles/r01_sweep_fused.txt): 4, 6, 8 rows for T = 2, 3, 4
-    if (R != 2 && R != 4 && R != 6 && R != 8) R = T == 2 ? 4 : (T == 3 ? 6 : 8);
-    const int W = tuning("j5xt_waves", 2);
+    // measured best at 16384^2 (profiles/r01_sweep_fused.txt): 4, 6, 8, 8, 16, 16, 12 rows for
+    // T = 2..8; capping the VGPRs for more waves per SIMD made no difference (2, 3, 4 waves tried)
+    constexpr int best_rows[9] = {0, 0, 4, 6, 8, 8, 16, 16, 12};
+    if (R != 2 && R != 4 && R != 6 && R != 8 && R != 12 && R != 16) R = best_rows[T];
+    if (T > 4 && R < 8) R = 8;                           // deep fusions: tall tiles only
+    if (T < 4 && R > 8) R = 8;
     const int strips = (b.y1 - b.y0 + R) / R;
     unsigned grid;
     if (tuning("j5xt_order", 0) == 1 && nxw >= 16) {    // XCD column bands (measured: no gain)
@@ -169,23 +170,18 @@ static void launch_xt(const double *in, double *out, int ld, int ny, const XtBox
         if (tpb > 8) tpb = 8;                           // launch bound of the kernel: 512 lanes
         grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
     }
-#define DLESM_XTW(RR, WW)                                                                                       \
-    hipLaunchKernelGGL((jacobi5xt_tile<T, RR, DPP, WW>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, ny, b, \
-                       cb, nxw, nband, 0.25)
 #define DLESM_XT(RR)                                                                                          \
-    do {                                                                                                      \
-        if (W >= 4) DLESM_XTW(RR, 4);                                                                         \
-        else if (W == 3) DLESM_XTW(RR, 3);                                                                    \
-        else DLESM_XTW(RR, 2);                                                                                \
-    } while (0)
+    hipLaunchKernelGGL((jacobi5xt_tile<T, RR, DPP>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, ny, b, cb, \
+                       nxw, nband, 0.25)
     switch (R) {
-    case 2: DLESM_XT(2); break;
-    case 4: DLESM_XT(4); break;
-    case 6: DLESM_XT(6); break;
+    case 2: if constexpr (T <= 4) DLESM_XT(2); break;
+    case 4: if constexpr (T <= 4) DLESM_XT(4); break;
+    case 6: if constexpr (T <= 4) DLESM_XT(6); break;
+    case 12: if constexpr (T >= 4) DLESM_XT(12); break;
+    case 16: if constexpr (T >= 4) DLESM_XT(16); break;
     default: DLESM_XT(8); break;
     }
 #undef DLESM_XT
-#undef DLESM_XTW
 }
 
 // 1-based inclusive boxes: output box, last intermediate box, and per side (W,E,S,N) whether the
@@ -194,7 +190,7 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
                           int ystart, int ystop, int exstart, int exstop, int eystart, int eystop, int gw,
                           int ge, int gs, int gn, hipStream_t s)
 {
-    DLESM_REQUIRE(nsteps >= 2 && nsteps <= 4, "fused Jacobi steps: nsteps = %d (2..4 supported)", nsteps);
+    DLESM_REQUIRE(nsteps >= 2 && nsteps <= 8, "fused Jacobi steps: nsteps = %d (2..8 supported)", nsteps);
     DLESM_REQUIRE((gw | ge | gs | gn | 1) == 1, "fused Jacobi steps: grow flags must be 0 or 1");
     if (xstop < xstart || ystop < ystart) return DLESM_OK; // empty box: a zero-trip loop nest
     if (int rc = check_box("fused Jacobi steps", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
@@ -233,9 +229,15 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
         if (dpp) launch_xt<TT, true>(in, out, ld, ny, b, R, s);                 \
         else launch_xt<TT, false>(in, out, ld, ny, b, R, s);                    \
     } while (0)
-    if (nsteps == 2) DLESM_T(2);
-    else if (nsteps == 3) DLESM_T(3);
-    else DLESM_T(4);
+    switch (nsteps) {
+    case 2: DLESM_T(2); break;
+    case 3: DLESM_T(3); break;
+    case 4: DLESM_T(4); break;
+    case 5: DLESM_T(5); break;
+    case 6: DLESM_T(6); break;
+    case 7: DLESM_T(7); break;
+    default: DLESM_T(8); break;
+    }
 #undef DLESM_T
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;

@@ -266,7 +266,7 @@ module parallel_comms_mod
 
   integer, parameter :: MAX_HALO_DEPTH = 1
   !> deepest exchange the device layer builds tables for (dlesm_map_comms_depth)
-  integer, parameter :: MAX_DEVICE_HALO_DEPTH = 4
+  integer, parameter :: MAX_DEVICE_HALO_DEPTH = 8
   integer, parameter :: MaxComm = DLESM_MAXCOMM
 
   ! One rank's message lists (reference parallel_comms_mod.f90:52-83); a module-level

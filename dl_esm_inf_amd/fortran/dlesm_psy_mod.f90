@@ -94,7 +94,7 @@ contains
     if (rc /= 0) call gocean_stop('invoke_jacobi5_dm: ' // dlesm_error_text())
   end subroutine invoke_jacobi5_dm
 
-  !> nsteps (2..4) Jacobi time steps in one sweep (temporal blocking).  Serial / one tile: the
+  !> nsteps (2..8) Jacobi time steps in one sweep (temporal blocking).  Serial / one tile: the
   !! boundary ring of `in` stays fixed through all steps.  Distributed (grid decomposed with
   !! halo_width = nsteps): one depth-nsteps halo exchange per call, hidden behind the interior;
   !! `in` must hold valid depth-nsteps halos and `out` leaves with them.  Bit-identical to nsteps

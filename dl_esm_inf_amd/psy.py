@@ -28,7 +28,7 @@ def invoke_jacobi5_x2(out_fld, in_fld, ebox=None, stream=None):
 
 
 def invoke_jacobi5_multi(out_fld, in_fld, nsteps, ebox=None, grow=(0, 0, 0, 0), stream=None):
-    """nsteps (2..4) Jacobi steps in one sweep over out_fld%internal; `ebox` is the last stage
+    """nsteps (2..8) Jacobi steps in one sweep over out_fld%internal; `ebox` is the last stage
     box (default: the same box, a fixed boundary ring), `grow` the (W, E, S, N) flags"""
     g, it = out_fld.grid, out_fld.internal
     e = ebox if ebox is not None else it.box()

@@ -201,7 +201,7 @@ int dlesm_stencil5_x2_f64(const double *in, double *out, int ld, int ny,
                           int xstart, int xstop, int ystart, int ystop,
                           int exstart, int exstop, int eystart, int eystop, void *stream);
 
-/* nsteps (2..4) Jacobi steps in one sweep:
+/* nsteps (2..8) Jacobi steps in one sweep:
  *   t_0 = in;  t_s = J(t_{s-1}) on the stage box E_s, t_{s-1} elsewhere (s = 1..nsteps-1);
  *   out = J(t_{nsteps-1}) on the box.
  * (exstart:exstop, eystart:eystop) is the LAST stage box E_{nsteps-1}; E_s is that box grown by
@@ -291,7 +291,7 @@ int dlesm_jacobi5_step_dm(dlesm_halo_plan *plan, const double *in, double *out,
                           int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                           void *stream);
 
-/* nsteps (2..4) distributed Jacobi time steps per call, ONE depth-nsteps exchange per call
+/* nsteps (2..8) distributed Jacobi time steps per call, ONE depth-nsteps exchange per call
  * (temporal blocking across tiles; dlesm_stencil5_multi_f64 with stage boxes grown towards
  * every neighbouring tile).  `plan` must come from dlesm_map_comms_depth(depth = nsteps) tables
  * and `in` must hold valid depth-nsteps halos; `out` leaves with valid depth-nsteps halos.

@@ -65,8 +65,9 @@ dm)
     tail -22 $OUT/dm_overhead_16384.log ;;
 dmfused)
     for t in 8192 16384; do
-        step dmf$t 300 python scripts/dm_overhead.py --fused 4 --tile $t --steps 24 --out $OUT/dm_fused4_$t.json > $OUT/dm_fused4_$t.log 2>&1
-        grep -v amdgpu.ids $OUT/dm_fused4_$t.log | tail -20
+        F=${FUSED:-8}
+        step dmf$t 300 python scripts/dm_overhead.py --fused $F --tile $t --steps 40 --out $OUT/dm_fused${F}_$t.json > $OUT/dm_fused${F}_$t.log 2>&1
+        grep -v amdgpu.ids $OUT/dm_fused${F}_$t.log | tail -20
     done ;;
 shallow)
     step shallow 400 python scripts/shallow_bench.py --out $OUT/shallow_bench.json > $OUT/shallow_bench.log 2>&1

@@ -37,7 +37,7 @@ def test_bench_line_and_secondary_legs():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     tb = d["temporal_blocking"]
-    assert tb["fused_steps"] == 4 and tb["bit_identical_to_single_steps"] is True and tb["value"] > 0
+    assert tb["fused_steps"] == 8 and tb["bit_identical_to_single_steps"] is True and tb["value"] > 0
     f = _bench("--fused", "4", "--no-cpu-baseline")
     assert f["config"]["fused_steps_per_launch"] == 4 and f["value"] > 0
 
@@ -46,4 +46,4 @@ def test_rehearsal_of_the_multi_gpu_secondary_leg():
     d = _bench("--force-dm-leg", "--no-cpu-baseline")
     tb = d["temporal_blocking"]
     assert "error" not in tb, tb
-    assert tb["halo_depth"] == 4 and tb["bit_identical_to_single_steps_plus_exchange"] is True
+    assert tb["halo_depth"] == 8 and tb["bit_identical_to_single_steps_plus_exchange"] is True

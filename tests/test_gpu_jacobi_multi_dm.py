@@ -27,7 +27,8 @@ def D():
 
 
 CASES = [(4, 4, 2, 2), (2, 5, 2, 2), (9, 7, 3, 2), (40, 33, 2, 8), (257, 66, 4, 64), (130, 9, 4, None), (8, 8, 4, 2),
-         (300, 40, 3, 64), (1900, 23, 4, 64), (64, 300, 2, None)]
+         (300, 40, 3, 64), (1900, 23, 4, 64), (64, 300, 2, None), (30, 20, 8, 2), (16, 16, 8, None), (700, 40, 6, 64),
+         (64, 70, 5, 8), (33, 9, 7, 2), (1200, 64, 8, 64)]
 
 
 @pytest.mark.parametrize("nx,ny,nsteps,alignment", CASES)

@@ -55,7 +55,8 @@ CASES = [(1, 1, None), (2, 3, 2), (4, 10, None), (10, 4, 8), (5, 5, 8), (64, 64,
          (119, 9, 2), (120, 9, 2), (121, 9, 2), (123, 9, 2), (124, 9, 2), (125, 9, 2), (247, 31, 64), (248, 31, 64),
          (249, 31, 64), (255, 130, 64), (256, 256, None), (511, 70, 4), (1021, 33, 64), (1500, 200, 64),
          (1500, 200, None), (4096, 300, 64), (1930, 37, 2), (2500, 40, 64), (3001, 21, None)]
-TUNES = [dict(), dict(j5xt_rows=2, j5xt_dpp=0), dict(j5xt_rows=8, j5_tpb=8), dict(j5xt_rows=4, j5_tpb=2, j5xt_dpp=0),
+STEPS = [2, 3, 4, 5, 6, 7, 8]
+TUNES = [dict(), dict(j5xt_rows=12), dict(j5xt_rows=16, j5xt_dpp=0), dict(j5xt_rows=2, j5xt_dpp=0), dict(j5xt_rows=8, j5_tpb=8), dict(j5xt_rows=4, j5_tpb=2, j5xt_dpp=0),
          dict(j5xt_order=1), dict(j5xt_order=1, j5xt_rows=4, j5_tpb=8), dict(j5xt_order=1, j5xt_rows=2, j5_tpb=2),
          dict(j5_variant=4)]
 DEFAULTS = dict(j5xt_rows=0, j5xt_dpp=1, j5xt_order=0, j5_tpb=0, j5_variant=0)
@@ -67,7 +68,7 @@ def _tune(D, kw):
 
 
 @pytest.mark.parametrize("nx,ny,alignment", CASES)
-@pytest.mark.parametrize("nsteps", [2, 3, 4])
+@pytest.mark.parametrize("nsteps", STEPS)
 @pytest.mark.parametrize("tune", TUNES, ids=lambda t: "-".join(f"{k}{v}" for k, v in t.items()) or "default")
 def test_fused_steps_bit_exact(D, nx, ny, alignment, nsteps, tune):
     if tune.get("j5_variant") == 4 and nsteps > 2:
@@ -90,26 +91,27 @@ def test_fused_steps_bit_exact(D, nx, ny, alignment, nsteps, tune):
         _tune(D, DEFAULTS)
 
 
-@pytest.mark.parametrize("nsteps", [2, 3, 4])
+@pytest.mark.parametrize("nsteps", STEPS)
 def test_fused_sub_boxes_and_grown_stage_boxes(D, nsteps):
     """the forms the distributed step uses: thin output boxes with the tile's stage boxes, stage
     boxes grown towards some sides (deep halos), empty boxes; refusals"""
     L = D._cabi.lib()
     import torch
-    g = _grid(D, 308, 97, 2)            # 312 x 100 array; cells 5..304 x 5..94 play the tile interior
+    g = _grid(D, 316, 105, 2)           # 320 x 108 array; cells 9..308 x 9..98 play the tile interior
     a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
     D.psy.hash_init(a, SEED, box=D._cabi.Region(0, 0, 1, g.nx, 1, g.ny))
     hin = a.get_data()
-    assert g.nx >= 309 and g.ny >= 99
-    full = (5, 304, 5, 94)
-    allg = (4, 305, 4, 95)              # last stage box of a tile with neighbours on every side
+    assert g.nx >= 317 and g.ny >= 107
+    x0, x1, y0, y1 = full = (9, 308, 9, 98)
+    allg = (x0 - 1, x1 + 1, y0 - 1, y1 + 1)   # last stage box of a tile with neighbours on every side
+    T = nsteps
     cases = [
-        (full, full, (0, 0, 0, 0)), (full, allg, (1, 1, 1, 1)), (full, (4, 304, 5, 95), (1, 0, 0, 1)),
-        (full, (5, 305, 4, 94), (0, 1, 1, 0)),
-        ((5, 8, 5, 94), allg, (1, 1, 1, 1)), ((301, 304, 5, 94), allg, (1, 1, 1, 1)),
-        ((5, 304, 5, 8), allg, (1, 1, 1, 1)), ((5, 304, 91, 94), (4, 304, 4, 95), (1, 0, 1, 1)),
-        ((9, 300, 9, 90), allg, (1, 1, 1, 1)), ((17, 17, 40, 40), full, (0, 0, 0, 0)),
-        ((40, 39, 5, 94), full, (0, 0, 0, 0)), (full, (10, 9, 5, 94), (0, 0, 0, 0)), ((5, 304, 50, 49), full, (1, 1, 1, 1)),
+        (full, full, (0, 0, 0, 0)), (full, allg, (1, 1, 1, 1)), (full, (x0 - 1, x1, y0, y1 + 1), (1, 0, 0, 1)),
+        (full, (x0, x1 + 1, y0 - 1, y1), (0, 1, 1, 0)),
+        ((x0, x0 + T - 1, y0, y1), allg, (1, 1, 1, 1)), ((x1 - T + 1, x1, y0, y1), allg, (1, 1, 1, 1)),
+        ((x0, x1, y0, y0 + T - 1), allg, (1, 1, 1, 1)), ((x0, x1, y1 - T + 1, y1), (x0 - 1, x1, y0 - 1, y1 + 1), (1, 0, 1, 1)),
+        ((x0 + T, x1 - T, y0 + T, y1 - T), allg, (1, 1, 1, 1)), ((17, 17, 40, 40), full, (0, 0, 0, 0)),
+        ((40, 39, y0, y1), full, (0, 0, 0, 0)), (full, (10, 9, y0, y1), (0, 0, 0, 0)), ((x0, x1, 50, 49), full, (1, 1, 1, 1)),
     ]
     for box, ebox, grow in cases:
         D.set_field(b, -7.0)
@@ -121,14 +123,14 @@ def test_fused_sub_boxes_and_grown_stage_boxes(D, nsteps):
         assert np.array_equal(got, want), (box, ebox, grow, np.argwhere(got != want)[:5])
     # boxes whose stencil ring leaves the array are refused, so are aliased arrays and bad step counts
     k = nsteps - 2
-    bad = [((1, 10, 5, 10), full, (0, 0, 0, 0)), (full, (2 + k - 1, 305, 4, 95), (1, 1, 1, 1)),
-           (full, (4, g.nx - k, 4, 95), (1, 1, 1, 1)), (full, allg, (2, 0, 0, 0))]
+    bad = [((1, 10, y0, 10), full, (0, 0, 0, 0)), (full, (k + 1, x1 + 1, y0 - 1, y1 + 1), (1, 1, 1, 1)),
+           (full, (x0 - 1, g.nx - k, y0 - 1, y1 + 1), (1, 1, 1, 1)), (full, allg, (2, 0, 0, 0))]
     for box, ebox, grow in bad:
         rc = L.dlesm_stencil5_multi_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, nsteps, *box, *ebox, *grow, None)
         assert rc == D._cabi.EINVAL, (box, ebox, grow)
     assert L.dlesm_stencil5_multi_f64(a.device_ptr, a.device_ptr, g.nx, g.ny, nsteps, *full, *full, 0, 0, 0, 0,
                                       None) == D._cabi.EINVAL
-    for n in (0, 1, 5):
+    for n in (0, 1, 9):
         assert L.dlesm_stencil5_multi_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, n, *full, *full, 0, 0, 0, 0,
                                           None) == D._cabi.EINVAL
 
@@ -158,7 +160,7 @@ def test_fused_equals_single_steps_full_size(D, n, alignment):
     for f in (p, q, c):
         D.copy_field(a, f)              # same fixed ring everywhere
     src, dst = a, p
-    for nsteps in (1, 2, 3, 4):
+    for nsteps in (1, 2, 3, 4, 5, 6, 7, 8):
         if nsteps > 1:
             D.psy.invoke_jacobi5_multi(c, a, nsteps)
         D.psy.invoke_jacobi5(dst, src)  # dst = J^nsteps(a)

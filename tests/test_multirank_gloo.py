@@ -44,7 +44,7 @@ def _run_ranks(world, args):
 
 # the depth-d extension: deep-halo exchange + the staged steps of the fused distributed kernel
 @pytest.mark.parametrize("nx,ny,world,depth", [(12, 8, 2, 2), (8, 13, 2, 3), (17, 16, 4, 2), (24, 21, 6, 4),
-                                               (16, 32, 8, 4)])
+                                               (16, 32, 8, 4), (32, 33, 4, 8), (20, 40, 2, 6)])
 def test_deep_halos_and_staged_steps_over_gloo(nx, ny, world, depth):
     _run_ranks(world, [nx, ny, depth])
 
