@@ -84,7 +84,7 @@ def cpu_baseline(host_in, ld, box, budget_s):
     }
 
 
-XT_ROWS = {2: 4, 3: 6, 4: 8, 5: 8, 6: 16, 7: 16, 8: 12}      # rows per wave tile the library picks per T
+XT_ROWS = {2: 4, 3: 6, 4: 8, 5: 8, 6: 12, 7: 16, 8: 16}      # rows per wave tile the library picks per T
 TB_STEPS = 8                                                 # time steps per launch of the secondary legs
 
 

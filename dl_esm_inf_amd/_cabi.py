@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libdlesm_hip.so")
+# DLESM_HIP_LIB: another build of the same library, for A/B measurements of kernel variants
+LIB_PATH = os.environ.get("DLESM_HIP_LIB") or os.path.join(HERE, "lib", "libdlesm_hip.so")
 MAXCOMM = 16
 UNIQUE_ID_BYTES = 128
 

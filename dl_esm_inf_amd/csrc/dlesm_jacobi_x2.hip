@@ -31,6 +31,11 @@ struct XtBoxes {           // 0-based inclusive
 
 typedef double xt_d2 __attribute__((ext_vector_type(2)));
 
+// from this many fused steps on, tile indices are computed on the scalar unit (A/B builds: 2 or 99)
+#ifndef DLESM_XT_SCALAR_FROM
+#define DLESM_XT_SCALAR_FROM 3
+#endif
+
 // Stages 1..T-1 in place on the register rows.  SEL: the wave touches the edge of a stage box,
 // so every value is selected between J(previous stage) and the previous stage itself; waves
 // wholly inside the last stage box (almost all of them) skip the selects.  `q` is 0.25, passed
@@ -70,6 +75,11 @@ __global__ __launch_bounds__(512) void jacobi5xt_tile(const double *__restrict__
     typedef xt_d2 d2;
     constexpr int H = (T + 1) / 2;                      // halo lanes per side
     const int lane = threadIdx.x & 63;
+    // the wave's number inside the workgroup as a SCALAR: everything derived from it (tile
+    // position, row numbers, row base addresses, the rim test) then lives in SGPRs and the row
+    // loads take the "scalar base + lane offset" form instead of one 64-bit VGPR address per row
+    int wv = threadIdx.x >> 6;
+    if constexpr (T >= DLESM_XT_SCALAR_FROM) wv = __builtin_amdgcn_readfirstlane(wv);
     int xw, strip;
     if (nband > 0) {
         // XCD column bands: workgroups are dealt round-robin to the 8 XCDs, so XCD k = blockIdx % 8
@@ -77,14 +87,18 @@ __global__ __launch_bounds__(512) void jacobi5xt_tile(const double *__restrict__
         // strip shares with the strip below ((R+2T) loaded per R stored) were then fetched by the
         // same XCD one strip earlier and are hits in ITS L2, whatever the row length; all 8 XCDs
         // work on the same strip at the same time, so memory is still swept linearly.
-        const int wi = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const int wi = (blockIdx.x >> 3) * (blockDim.x >> 6) + wv;
         strip = wi / nband;
         xw = (blockIdx.x & 7) * nband + wi % nband;
         if (xw >= nxw) return;
     } else {
-        const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const int w = blockIdx.x * (blockDim.x >> 6) + wv;
         xw = w % nxw;
         strip = w / nxw;
+    }
+    if constexpr (T >= DLESM_XT_SCALAR_FROM) {
+        xw = __builtin_amdgcn_readfirstlane(xw);       // (the integer division runs on the VALU)
+        strip = __builtin_amdgcn_readfirstlane(strip);
     }
     const int jb = b.y0 + strip * R;
     if (jb > b.y1) return;
@@ -98,14 +112,15 @@ __global__ __launch_bounds__(512) void jacobi5xt_tile(const double *__restrict__
     const bool ol = lane >= H && lane <= 63 - H && c <= c_ld;
     const bool m0 = ol && 2 * c >= b.x0 && 2 * c <= b.x1;
     const bool m1 = ol && 2 * c + 1 >= b.x0 && 2 * c + 1 <= b.x1;
-    const double *pin = in + (size_t)cl * 2;
+    const unsigned lane_off = (unsigned)cl * 16u;       // bytes; a row is < 4 GiB
     d2 v[R + 2 * T];
 #pragma unroll
     for (int u = 0; u < R + 2 * T; u++) {
         int jj = jb - T + u;
         if (jj > je + T) jj = je + T;                   // short last strip: loaded again, never used
         jj = jj < 0 ? 0 : (jj > ny - 1 ? ny - 1 : jj);  // rows outside the array feed discarded values only
-        v[u] = *(const d2 *)(pin + (size_t)jj * ld);
+        const char *row = (const char *)(in + (size_t)jj * ld);     // wave-uniform
+        v[u] = *(const d2 *)(row + lane_off);
     }
     // every column of the wave and every intermediate row it computes inside the LAST (smallest)
     // stage box: no value is ever "carried", the selects can go
@@ -120,7 +135,7 @@ __global__ __launch_bounds__(512) void jacobi5xt_tile(const double *__restrict__
         if (jb + u <= je) {
             const double o0 = q * ((west + mid.y) + (v[u].x + v[u + 2].x));
             const double o1 = q * ((mid.x + east) + (v[u].y + v[u + 2].y));
-            double *po = out + (size_t)(jb + u) * ld + (size_t)c * 2;
+            double *po = (double *)((char *)(out + (size_t)(jb + u) * ld) + (size_t)(unsigned)c * 16u);
             if (m0 && m1) *(d2 *)po = d2{o0, o1};
             else {
                 if (m0) po[0] = o0;
@@ -152,9 +167,9 @@ static void launch_xt(const double *in, double *out, int ld, int ny, const XtBox
     constexpr int OL = 64 - 2 * ((T + 1) / 2);
     const int cb = b.x0 / 2, c_last = b.x1 / 2;
     int nxw = (c_last - cb + OL) / OL, tpb = 4, nband = 0;
-    // measured best at 16384^2 (profiles/r01_sweep_fused.txt): 4, 6, 8, 8, 16, 16, 12 rows for
+    // measured best at 16384^2 (profiles/r01_sweep_fused.txt): 4, 6, 8, 8, 12, 16, 16 rows for
     // T = 2..8; capping the VGPRs for more waves per SIMD made no difference (2, 3, 4 waves tried)
-    constexpr int best_rows[9] = {0, 0, 4, 6, 8, 8, 16, 16, 12};
+    constexpr int best_rows[9] = {0, 0, 4, 6, 8, 8, 12, 16, 16};
     if (R != 2 && R != 4 && R != 6 && R != 8 && R != 12 && R != 16) R = best_rows[T];
     if (T > 4 && R < 8) R = 8;                           // deep fusions: tall tiles only
     if (T < 4 && R > 8) R = 8;

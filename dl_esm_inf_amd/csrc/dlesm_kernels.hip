@@ -8,6 +8,14 @@
 
 #include "dlesm_internal.h"
 
+// 1: tile indices of jacobi5_tile on the scalar unit (readfirstlane of the wave number).  Measured
+// A/B on one box at 16384^2: 0.732 ms per launch against 0.718 ms with the per-lane form -- the
+// scalar chain delays the first loads of these short-lived waves -- so the default stays 0.  (The
+// long fused-step kernel in dlesm_jacobi_x2.hip does gain from it.)
+#ifndef DLESM_J5_SCALAR
+#define DLESM_J5_SCALAR 0
+#endif
+
 namespace dlesm {
 
 // ===========================================================================
@@ -220,6 +228,11 @@ __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ 
                                                     int band_rows, int gs, int flags)
 {
     const int lane = threadIdx.x & 63;
+#if DLESM_J5_SCALAR
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+    const int wv = threadIdx.x >> 6;
+#endif
     int xw, jb, by1;
     if (gs > 0) {
         // XCD-aware order.  Strips are taken in groups of gs; a group's tiles, padded to a
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ 
         // work on the same gs*R rows at a time, and groups follow each other linearly.
         const int bpg = band_rows;                       // blocks per group (multiple of 8)
         const int g = blockIdx.x / bpg, bg = blockIdx.x % bpg;
-        const int slot = ((bg % 8) * (bpg / 8) + bg / 8) * 4 + (threadIdx.x >> 6);   // 256-thread blocks
+        const int slot = ((bg % 8) * (bpg / 8) + bg / 8) * 4 + wv;                   // 256-thread blocks
         xw = slot / gs;
         if (xw >= nxw) return;
         jb = y0 + (g * gs + slot % gs) * R;
@@ -238,13 +251,17 @@ __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ 
     } else {
         const int band = blockIdx.x % nbands;
         // wave-tile number inside the band; a block is blockDim.x/64 consecutive tiles
-        const int w = (blockIdx.x / nbands) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const int w = (blockIdx.x / nbands) * (blockDim.x >> 6) + wv;
         xw = w % nxw;
         const int by0 = y0 + band * band_rows;
         by1 = by0 + band_rows - 1;
         if (by1 > y1) by1 = y1;
         jb = by0 + (w / nxw) * R;
     }
+#if DLESM_J5_SCALAR
+    xw = __builtin_amdgcn_readfirstlane(xw);           // (integer division runs on the VALU)
+    jb = __builtin_amdgcn_readfirstlane(jb);
+#endif
     if (jb > by1) return;
     int je = jb + R - 1;
     if (je > by1) je = by1;
