@@ -169,7 +169,7 @@ static void launch_xt(const double *in, double *out, int ld, int ny, const XtBox
     int nxw = (c_last - cb + OL) / OL, tpb = 4, nband = 0;
     // measured best at 16384^2 (profiles/r01_sweep_fused.txt): 4, 6, 8, 8, 12, 16, 16 rows for
     // T = 2..8; capping the VGPRs for more waves per SIMD made no difference (2, 3, 4 waves tried)
-    constexpr int best_rows[9] = {0, 0, 4, 6, 8, 8, 12, 16, 16};
+    constexpr int best_rows[9] = {0, 8, 4, 6, 8, 8, 12, 16, 16};
     if (R != 2 && R != 4 && R != 6 && R != 8 && R != 12 && R != 16) R = best_rows[T];
     if (T > 4 && R < 8) R = 8;                           // deep fusions: tall tiles only
     if (T < 4 && R > 8) R = 8;
@@ -205,13 +205,14 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
                           int ystart, int ystop, int exstart, int exstop, int eystart, int eystop, int gw,
                           int ge, int gs, int gn, hipStream_t s)
 {
-    DLESM_REQUIRE(nsteps >= 2 && nsteps <= 8, "fused Jacobi steps: nsteps = %d (2..8 supported)", nsteps);
+    // nsteps = 1 (internal callers only): the single step through this kernel's tile shape
+    DLESM_REQUIRE(nsteps >= 1 && nsteps <= 8, "fused Jacobi steps: nsteps = %d (2..8 supported)", nsteps);
     DLESM_REQUIRE((gw | ge | gs | gn | 1) == 1, "fused Jacobi steps: grow flags must be 0 or 1");
     if (xstop < xstart || ystop < ystart) return DLESM_OK; // empty box: a zero-trip loop nest
     if (int rc = check_box("fused Jacobi steps", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     DLESM_REQUIRE(in != nullptr && out != nullptr && in != out, "fused Jacobi steps: null or aliased arrays");
-    const bool empty_e = exstop < exstart || eystop < eystart;
-    const int g = nsteps - 2;                            // growth of the first intermediate box
+    const bool empty_e = nsteps == 1 || exstop < exstart || eystop < eystart;
+    const int g = nsteps > 2 ? nsteps - 2 : 0;           // growth of the first intermediate box
     if (!empty_e)
         if (int rc = check_box("fused Jacobi steps (first intermediate box)", ld, ny, exstart - gw * g,
                                exstop + ge * g, eystart - gs * g, eystop + gn * g, 1))
@@ -245,6 +246,7 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
         else launch_xt<TT, false>(in, out, ld, ny, b, R, s);                    \
     } while (0)
     switch (nsteps) {
+    case 1: DLESM_T(1); break;
     case 2: DLESM_T(2); break;
     case 3: DLESM_T(3); break;
     case 4: DLESM_T(4); break;
@@ -276,6 +278,7 @@ extern "C" int dlesm_stencil5_multi_f64(const double *in, double *out, int ld, i
                                         int grow_n, void *stream)
 {
     dlesm::clear_error();
+    if (nsteps < 2) return dlesm::fail(DLESM_EINVAL, "fused Jacobi steps: nsteps = %d (2..8 supported)", nsteps);
     if (int rc = dlesm::ensure_device()) return rc;
     return dlesm::launch_stencil5_multi(in, out, ld, ny, nsteps, xstart, xstop, ystart, ystop, exstart, exstop,
                                         eystart, eystop, grow_w, grow_e, grow_s, grow_n, (hipStream_t)stream);

@@ -611,6 +611,9 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
         DLESM_HIP_TRY(hipGetLastError());
         return DLESM_OK;
     }
+    if (tuning("j5_kernel", 0) == 3 && vec2)   // the fused-step kernel's tile shape with one step
+        return launch_stencil5_multi(in, out, ld, ny, 1, xstart, xstop, ystart, ystop, xstart, xstop, ystart, ystop,
+                                     0, 0, 0, 0, s);
     if (tuning("j5_kernel", 0) == 2 && vec2) { // LDS-staged comparison kernel
         int tpb = tuning("j5_tpb", 4), R = tuning("j5_tile_rows", 8);
         if (tpb != 1 && tpb != 2 && tpb != 4 && tpb != 8 && tpb != 16) tpb = 4;

@@ -86,6 +86,7 @@ TUNINGS = [
     dict(j5_kernel=1, j5_rows=64), dict(j5_kernel=1, j5_rows=7, j5_variant=1),
     dict(j5_kernel=1, j5_rows=16, j5_variant=2, j5_unroll=2), dict(j5_kernel=1, j5_rows=5, j5_variant=3, j5_unroll=8),
     dict(j5_kernel=1, j5_variant=4), dict(j5_kernel=1, j5_rows=9, j5_unroll=2),
+    dict(j5_kernel=3), dict(j5_kernel=3, j5_variant=16),
     dict(j5_kernel=2), dict(j5_kernel=2, j5_tile_rows=2, j5_tpb=16), dict(j5_kernel=2, j5_tile_rows=4, j5_tpb=1),
     dict(j5_kernel=2, j5_tile_rows=16, j5_tpb=8, j5_pad_tiles=2), dict(j5_kernel=2, j5_variant=16),
 ]
