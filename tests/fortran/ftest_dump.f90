@@ -40,7 +40,11 @@ program ftest_dump
   case ('gather')
      call dump_gather(nx, ny)
   case ('comms')
-     call dump_comms(nx, ny)
+     ndom = 1                                   ! optional 4th argument: halo width of the decomposition
+     if (command_argument_count() >= 4) then
+        call get_command_argument(4, arg); read(arg, *) ndom
+     end if
+     call dump_comms(nx, ny, ndom)
   case default
      stop 'ftest_dump: unknown command'
   end select
@@ -140,12 +144,12 @@ contains
   end subroutine dump_gather
 
   !> this rank's message tables after grid_init (dry communicator)
-  subroutine dump_comms(nx, ny)
-    integer, intent(in) :: nx, ny
+  subroutine dump_comms(nx, ny, hw)
+    integer, intent(in) :: nx, ny, hw
     type(grid_type), target :: g
     integer :: k
     g = grid_type(GO_ARAKAWA_C, (/GO_BC_EXTERNAL, GO_BC_EXTERNAL, GO_BC_NONE/), GO_OFFSET_NE)
-    call g%decompose(nx, ny)
+    call g%decompose(nx, ny, halo_width=hw)
     call grid_init(g, 1.0_go_wp, 1.0_go_wp)
     write(*, '("G: rank ",4(I0,1x))') get_rank(), get_num_ranks(), g%nx, g%ny
     write(*, '("G: counts ",2(I0,1x))') nsend, nrecv

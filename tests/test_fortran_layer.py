@@ -117,6 +117,24 @@ def test_fortran_message_tables_match_oracle(exe, nx, ny, nranks):
         assert ints(g["bounds"][0]) == [sg.xstart, sg.xstop, sg.ystart, sg.ystop]
 
 
+@pytest.mark.parametrize("nx,ny,nranks,hw", [(16, 32, 8, 4), (24, 20, 6, 3), (40, 12, 2, 8)])
+def test_fortran_deep_halo_tables_match_the_c_abi(exe, nx, ny, nranks, hw):
+    """a decomposition made with halo_width > 1 gets the depth-hw tables (the extension of
+    dlesm_map_comms_depth) from the Fortran grid_init too"""
+    import dl_esm_inf_amd as D
+    d = D.go_decompose(nx, ny, ndomains=nranks, halo_width=hw)
+    for r in range(nranks):
+        _, g, _ = exe("ftest_dump.exe", "comms", nx, ny, hw,
+                      env={"RANK": str(r), "WORLD_SIZE": str(nranks), "DLESM_DRY_COMMS": "1"})
+        c = D.map_comms(d, rank1=r + 1, nranks=nranks, depth=hw)
+        assert ints(g["counts"][0]) == [c.nsend, c.nrecv]
+        assert [ints(s) for s in g.get("send", [])] == \
+            [[s["dir"], s["dest"], s["isrc"], s["jsrc"], s["ides"], s["jdes"], s["nx"], s["ny"]] for s in c.sends()]
+        assert [ints(q) for q in g.get("recv", [])] == \
+            [[q["dir"], q["src"], q["ides"], q["jdes"], q["nx"], q["ny"]] for q in c.recvs()]
+        assert any(s["nx"] == hw or s["ny"] == hw for s in c.sends())
+
+
 @pytest.mark.gpu
 def test_fortran_device_io_and_jacobi_on_gpu(exe):
     nx, ny, nsteps = 300, 171, 5
