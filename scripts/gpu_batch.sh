@@ -38,15 +38,17 @@ pmc)
     step pmcF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
     step pmcW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
     python scripts/parse_rocprof.py pmc $OUT/pmc_fetch $OUT/pmc_write "16384x16384/A64" $OUT/traffic.json 2>&1 | tail -12 ;;
-pmcx4)   # HBM traffic of the fused 4-step kernel
-    rm -rf $OUT/pmcx4_fetch $OUT/pmcx4_write
+pmcx)    # HBM traffic of the fused kernel, FUSED steps per launch (default 8)
+    F=${FUSED:-8}
+    rm -rf $OUT/pmcx_fetch $OUT/pmcx_write
     [ -f profiles/traffic.json ] && cp profiles/traffic.json $OUT/traffic.json   # records are merged by key
-    step pmcx4F 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcx4_fetch -- python3 bench.py --fused 4 --steps 20 --warmup 4 --no-cpu-baseline > $OUT/pmcx4_fetch.log 2>&1
-    step pmcx4W 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcx4_write -- python3 bench.py --fused 4 --steps 20 --warmup 4 --no-cpu-baseline > $OUT/pmcx4_write.log 2>&1
-    python scripts/parse_rocprof.py pmc $OUT/pmcx4_fetch $OUT/pmcx4_write "16384x16384/A64/fused4" $OUT/traffic.json jacobi5xt_ 2>&1 | tail -12 ;;
-benchx4)
-    step benchx4 400 python bench.py --fused 4 --no-cpu-baseline > $OUT/bench_fused4.json 2> $OUT/bench_fused4.err
-    cat $OUT/bench_fused4.json ;;
+    step pmcxF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcx_fetch -- python3 bench.py --fused $F --steps $((F*5)) --warmup $F --no-cpu-baseline > $OUT/pmcx_fetch.log 2>&1
+    step pmcxW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcx_write -- python3 bench.py --fused $F --steps $((F*5)) --warmup $F --no-cpu-baseline > $OUT/pmcx_write.log 2>&1
+    python scripts/parse_rocprof.py pmc $OUT/pmcx_fetch $OUT/pmcx_write "16384x16384/A64/fused$F" $OUT/traffic.json jacobi5xt_ 2>&1 | tail -12 ;;
+benchx)
+    F=${FUSED:-8}
+    step benchx 400 python bench.py --fused $F --steps $((F*25)) --no-cpu-baseline > $OUT/bench_fused$F.json 2> $OUT/bench_fused$F.err
+    cat $OUT/bench_fused$F.json ;;
 bench)
     step bench 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
     cat $OUT/bench.json ;;
