@@ -193,7 +193,7 @@ static void launch_xt(const double *in, double *out, int ld, int ny, const XtBox
     case 4: if constexpr (T <= 4) DLESM_XT(4); break;
     case 6: if constexpr (T <= 4) DLESM_XT(6); break;
     case 12: if constexpr (T >= 4) DLESM_XT(12); break;
-    case 16: if constexpr (T >= 4) DLESM_XT(16); break;
+    case 16: if constexpr (T >= 4) DLESM_XT(16); break;    // (24 rows spill: 71-224 VGPRs at T = 6..8)
     default: DLESM_XT(8); break;
     }
 #undef DLESM_XT
