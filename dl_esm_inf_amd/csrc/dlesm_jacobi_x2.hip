@@ -161,6 +161,130 @@ __global__ __launch_bounds__(256) void jacobi5x2_direct(const double *__restrict
     out[(size_t)j * ld + i] = 0.25 * ((T1(i - 1, j) + T1(i + 1, j)) + (T1(i, j - 1) + T1(i, j + 1)));
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same T steps as a PIPELINE marching in y (no vertical redundancy): a wave owns 128 columns
+// and walks up a strip of rows; level s = 1..T keeps only its three newest rows in registers, and
+// every new input row pushes one new row through all T levels -- level s computes row j-s from
+// the rows j-s-1, j-s, j-s+1 of level s-1 -- so that row j-T of the result leaves the pipeline.
+// Work per cell and step is one stencil evaluation (the tile kernel above evaluates (R+2T)/R of
+// them); the price is the 2T-row run-in of every strip and long-lived waves.
+//
+// Only for the part of the box where nothing is ever "carried": every column of the wave and
+// every row it touches lies inside the last stage box, so there are no selects and no masks; the
+// rim of the box is left to jacobi5xt_tile (launch_xt_region below).  Input rows are prefetched
+// P-3 rows ahead through a ring of P registers rows; all register arrays are indexed statically
+// (the row loop is unrolled P times, P a multiple of 3).
+// ---------------------------------------------------------------------------------------------
+template <bool DPP>
+__device__ __forceinline__ xt_d2 xt_row(const xt_d2 &south, const xt_d2 &mid, const xt_d2 &north, double q)
+{
+    const double west = from_lower<DPP>(mid.y), east = from_upper<DPP>(mid.x);
+    xt_d2 r;
+    r.x = q * ((west + mid.y) + (south.x + north.x));
+    r.y = q * ((mid.x + east) + (south.y + north.y));
+    return r;
+}
+
+template <int T, int P, bool DPP>
+__global__ __launch_bounds__(256) void jacobi5xt_march(const double *__restrict__ in, double *__restrict__ out,
+                                                      int ld, int cb, int ntx, int S, int Y0, int Y1, double q)
+{
+    typedef xt_d2 d2;
+    static_assert(P % 3 == 0 && P >= 6, "ring size");
+    constexpr int H = (T + 1) / 2, OL = 64 - 2 * H, D = P - 3;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = blockIdx.x * (blockDim.x >> 6) + wv;
+    const int xw = __builtin_amdgcn_readfirstlane(w % ntx), strip = __builtin_amdgcn_readfirstlane(w / ntx);
+    const int Jb = Y0 + strip * S;
+    if (Jb > Y1) return;
+    const int Je = Jb + S - 1 < Y1 ? Jb + S - 1 : Y1;
+    const unsigned lane_off = (unsigned)(cb + xw * OL + lane) * 16u;
+    const bool ol = lane >= H && lane <= 63 - H;
+    const int jfirst = Jb - T, jlast = Je + T;           // input rows of this strip
+    const int nit = jlast - jfirst + 1;
+    auto load_row = [&](int j) {
+        const char *row = (const char *)(in + (size_t)(j < jlast ? j : jlast) * ld);
+        return *(const d2 *)(row + lane_off);
+    };
+    d2 Q[P], W[T > 1 ? T : 2][3];
+#pragma unroll
+    for (int i = 0; i < P; i++) Q[i] = d2{0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < (T > 1 ? T : 2); s++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) W[s][i] = d2{0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < D; i++) Q[i] = load_row(jfirst + i);
+    for (int k0 = 0; k0 < nit; k0 += P) {
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const int k = k0 + i;                        // this iteration's input row is jfirst + k
+            Q[(i + D) % P] = load_row(jfirst + k + D);   // overwrites row k-3, which is dead
+            d2 nw = xt_row<DPP>(Q[(i + P - 2) % P], Q[(i + P - 1) % P], Q[i], q);
+#pragma unroll
+            for (int s = 2; s <= T; s++) {
+                W[s - 1][i % 3] = nw;                    // level s-1 gets its row j-(s-1), the oldest goes
+                nw = xt_row<DPP>(W[s - 1][(i + 1) % 3], W[s - 1][(i + 2) % 3], W[s - 1][i % 3], q);
+            }
+            const int jo = jfirst + k - T;               // the row that leaves the pipeline
+            if (jo >= Jb && jo <= Je && ol)
+                *(d2 *)((char *)(out + (size_t)jo * ld) + lane_off) = nw;
+        }
+    }
+}
+
+template <int T, bool DPP>
+static void launch_xt(const double *in, double *out, int ld, int ny, const XtBoxes &b, int R, hipStream_t s);
+
+// The box as marching interior + four rim bands of tile launches.  Returns false when the box has
+// no room for the marching kernel (then nothing has been launched).
+template <int T, bool DPP>
+static bool launch_xt_region(const double *in, double *out, int ld, int ny, const XtBoxes &b, int R,
+                             hipStream_t s)
+{
+    constexpr int H = (T + 1) / 2, OL = 64 - 2 * H;
+    if (b.ex1 < b.ex0 || b.ey1 < b.ey0) return false;
+    // rows: every level's rows of a strip inside the last stage box
+    const int my0 = std::max(b.y0, b.ey0 + T - 1), my1 = std::min(b.y1, b.ey1 - (T - 1));
+    // columns: lane 0 of the first tile; all 128 columns of a tile inside the last stage box, output
+    // lanes inside the output box
+    const int c0 = std::max((b.ex0 + 1) / 2, (b.x0 + 1) / 2 - H);
+    const int c_max = std::min((b.ex1 - 1) / 2 - 63, (b.x1 - 1) / 2 - 63 + H);   // last admissible lane-0 chunk
+    if (my1 - my0 + 1 < 4 * T || c_max < c0) return false;
+    const int ntx = (c_max - c0) / OL + 1;
+    const int mx0 = 2 * (c0 + H), mx1 = 2 * (c0 + (ntx - 1) * OL + 63 - H) + 1;   // columns the march writes
+    if (ntx < 8) return false;
+    // strips: one per resident wave slot, so that all waves march side by side for the whole launch
+    const int slots = tuning("j5xt_march_slots", 3072);
+    int nstrips = slots / ntx;
+    if (nstrips < 1) nstrips = 1;
+    int S = (my1 - my0 + nstrips) / nstrips;
+    if (S < 8 * T) S = 8 * T;                            // run-in of 2T rows per strip: at most 25 %
+    nstrips = (my1 - my0 + S) / S;
+    const long waves = (long)ntx * nstrips;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    const int P = tuning("j5xt_march_ring", 9);
+    if (P == 6)
+        hipLaunchKernelGGL((jacobi5xt_march<T, 6, DPP>), dim3(grid), dim3(256), 0, s, in, out, ld, c0, ntx, S, my0, my1, 0.25);
+    else if (P == 12)
+        hipLaunchKernelGGL((jacobi5xt_march<T, 12, DPP>), dim3(grid), dim3(256), 0, s, in, out, ld, c0, ntx, S, my0, my1, 0.25);
+    else
+        hipLaunchKernelGGL((jacobi5xt_march<T, 9, DPP>), dim3(grid), dim3(256), 0, s, in, out, ld, c0, ntx, S, my0, my1, 0.25);
+    // the rim: south and north bands over the full width, west and east bands beside the march
+    auto band = [&](int x0, int x1, int y0, int y1) {
+        if (x1 < x0 || y1 < y0) return;
+        XtBoxes t = b;
+        t.x0 = x0; t.x1 = x1; t.y0 = y0; t.y1 = y1;
+        launch_xt<T, DPP>(in, out, ld, ny, t, R, s);
+    };
+    band(b.x0, b.x1, b.y0, my0 - 1);
+    band(b.x0, b.x1, my1 + 1, b.y1);
+    band(b.x0, mx0 - 1, my0, my1);
+    band(mx1 + 1, b.x1, my0, my1);
+    return true;
+}
+
 template <int T, bool DPP>
 static void launch_xt(const double *in, double *out, int ld, int ny, const XtBoxes &b, int R, hipStream_t s)
 {
@@ -240,10 +364,16 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
     }
     const int R = tuning("j5xt_rows", 0);
     const bool dpp = tuning("j5xt_dpp", 1);
-#define DLESM_T(TT)                                                             \
-    do {                                                                        \
-        if (dpp) launch_xt<TT, true>(in, out, ld, ny, b, R, s);                 \
-        else launch_xt<TT, false>(in, out, ld, ny, b, R, s);                    \
+    const bool march = tuning("j5xt_march", 0);
+#define DLESM_T(TT)                                                                             \
+    do {                                                                                        \
+        if (dpp) {                                                                              \
+            if (!(march && launch_xt_region<TT, true>(in, out, ld, ny, b, R, s)))               \
+                launch_xt<TT, true>(in, out, ld, ny, b, R, s);                                  \
+        } else {                                                                                \
+            if (!(march && launch_xt_region<TT, false>(in, out, ld, ny, b, R, s)))              \
+                launch_xt<TT, false>(in, out, ld, ny, b, R, s);                                 \
+        }                                                                                       \
     } while (0)
     switch (nsteps) {
     case 1: DLESM_T(1); break;

@@ -58,8 +58,13 @@ CASES = [(1, 1, None), (2, 3, 2), (4, 10, None), (10, 4, 8), (5, 5, 8), (64, 64,
 STEPS = [2, 3, 4, 5, 6, 7, 8]
 TUNES = [dict(), dict(j5xt_rows=12), dict(j5xt_rows=16, j5xt_dpp=0), dict(j5xt_rows=2, j5xt_dpp=0), dict(j5xt_rows=8, j5_tpb=8), dict(j5xt_rows=4, j5_tpb=2, j5xt_dpp=0),
          dict(j5xt_order=1), dict(j5xt_order=1, j5xt_rows=4, j5_tpb=8), dict(j5xt_order=1, j5xt_rows=2, j5_tpb=2),
+         dict(j5xt_march=1), dict(j5xt_march=1, j5xt_march_ring=6, j5xt_dpp=0),
+         dict(j5xt_march=1, j5xt_march_ring=12, j5xt_march_slots=40), dict(j5xt_march=1, j5xt_march_slots=100000),
          dict(j5_variant=4)]
-DEFAULTS = dict(j5xt_rows=0, j5xt_dpp=1, j5xt_order=0, j5_tpb=0, j5_variant=0)
+DEFAULTS = dict(j5xt_rows=0, j5xt_dpp=1, j5xt_order=0, j5_tpb=0, j5_variant=0, j5xt_march=0, j5xt_march_ring=9,
+                j5xt_march_slots=3072)
+# wide and tall enough for the marching kernel to take the interior (8 wave tiles, 4T rows)
+CASES += [(1100, 90, 64), (1100, 90, None), (2047, 150, 2), (5000, 64, 64)]
 
 
 def _tune(D, kw):
@@ -97,12 +102,12 @@ def test_fused_sub_boxes_and_grown_stage_boxes(D, nsteps):
     boxes grown towards some sides (deep halos), empty boxes; refusals"""
     L = D._cabi.lib()
     import torch
-    g = _grid(D, 316, 105, 2)           # 320 x 108 array; cells 9..308 x 9..98 play the tile interior
+    g = _grid(D, 1216, 105, 2)          # 1220 x 108 array; cells 9..1208 x 9..98 play the tile interior
     a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
     D.psy.hash_init(a, SEED, box=D._cabi.Region(0, 0, 1, g.nx, 1, g.ny))
     hin = a.get_data()
-    assert g.nx >= 317 and g.ny >= 107
-    x0, x1, y0, y1 = full = (9, 308, 9, 98)
+    assert g.nx >= 1217 and g.ny >= 107
+    x0, x1, y0, y1 = full = (9, 1208, 9, 98)
     allg = (x0 - 1, x1 + 1, y0 - 1, y1 + 1)   # last stage box of a tile with neighbours on every side
     T = nsteps
     cases = [
@@ -114,13 +119,16 @@ def test_fused_sub_boxes_and_grown_stage_boxes(D, nsteps):
         ((40, 39, y0, y1), full, (0, 0, 0, 0)), (full, (10, 9, y0, y1), (0, 0, 0, 0)), ((x0, x1, 50, 49), full, (1, 1, 1, 1)),
     ]
     for box, ebox, grow in cases:
-        D.set_field(b, -7.0)
-        D._cabi.check(L.dlesm_stencil5_multi_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, nsteps, *box, *ebox, *grow,
-                                                 None))
-        torch.cuda.synchronize()
         want = _oracle_multi(hin, g.nx, nsteps, box, ebox, grow)
-        got = b.get_data()
-        assert np.array_equal(got, want), (box, ebox, grow, np.argwhere(got != want)[:5])
+        for march in (0, 1):            # tile kernel everywhere / marching kernel in the interior
+            _tune(D, dict(j5xt_march=march, j5xt_march_slots=64))
+            D.set_field(b, -7.0)
+            D._cabi.check(L.dlesm_stencil5_multi_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, nsteps, *box, *ebox,
+                                                     *grow, None))
+            torch.cuda.synchronize()
+            got = b.get_data()
+            _tune(D, DEFAULTS)
+            assert np.array_equal(got, want), (box, ebox, grow, march, np.argwhere(got != want)[:5])
     # boxes whose stencil ring leaves the array are refused, so are aliased arrays and bad step counts
     k = nsteps - 2
     bad = [((1, 10, y0, 10), full, (0, 0, 0, 0)), (full, (k + 1, x1 + 1, y0 - 1, y1 + 1), (1, 1, 1, 1)),
@@ -161,10 +169,12 @@ def test_fused_equals_single_steps_full_size(D, n, alignment):
         D.copy_field(a, f)              # same fixed ring everywhere
     src, dst = a, p
     for nsteps in (1, 2, 3, 4, 5, 6, 7, 8):
-        if nsteps > 1:
-            D.psy.invoke_jacobi5_multi(c, a, nsteps)
         D.psy.invoke_jacobi5(dst, src)  # dst = J^nsteps(a)
-        torch.cuda.synchronize()
-        if nsteps > 1:
-            assert torch.equal(dst.data, c.data), nsteps
+        for march in (0, 1):
+            if nsteps > 1:
+                _tune(D, dict(j5xt_march=march))
+                D.psy.invoke_jacobi5_multi(c, a, nsteps)
+                torch.cuda.synchronize()
+                _tune(D, DEFAULTS)
+                assert torch.equal(dst.data, c.data), (nsteps, march)
         src, dst = dst, (q if dst is p else p)
