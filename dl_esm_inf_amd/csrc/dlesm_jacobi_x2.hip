@@ -264,9 +264,9 @@ static bool launch_xt_region(const double *in, double *out, int ld, int ny, cons
     nstrips = (my1 - my0 + S) / S;
     const long waves = (long)ntx * nstrips;
     const unsigned grid = (unsigned)((waves + 3) / 4);
-    // (scattering the tiles over the workgroups by a multiplicative permutation changes nothing:
-    // 0.843-0.847 ms for eight multipliers at T = 1, so the limit is not an L2-channel hot spot)
-    const int perm = 1;
+    // experiment: tile number -> column position through a multiplicative permutation (1 = identity)
+    int perm = tuning("j5xt_march_perm", 1);
+    if (perm < 1 || std::__gcd(perm, ntx) != 1) perm = 1;
     const int P = tuning("j5xt_march_ring", 9);
     if (P == 6)
         hipLaunchKernelGGL((jacobi5xt_march<T, 6, DPP>), dim3(grid), dim3(256), 0, s, in, out, ld, c0, ntx, S, my0, my1, 0.25, perm);
@@ -338,7 +338,7 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
     if (xstop < xstart || ystop < ystart) return DLESM_OK; // empty box: a zero-trip loop nest
     if (int rc = check_box("fused Jacobi steps", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     DLESM_REQUIRE(in != nullptr && out != nullptr && in != out, "fused Jacobi steps: null or aliased arrays");
-    const bool empty_e = nsteps == 1 || exstop < exstart || eystop < eystart;
+    const bool empty_e = exstop < exstart || eystop < eystart;
     const int g = nsteps > 2 ? nsteps - 2 : 0;           // growth of the first intermediate box
     if (!empty_e)
         if (int rc = check_box("fused Jacobi steps (first intermediate box)", ld, ny, exstart - gw * g,

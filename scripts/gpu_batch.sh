@@ -115,6 +115,14 @@ pmcmulti)   # one counter per pass, default bench (single-step kernel + the fuse
     done
     python scripts/pmc_table.py $OUT/pmcmulti jacobi5_tile jacobi5xt_tile > $OUT/pmcmulti_table.txt 2>&1
     cat $OUT/pmcmulti_table.txt ;;
+pmccmp)     # counters of the linear-sweep tile kernel against the column-marching pipeline kernel, one step each
+    rm -rf $OUT/pmccmp
+    for cnt in ${PMC_LIST:-TCP_PENDING_STALL_CYCLES_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum TCC_EA0_WRREQ_STALL_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum MemUnitStalled TA_BUSY_avr TCC_BUSY_avr}; do
+        step a_$cnt 200 rocprofv3 --pmc $cnt --output-format csv -d $OUT/pmccmp/tile/$cnt -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-temporal-blocking > $OUT/pmccmp_a.log 2>&1
+        step b_$cnt 200 rocprofv3 --pmc $cnt --output-format csv -d $OUT/pmccmp/march/$cnt -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-temporal-blocking --tune j5_kernel=3 --tune j5xt_march=1 > $OUT/pmccmp_b.log 2>&1
+    done
+    python scripts/pmc_table.py $OUT/pmccmp jacobi5_tile jacobi5xt_march > $OUT/pmccmp_table.txt 2>&1
+    cat $OUT/pmccmp_table.txt ;;
 counters)
     step counters 120 rocprofv3 -L > $OUT/counters.txt 2>&1
     grep -c . $OUT/counters.txt ;;
