@@ -45,19 +45,27 @@ program jacobi_app
   use dlesm_psy_mod
   implicit none
   character(len=32) :: arg
-  integer :: n, nsteps, i, p, q, nr
+  integer :: n, nsteps, i, p, q, nr, fuse, ncalls
   integer(8) :: t0, t1, rate
   type(grid_type), target :: model_grid
   type(r2d_field), target :: a, b
   real(go_wp) :: cs, secs
 
-  n = 4096;  nsteps = 100
+  ! jacobi_app [n [nsteps [fuse]]]: tile n x n per rank, nsteps time steps, `fuse` (1..8) of them
+  ! advanced per sweep (temporal blocking; one depth-`fuse` halo exchange per sweep)
+  n = 4096;  nsteps = 100;  fuse = 1
   if (command_argument_count() >= 1) then
      call get_command_argument(1, arg);  read(arg, *) n
   end if
   if (command_argument_count() >= 2) then
      call get_command_argument(2, arg);  read(arg, *) nsteps
   end if
+  if (command_argument_count() >= 3) then
+     call get_command_argument(3, arg);  read(arg, *) fuse
+  end if
+  if (fuse < 1 .or. fuse > 8) stop 'jacobi_app: fuse must be 1..8'
+  nsteps = (nsteps / fuse) * fuse
+  ncalls = nsteps / fuse
 
   call gocean_initialise()
   nr = get_num_ranks()
@@ -68,7 +76,7 @@ program jacobi_app
   q = nr / p
 
   model_grid = grid_type(GO_ARAKAWA_C, (/GO_BC_EXTERNAL, GO_BC_EXTERNAL, GO_BC_NONE/), GO_OFFSET_NE)
-  call model_grid%decompose(n * p, n * q)
+  call model_grid%decompose(n * p, n * q, halo_width=fuse)
   call grid_init(model_grid, 1.0_go_wp, 1.0_go_wp)
   a = r2d_field(model_grid, GO_T_POINTS)
   b = r2d_field(model_grid, GO_T_POINTS)
@@ -81,18 +89,26 @@ program jacobi_app
 
   call device_sync()
   call system_clock(t0, rate)
-  do i = 1, nsteps
-     if (mod(i, 2) == 1) then
-        call invoke_jacobi5_dm(b, a)      ! exchange of the result hidden behind the interior
+  do i = 1, ncalls
+     if (fuse == 1) then
+        if (mod(i, 2) == 1) then
+           call invoke_jacobi5_dm(b, a)   ! exchange of the result hidden behind the interior
+        else
+           call invoke_jacobi5_dm(a, b)
+        end if
      else
-        call invoke_jacobi5_dm(a, b)
+        if (mod(i, 2) == 1) then
+           call invoke_jacobi5_multi(b, a, fuse)
+        else
+           call invoke_jacobi5_multi(a, b, fuse)
+        end if
      end if
   end do
   call device_sync()
   call system_clock(t1)
   secs = real(t1 - t0, go_wp) / real(rate, go_wp)
 
-  if (mod(nsteps, 2) == 1) then
+  if (mod(ncalls, 2) == 1) then
      cs = field_checksum(b)
   else
      cs = field_checksum(a)
