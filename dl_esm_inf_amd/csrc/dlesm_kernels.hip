@@ -469,6 +469,8 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
         const long tiles = (long)nxw * (band_rows / R);  // per band
         grid = (unsigned)(((tiles + tpb - 1) / tpb) * nbands);
     }
+    // (capping the resident waves with unused LDS -- 32 down to 16 waves per CU -- changes nothing
+    // until 16, where it costs 2 %: the band of rows in flight is not a lever)
 #define DLESM_TILE(RR)                                                                               \
     hipLaunchKernelGGL((jacobi5_tile<VEC, RR, NT>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, x0, x1, \
                        y0, y1, c_first, nxw, nbands, band_rows, gs, flags)
