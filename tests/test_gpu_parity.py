@@ -112,6 +112,47 @@ def test_jacobi5_bit_exact(D, nx, ny, alignment, tune):
         _set_tuning(D, **DEFAULT_TUNING)
 
 
+@pytest.mark.parametrize("nsteps", [1, 2, 4, 8])
+def test_jacobi5_special_values_follow_ieee_like_the_cpu(D, nsteps):
+    """subnormals (not flushed), signed zeros, overflow to infinity and NaN propagate exactly as in
+    the CPU loops: bit-identical wherever the result is not a NaN, NaN where the oracle has a NaN"""
+    g = _grid(D, 200, 50, 8)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    rng = np.random.default_rng(7)
+    h = rng.random((g.ny, g.nx))
+    h[2:28, 150:199] = rng.random((26, 49)) * 1e-310        # subnormals: sums and quarters of them
+    h[14:18, 10:40] = -0.0
+    h[14:18, 40:70] = 0.0
+    h[20:24, 5:90] = 1.7e308                                 # (a+b) overflows
+    h[20:24, 100:150] = -1.7e308
+    h[30, 20] = np.inf
+    h[30, 80] = -np.inf
+    h[31, 50] = np.nan
+    h[40:44, 60:120] = np.ldexp(rng.random((4, 60)), -1070)  # results cross the subnormal boundary
+    a.set_data(h)
+    b.set_data(h)                                            # same ring in both buffers
+    it = b.internal
+    want = h.copy()
+    cur = h
+    with np.errstate(all="ignore"):
+        for _ in range(nsteps):
+            nxt = cur.copy()
+            O.jacobi5(cur, nxt, g.nx, it.xstart, it.xstop, it.ystart, it.ystop)
+            cur = nxt
+        want = cur
+    if nsteps == 1:
+        D.psy.invoke_jacobi5(b, a)
+    else:
+        D.psy.invoke_jacobi5_multi(b, a, nsteps)
+    got = b.get_data()
+    nan_w, nan_g = np.isnan(want), np.isnan(got)
+    assert np.array_equal(nan_w, nan_g)
+    assert np.array_equal(got[~nan_w].view(np.uint64), want[~nan_w].view(np.uint64))
+    assert np.count_nonzero(nan_w) > 0 and np.count_nonzero(np.isinf(want)) > 0
+    sub = (np.abs(want) > 0) & (np.abs(want) < 2.3e-308)
+    assert np.count_nonzero(sub) > 100                       # subnormal results really occur
+
+
 def test_jacobi5_sub_boxes_and_empty(D):
     """arbitrary PSy boxes (what the frame/interior split uses), incl. zero-trip loops"""
     g = _grid(D, 300, 90, 64)
