@@ -75,13 +75,33 @@ def cpu_baseline(host_in, ld, box, budget_s):
             if dt > budget_s * share or sweeps >= 2000:
                 break
         res[label] = (cells * sweeps / dt / 1e6, sweeps, dt)
-    return {
+    out_d = {
         "value": round(res["all"][0], 1), "unit": "Mcells/s", "cores": threads, "kind": "port",
         "single_core_value": round(res["one"][0], 1),
         "sample": f"oracle orc_jacobi5 (C, gcc -O3, GOcean kernel form) on the same "
                   f"{xe - xs + 1}x{ye - ys + 1} tile: {res['all'][1]} sweeps in {res['all'][2]:.1f}s "
                   f"with {threads} OpenMP threads, {res['one'][1]} sweeps in {res['one'][2]:.1f}s on 1 core",
     }
+    # the same step the way a GOcean application runs it on the CPU: Fortran pointwise kernel called from
+    # the PSy loop nest, OpenMP over jj (oracle/cpu_psy_loops.f90, amdflang -O3); a quarter of the budget
+    try:
+        src, out = np.empty_like(host_in), np.empty_like(host_in)
+        O.lib().orc_copy_rows_omp(src, host_in, ld, host_in.shape[0], threads)
+        O.lib().orc_copy_rows_omp(out, host_in, ld, host_in.shape[0], threads)
+        O.jacobi5_fortran(src, out, ld, xs, xe, ys, ye, threads=threads)
+        t0, sweeps = time.perf_counter(), 0
+        while True:
+            O.jacobi5_fortran(src, out, ld, xs, xe, ys, ye, threads=threads)
+            sweeps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s * 0.25 or sweeps >= 2000:
+                break
+        out_d["fortran_psy_loops_value"] = round(cells * sweeps / dt / 1e6, 1)
+        out_d["sample"] += f"; Fortran PSy loops (amdflang -O3, {threads} threads): {sweeps} sweeps in {dt:.1f}s"
+    except Exception as e:                                # noqa: BLE001  (a missing Fortran runtime must not cost the line)
+        out_d["fortran_psy_loops_value"] = None
+        out_d["fortran_psy_loops_error"] = f"{type(e).__name__}: {e}"
+    return out_d
 
 
 XT_ROWS = {2: 4, 3: 6, 4: 8, 5: 8, 6: 12, 7: 16, 8: 16}      # rows per wave tile the library picks per T

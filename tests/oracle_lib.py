@@ -181,6 +181,27 @@ def host_threads():
     return max(1, n)
 
 
+_flib = None
+
+
+def fortran_psy_lib():
+    """oracle/libcpu_psy_fortran.so: the Jacobi step as Fortran kernel + PSy loop nest (amdflang)"""
+    global _flib
+    if _flib is None:
+        so = os.path.join(ORACLE_DIR, "libcpu_psy_fortran.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "libcpu_psy_fortran.so"], stdout=subprocess.DEVNULL)
+        _flib = C.CDLL(so)
+        _flib.psy_jacobi5_f.argtypes = [_dp, _dp] + [C.c_int] * 7
+        _flib.psy_jacobi5_f.restype = None
+    return _flib
+
+
+def jacobi5_fortran(inp, out, ld, xs, xe, ys, ye, threads=1):
+    """same update through the Fortran PSy loops (arrays are (ny, ld) C-order = (ld, ny) Fortran)"""
+    fortran_psy_lib().psy_jacobi5_f(inp, out, ld, inp.shape[0], xs, xe, ys, ye, threads)
+
+
 def jacobi5(inp, out, ld, xs, xe, ys, ye, threads=1):
     if threads > 1:
         lib().orc_jacobi5_omp(inp, out, ld, xs, xe, ys, ye, threads)

@@ -36,6 +36,7 @@ def test_bench_line_and_secondary_legs():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["unit"] == "Mcells/s" and d["dtype"] == "f64"
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["cpu_baseline"]["fortran_psy_loops_value"] > 0, d["cpu_baseline"]
     tb = d["temporal_blocking"]
     assert tb["fused_steps"] == 8 and tb["bit_identical_to_single_steps"] is True and tb["value"] > 0
     f = _bench("--fused", "4", "--no-cpu-baseline")

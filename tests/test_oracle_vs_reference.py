@@ -205,3 +205,18 @@ def test_jacobi5_against_numpy():
     out2 = np.full_like(a, -7.0)
     O.jacobi5(a, out2, ld, 2, n + 1, 2, n + 1, threads=3)
     assert np.array_equal(out2[1:n + 1, 1:n + 1], want)
+
+
+def test_fortran_psy_loops_equal_the_c_oracle():
+    """the same step written the way a GOcean application runs it on the CPU -- Fortran pointwise
+    kernel called from the PSy loop nest, with and without OpenMP over jj -- is bit-identical"""
+    rng = np.random.default_rng(3)
+    for ny, ld, box in [(40, 44, (2, 38, 2, 37)), (9, 200, (2, 199, 2, 8)), (130, 17, (3, 9, 5, 120)),
+                        (5, 5, (3, 3, 3, 3))]:
+        a = rng.random((ny, ld))
+        want = np.full_like(a, -7.0)
+        O.jacobi5(a, want, ld, *box)
+        for threads in (1, 4):
+            got = np.full_like(a, -7.0)
+            O.jacobi5_fortran(a, got, ld, *box, threads=threads)
+            assert np.array_equal(got, want), (ny, ld, box, threads)
