@@ -207,6 +207,25 @@ def test_map_comms_depth_1_is_the_reference_table_plus_ring_cells(nx, ny, nranks
             assert a["ides"] - b["ides"] in (0, 1) and a["jdes"] - b["jdes"] in (0, 1)
 
 
+@pytest.mark.parametrize("nx,ny,nranks,depth", [(16, 32, 8, None), (10, 10, 6, None), (64, 64, 16, None),
+                                                (32, 64, 8, 4), (40, 30, 12, 2), (64, 64, 16, 8)])
+def test_untagged_message_order_matches_between_every_pair_of_ranks(nx, ny, nranks, depth):
+    """RCCL has no tags: between a pair of ranks the k-th send must be the k-th receive.  The plan
+    issues sends ordered by (peer, direction code) and receives likewise (dlesm_halo.hip); replay
+    that rule on the tables of every rank and compare position by position"""
+    d = D.go_decompose(nx, ny, ndomains=nranks, halo_width=depth or 1)
+    T = [D.map_comms(d, rank1=r + 1, nranks=nranks, depth=depth) for r in range(nranks)]
+    for a in range(nranks):
+        for b in range(nranks):
+            if a == b:
+                continue
+            sends = [(m["dir"], m["nx"] * m["ny"]) for m in sorted(T[a].sends(), key=lambda m: (m["dest"], m["dir"]))
+                     if m["dest"] == b]
+            recvs = [(m["dir"], m["nx"] * m["ny"]) for m in sorted(T[b].recvs(), key=lambda m: (m["src"], m["dir"]))
+                     if m["src"] == a]
+            assert sends == recvs, (a, b, sends, recvs)
+
+
 def test_map_comms_depth_needs_room():
     t = _cabi.CommTables()
     d = D.go_decompose(40, 40, ndomains=4, halo_width=2)
