@@ -41,6 +41,7 @@ def parse():
                     help="1 GPU only: advance this many time steps per launch (2..8, temporal blocking); "
                          "the headline run keeps 1 = one sweep per time step")
     ap.add_argument("--no-temporal-blocking", action="store_true", help="skip the secondary fused-steps figure")
+    ap.add_argument("--no-shallow", action="store_true", help="skip the secondary shallow-water figure")
     ap.add_argument("--force-dm-leg", action="store_true",
                     help="rehearsal on 1 GPU: run the N>1 secondary leg with a 1-rank process group")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
@@ -143,6 +144,45 @@ def temporal_blocking(D, torch, grid, a, stream, steps, tile, T=TB_STEPS):
             "hbm_gbs": round(BYTES_PER_CELL * cells / (ms * 1e-3) / 1e9, 1),
             "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells,
             "bit_identical_to_single_steps": same, "kernel": f"jacobi5xt_tile<{T},{XT_ROWS[T]},dpp>"}
+
+
+def shallow_water(D, torch, stream, alignment, tile=8192, steps=40):
+    """Secondary figure (never `value`): BASELINE configs[3], the fused shallow-water u/v/h step
+    (9-point composite footprint, 72 B/cell algorithmic) on a tile x tile C-grid, leapfrog rotation
+    of the three time levels between steps."""
+    os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
+    g.decompose(tile, tile)
+    D.grid_init(g, 1.0, 1.0)
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    F = {}
+    with torch.cuda.stream(stream):
+        for k, name in enumerate(["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]):
+            F[name] = D.r2d_field(g, pts[name[0]])
+            D.psy.hash_init(F[name], SEED + k, stream=stream)
+            F[name].data.add_(1.0 if name[0] == "p" else -0.5)     # p in [1,2), u, v in [-0.5,0.5)
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
+    cur, old, new = [F["u"], F["v"], F["p"]], [F["uold"], F["vold"], F["pold"]], [F["unew"], F["vnew"], F["pnew"]]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            D.psy.invoke_shallow_step(prm, *cur, *old, *new, stream=stream)
+            old, cur, new = cur, new, old
+        e0.record(stream)
+        for _ in range(steps):
+            D.psy.invoke_shallow_step(prm, *cur, *old, *new, stream=stream)
+            old, cur, new = cur, new, old
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    cells, bpc = tile * tile, 72
+    gbs = bpc * cells / (ms * 1e-3) / 1e9
+    return {"workload": f"shallow-water u/v/h fused step {tile}x{tile} fp64 (BASELINE configs[3])", "steps": steps,
+            "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_cell": bpc,
+                         "kernel": "shallow_tile<2,dpp>"},
+            "checksum_pnew": D.field_checksum(cur[2])}
 
 
 def temporal_blocking_dm(D, torch, dist, tile, P, Q, stream, steps, T=TB_STEPS):
@@ -371,6 +411,12 @@ def main():
                 print(json.dumps(out), flush=True)
             os._exit(0)                                   # the other ranks may be stuck in a collective
         dog.cancel()
+    if world == 1 and not args.no_shallow and fused == 1 and not args.force_dm_leg:
+        try:
+            out["shallow_water"] = shallow_water(D, torch, stream, args.alignment,
+                                                 tile=min(8192, args.tile), steps=max(8, min(40, args.steps)))
+        except Exception as e:                            # noqa: BLE001  (never at the cost of the headline line)
+            out["shallow_water"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         host = a.get_data()
         out["cpu_baseline"] = cpu_baseline(host, grid.nx, it.box(), args.cpu_seconds)

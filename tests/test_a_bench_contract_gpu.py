@@ -37,6 +37,8 @@ def test_bench_line_and_secondary_legs():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["cpu_baseline"]["fortran_psy_loops_value"] > 0, d["cpu_baseline"]
+    sw = d["shallow_water"]
+    assert "error" not in sw and sw["value"] > 0 and sw["roofline"]["algorithmic_bytes_per_cell"] == 72, sw
     tb = d["temporal_blocking"]
     assert tb["fused_steps"] == 8 and tb["bit_identical_to_single_steps"] is True and tb["value"] > 0
     f = _bench("--fused", "4", "--no-cpu-baseline")
