@@ -301,53 +301,6 @@ __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ 
     }
 }
 
-// Variant of jacobi5_tile without the two scattered edge loads: a wave loads 64 lanes but only
-// lanes 1..62 produce output, lanes 0 and 63 are halo lanes feeding their neighbours by shuffle
-// (the layout the shallow-water kernel uses).  16-byte lanes only.  `cb` = first output chunk.
-template <int R>
-__global__ __launch_bounds__(1024) void jacobi5_tile62(const double *__restrict__ in,
-                                                      double *__restrict__ out, int ld, int x0, int x1,
-                                                      int y0, int y1, int cb, int nxw)
-{
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int xw = w % nxw;
-    const int jb = y0 + (w / nxw) * R;
-    if (jb > y1) return;
-    int je = jb + R - 1;
-    if (je > y1) je = y1;
-    const int c = cb + xw * 62 - 1 + lane;
-    if (c - lane + 1 > x1 / 2) return;                  // idle padding tile
-    const int c_ld = ld / 2 - 1;
-    const int cl = c < 0 ? 0 : (c > c_ld ? c_ld : c);
-    const bool ol = lane >= 1 && lane <= 62 && c <= c_ld;
-    const bool m0 = ol && 2 * c >= x0 && 2 * c <= x1;
-    const bool m1 = ol && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
-    const double *pin = in + (size_t)cl * 2;
-    d2 r[R + 2];
-#pragma unroll
-    for (int u = 0; u < R + 2; u++) {
-        int jj = jb - 1 + u;
-        if (jj > je + 1) jj = je + 1;
-        r[u] = *(const d2 *)(pin + (size_t)jj * ld);
-    }
-#pragma unroll
-    for (int u = 0; u < R; u++) {
-        if (jb + u <= je) {
-            const double west = __shfl_up(r[u + 1].y, 1), east = __shfl_down(r[u + 1].x, 1);
-            const double o0 = 0.25 * ((west + r[u + 1].y) + (r[u].x + r[u + 2].x));
-            const double o1 = 0.25 * ((r[u + 1].x + east) + (r[u].y + r[u + 2].y));
-            double *po = out + (size_t)(jb + u) * ld + (size_t)c * 2;
-            if (m0 && m1) *(d2 *)po = d2{o0, o1};
-            else {
-                if (m0) po[0] = o0;
-                if (m1) po[1] = o1;
-            }
-        }
-    }
-}
-
 // LDS-staged form (j5_kernel = 2, the comparison point for "stage the tile and its halo ring in
 // LDS"): a workgroup of 64*T lanes stages rows jb-1..je+1 of a 128*T-column tile, plus the two
 // ring columns, in LDS (row pitch 2*blockDim+4 doubles, interior chunks 16-byte aligned at
@@ -595,17 +548,6 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
         int R = tuning("j5_tile_rows", 0);
         if (R < 1) R = vec2 ? 2 : 4;
         const int nb = tuning("j5_bands", 1), gs = tuning("j5_group", 0);
-        if ((variant & 32) && vec2) {      // halo-lane variant (no edge loads), R = 2 or 3
-            const int cb = x0 / 2, c_last = x1 / 2;
-            int nxw = (c_last - cb + 62) / 62, tpb = 4;
-            choose_block_shape(&nxw, &tpb);
-            const int RR = R == 3 ? 3 : 2, strips = (y1 - y0 + RR) / RR;
-            const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
-            if (RR == 3) hipLaunchKernelGGL(jacobi5_tile62<3>, dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, x0, x1, y0, y1, cb, nxw);
-            else hipLaunchKernelGGL(jacobi5_tile62<2>, dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, x0, x1, y0, y1, cb, nxw);
-            DLESM_HIP_TRY(hipGetLastError());
-            return DLESM_OK;
-        }
         if (vec2) { if (nt) launch_tile<2, true>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s);
                     else launch_tile<2, false>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s); }
         else { if (nt) launch_tile<1, true>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s);

@@ -78,7 +78,6 @@ TUNINGS = [
     dict(j5_kernel=0, j5_tpb=2), dict(j5_kernel=0, j5_tpb=8, j5_tile_rows=3), dict(j5_kernel=0, j5_tpb=16, j5_pad_tiles=3),
     dict(j5_kernel=0, j5_skew=0, j5_tpb=4, j5_tile_rows=2),
     dict(j5_kernel=0, j5_variant=16), dict(j5_kernel=0, j5_variant=16, j5_tile_rows=3), dict(j5_kernel=1, j5_variant=16),
-    dict(j5_kernel=0, j5_variant=32), dict(j5_kernel=0, j5_variant=32, j5_tile_rows=3, j5_tpb=4),
     dict(j5_kernel=0, j5_tile_rows=1, j5_bands=3), dict(j5_kernel=0, j5_tile_rows=2, j5_bands=1),
     dict(j5_kernel=0, j5_tile_rows=4, j5_bands=8, j5_variant=1), dict(j5_kernel=0, j5_tile_rows=6, j5_bands=5),
     dict(j5_kernel=0, j5_tile_rows=12, j5_bands=2), dict(j5_kernel=0, j5_tile_rows=16, j5_bands=8),
