@@ -201,31 +201,28 @@ __global__ __launch_bounds__(256) void jacobi5_march(const double *__restrict__ 
 }
 
 // ===========================================================================
-// 5-point Jacobi, "XCD band sweep" form (the default).
+// 5-point Jacobi, linear tile sweep (the default).
 //
 // Measured on MI355X (scripts/membench.hip): a read+write stream reaches its best
 // rate, 6.3 TB/s, when the workgroups of a launch sweep memory linearly in
 // dispatch order with short-lived groups; long-lived groups marching far apart
-// (62 fronts across 2 GB) lose 15 %.  So the box is cut into NB horizontal bands,
-// one per XCD (workgroups are dealt round-robin to the 8 XCDs: group b runs on
-// XCD b % 8), and inside its band every XCD walks wave tiles of 64*VEC columns x
-// R rows in row-major order.  Consequences:
-//   * the two halo rows a tile shares with the tile above/below were fetched by
-//     the SAME XCD a few dozen tiles earlier -> served by that XCD's L2, not by
-//     the fabric; the same holds for the single edge column shared with the
-//     left/right tile.  HBM sees each input line once (plus NB-1 band seams);
+// lose 15 %.  So wave tiles of 64*VEC columns x R rows are numbered row-major over
+// the box and a workgroup is blockDim/64 consecutive tiles:
+//   * the chip reads one narrow band of rows and writes another, front to back;
 //   * all R+2 row loads of a tile are issued before the first is consumed
 //     (straight-line code, no loop-carried vmcnt wait), (R+2) KiB in flight/wave;
-//   * waves are independent (no LDS, no barrier): a 256-thread group is just four
-//     consecutive tiles, so a ragged last column costs one partial wave per strip.
-// Placement only affects speed: any other group->XCD assignment gives the same
-// results.
+//   * waves are independent (no LDS, no barrier), so a ragged last column costs one
+//     partial wave per strip;
+//   * the rows a tile shares with the tile below are re-read from L2 when the two
+//     run on the same XCD (workgroups are dealt round-robin to the 8 XCDs) and from
+//     the Infinity Cache otherwise -- choose_block_shape() picks the shape.
+// Per-XCD row bands and an XCD-affine column-major tile order were built, measured
+// (70 %, 69-70 % against 75-78 %; profiles/r01_sweep_tile_group.txt) and removed.
 // ===========================================================================
 template <int VEC, int R, bool NT>
 __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ in,
                                                     double *__restrict__ out, int ld, int x0, int x1,
-                                                    int y0, int y1, int c_first, int nxw, int nbands,
-                                                    int band_rows, int gs, int flags)
+                                                    int y0, int y1, int c_first, int nxw, int flags)
 {
     const int lane = threadIdx.x & 63;
 #if DLESM_J5_SCALAR
@@ -233,31 +230,9 @@ __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ 
 #else
     const int wv = threadIdx.x >> 6;
 #endif
-    int xw, jb, by1;
-    if (gs > 0) {
-        // XCD-aware order.  Strips are taken in groups of gs; a group's tiles, padded to a
-        // whole number of 8-block rounds, are numbered COLUMN-major (slot = xw*gs + s) and
-        // XCD k = blockIdx % 8 receives the k-th eighth of the slots.  A tile's vertical and
-        // horizontal neighbours then sit on the same XCD (and the 4 waves of a block are 4
-        // vertically stacked tiles), so halo rows / edge columns are L1/L2 hits; all 8 XCDs
-        // work on the same gs*R rows at a time, and groups follow each other linearly.
-        const int bpg = band_rows;                       // blocks per group (multiple of 8)
-        const int g = blockIdx.x / bpg, bg = blockIdx.x % bpg;
-        const int slot = ((bg % 8) * (bpg / 8) + bg / 8) * 4 + wv;                   // 256-thread blocks
-        xw = slot / gs;
-        if (xw >= nxw) return;
-        jb = y0 + (g * gs + slot % gs) * R;
-        by1 = y1;
-    } else {
-        const int band = blockIdx.x % nbands;
-        // wave-tile number inside the band; a block is blockDim.x/64 consecutive tiles
-        const int w = (blockIdx.x / nbands) * (blockDim.x >> 6) + wv;
-        xw = w % nxw;
-        const int by0 = y0 + band * band_rows;
-        by1 = by0 + band_rows - 1;
-        if (by1 > y1) by1 = y1;
-        jb = by0 + (w / nxw) * R;
-    }
+    const int w = blockIdx.x * (blockDim.x >> 6) + wv;  // wave-tile number
+    int xw = w % nxw, jb = y0 + (w / nxw) * R;
+    const int by1 = y1;
 #if DLESM_J5_SCALAR
     xw = __builtin_amdgcn_readfirstlane(xw);           // (integer division runs on the VALU)
     jb = __builtin_amdgcn_readfirstlane(jb);
@@ -389,44 +364,27 @@ void choose_block_shape(int *nxw_io, int *tpb_out, int prefer)
 
 template <int VEC, bool NT>
 static void launch_tile(const double *in, double *out, int ld, int x0, int x1, int y0, int y1, int R,
-                        int nbands, int gs, int flags, hipStream_t s)
+                        int flags, hipStream_t s)
 {
     if (R != 1 && R != 2 && R != 3 && R != 4 && R != 6 && R != 12 && R != 16) R = 8;
     // tiles are anchored on a 128-byte line of the row (not on the first interior column), so
     // every wave access covers whole lines whatever the box: lanes left of x0 are masked
     const int c_first = (x0 / VEC) & ~(128 / (8 * VEC) - 1), c_last = x1 / VEC;
     int nxw = (c_last - c_first + 64) / 64;             // wave tiles per row
-    const int h = y1 - y0 + 1;
-    unsigned grid;
-    int band_rows, tpb = 4;                              // tiles (waves) per block
-    if (gs > 0) {
-        const int strips = (h + R - 1) / R, groups = (strips + gs - 1) / gs;
-        const int bpg = ((nxw * gs + 31) / 32) * 8;      // blocks per group, whole 8-XCD rounds
-        band_rows = bpg;                                 // (parameter reused)
-        grid = (unsigned)(groups * bpg);
-        nbands = 1;
-    } else {
-        if (nbands > h / R) nbands = h / R;              // tiny boxes: fewer, never empty, bands
-        if (nbands < 1) nbands = 1;
-        band_rows = (h + nbands - 1) / nbands;
-        band_rows = (band_rows + R - 1) / R * R;         // whole strips per band
-        if (nbands == 1) {
-            // Blocks go round-robin to the 8 XCDs, so the tile below a given tile runs on the
-            // XCD (blocks per row) mod 8 further on: the re-read of the shared rows is an L2
-            // hit only when that is ~0.  Measured (scripts/pad_probe.py): 32.25 blocks per row
-            // is the sweet spot at 16384^2, 33 blocks per row costs 19 %.  Pick the block size
-            // (2..16 waves) that brings blocks-per-row closest above a multiple of 8, and skew
-            // an exact multiple by one idle tile per row.
-            choose_block_shape(&nxw, &tpb);
-        }
-        const long tiles = (long)nxw * (band_rows / R);  // per band
-        grid = (unsigned)(((tiles + tpb - 1) / tpb) * nbands);
-    }
+    const int strips = (y1 - y0 + R) / R;
+    int tpb = 4;                                         // tiles (waves) per block
+    // Blocks go round-robin to the 8 XCDs, so the tile below a given tile runs on the XCD
+    // (blocks per row) mod 8 further on: the re-read of the shared rows is an L2 hit only when
+    // that is ~0.  Measured (scripts/pad_probe.py): 32.25 blocks per row is the sweet spot at
+    // 16384^2, 33 blocks per row costs 19 %.  Pick the block size (2..16 waves) that brings
+    // blocks-per-row closest above a multiple of 8, and skew an exact multiple by one idle tile.
+    choose_block_shape(&nxw, &tpb);
+    const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
     // (capping the resident waves with unused LDS -- 32 down to 16 waves per CU -- changes nothing
     // until 16, where it costs 2 %: the band of rows in flight is not a lever)
 #define DLESM_TILE(RR)                                                                               \
     hipLaunchKernelGGL((jacobi5_tile<VEC, RR, NT>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, x0, x1, \
-                       y0, y1, c_first, nxw, nbands, band_rows, gs, flags)
+                       y0, y1, c_first, nxw, flags)
     switch (R) {
     case 1: DLESM_TILE(1); break;
     case 2: DLESM_TILE(2); break;
@@ -547,11 +505,10 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
         // rows per tile: 2 for 16-byte lanes, 4 for the 8-byte-lane fallback (measured, scripts/size_probe.py)
         int R = tuning("j5_tile_rows", 0);
         if (R < 1) R = vec2 ? 2 : 4;
-        const int nb = tuning("j5_bands", 1), gs = tuning("j5_group", 0);
-        if (vec2) { if (nt) launch_tile<2, true>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s);
-                    else launch_tile<2, false>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s); }
-        else { if (nt) launch_tile<1, true>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s);
-               else launch_tile<1, false>(in, out, ld, x0, x1, y0, y1, R, nb, gs, flags, s); }
+        if (vec2) { if (nt) launch_tile<2, true>(in, out, ld, x0, x1, y0, y1, R, flags, s);
+                    else launch_tile<2, false>(in, out, ld, x0, x1, y0, y1, R, flags, s); }
+        else { if (nt) launch_tile<1, true>(in, out, ld, x0, x1, y0, y1, R, flags, s);
+               else launch_tile<1, false>(in, out, ld, x0, x1, y0, y1, R, flags, s); }
         DLESM_HIP_TRY(hipGetLastError());
         return DLESM_OK;
     }

@@ -68,19 +68,16 @@ JACOBI_CASES = [
 ]
 
 
-DEFAULT_TUNING = dict(j5_kernel=0, j5_tile_rows=0, j5_bands=1, j5_group=0, j5_tpb=0, j5_skew=1, j5_pad_tiles=0, j5_variant=0, j5_rows=0, j5_unroll=4)
-# every code path of both kernels: band-sweep tiles of every height / band count / VEC / nt,
-# and the y-march kernel with and without register double buffering
+DEFAULT_TUNING = dict(j5_kernel=0, j5_tile_rows=0, j5_tpb=0, j5_skew=1, j5_pad_tiles=0, j5_variant=0, j5_rows=0, j5_unroll=4)
+# every code path: linear-sweep tiles of every height / block size / VEC / nt, the y-march kernel with
+# and without register double buffering, the LDS-staged kernel, the fused-step tile with one step
 TUNINGS = [
-    dict(j5_kernel=0), dict(j5_kernel=0, j5_tile_rows=8, j5_bands=8), dict(j5_kernel=0, j5_tile_rows=3, j5_bands=4),
-    dict(j5_kernel=0, j5_group=8), dict(j5_kernel=0, j5_group=4, j5_tile_rows=3), dict(j5_kernel=0, j5_group=16, j5_tile_rows=1, j5_variant=4),
-    dict(j5_kernel=0, j5_group=3, j5_tile_rows=4, j5_variant=1),
+    dict(j5_kernel=0), dict(j5_kernel=0, j5_tile_rows=8), dict(j5_kernel=0, j5_tile_rows=3),
+    dict(j5_kernel=0, j5_tile_rows=1, j5_variant=4), dict(j5_kernel=0, j5_tile_rows=4, j5_variant=1),
     dict(j5_kernel=0, j5_tpb=2), dict(j5_kernel=0, j5_tpb=8, j5_tile_rows=3), dict(j5_kernel=0, j5_tpb=16, j5_pad_tiles=3),
     dict(j5_kernel=0, j5_skew=0, j5_tpb=4, j5_tile_rows=2),
     dict(j5_kernel=0, j5_variant=16), dict(j5_kernel=0, j5_variant=16, j5_tile_rows=3), dict(j5_kernel=1, j5_variant=16),
-    dict(j5_kernel=0, j5_tile_rows=1, j5_bands=3), dict(j5_kernel=0, j5_tile_rows=2, j5_bands=1),
-    dict(j5_kernel=0, j5_tile_rows=4, j5_bands=8, j5_variant=1), dict(j5_kernel=0, j5_tile_rows=6, j5_bands=5),
-    dict(j5_kernel=0, j5_tile_rows=12, j5_bands=2), dict(j5_kernel=0, j5_tile_rows=16, j5_bands=8),
+    dict(j5_kernel=0, j5_tile_rows=6), dict(j5_kernel=0, j5_tile_rows=12), dict(j5_kernel=0, j5_tile_rows=16),
     dict(j5_kernel=0, j5_variant=4),
     dict(j5_kernel=1, j5_rows=64), dict(j5_kernel=1, j5_rows=7, j5_variant=1),
     dict(j5_kernel=1, j5_rows=16, j5_variant=2, j5_unroll=2), dict(j5_kernel=1, j5_rows=5, j5_variant=3, j5_unroll=8),
