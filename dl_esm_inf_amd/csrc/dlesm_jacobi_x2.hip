@@ -70,7 +70,7 @@ __device__ __forceinline__ void xt_stages(xt_d2 (&v)[R + 2 * T], const XtBoxes &
 
 template <int T, int R, bool DPP>
 __global__ __launch_bounds__(512) void jacobi5xt_tile(const double *__restrict__ in, double *__restrict__ out, int ld, int ny, XtBoxes b,
-                    int cb, int nxw, int nband, double q)
+                    int cb, int nxw, double q)
 {
     typedef xt_d2 d2;
     constexpr int H = (T + 1) / 2;                      // halo lanes per side
@@ -80,22 +80,8 @@ __global__ __launch_bounds__(512) void jacobi5xt_tile(const double *__restrict__
     // loads take the "scalar base + lane offset" form instead of one 64-bit VGPR address per row
     int wv = threadIdx.x >> 6;
     if constexpr (T >= DLESM_XT_SCALAR_FROM) wv = __builtin_amdgcn_readfirstlane(wv);
-    int xw, strip;
-    if (nband > 0) {
-        // XCD column bands: workgroups are dealt round-robin to the 8 XCDs, so XCD k = blockIdx % 8
-        // takes tile columns [k*nband, (k+1)*nband) of EVERY strip, strip after strip.  The rows a
-        // strip shares with the strip below ((R+2T) loaded per R stored) were then fetched by the
-        // same XCD one strip earlier and are hits in ITS L2, whatever the row length; all 8 XCDs
-        // work on the same strip at the same time, so memory is still swept linearly.
-        const int wi = (blockIdx.x >> 3) * (blockDim.x >> 6) + wv;
-        strip = wi / nband;
-        xw = (blockIdx.x & 7) * nband + wi % nband;
-        if (xw >= nxw) return;
-    } else {
-        const int w = blockIdx.x * (blockDim.x >> 6) + wv;
-        xw = w % nxw;
-        strip = w / nxw;
-    }
+    const int w = blockIdx.x * (blockDim.x >> 6) + wv;
+    int xw = w % nxw, strip = w / nxw;
     if constexpr (T >= DLESM_XT_SCALAR_FROM) {
         xw = __builtin_amdgcn_readfirstlane(xw);       // (the integer division runs on the VALU)
         strip = __builtin_amdgcn_readfirstlane(strip);
@@ -293,7 +279,7 @@ static void launch_xt(const double *in, double *out, int ld, int ny, const XtBox
 {
     constexpr int OL = 64 - 2 * ((T + 1) / 2);
     const int cb = b.x0 / 2, c_last = b.x1 / 2;
-    int nxw = (c_last - cb + OL) / OL, tpb = 4, nband = 0;
+    int nxw = (c_last - cb + OL) / OL, tpb = 4;
     // measured best at 16384^2 (profiles/r01_sweep_fused.txt): 4, 6, 8, 8, 12, 16, 16 rows for
     // T = 2..8; capping the VGPRs for more waves per SIMD made no difference (2, 3, 4 waves tried)
     constexpr int best_rows[9] = {0, 8, 4, 6, 8, 8, 12, 16, 16};
@@ -301,20 +287,15 @@ static void launch_xt(const double *in, double *out, int ld, int ny, const XtBox
     if (T > 4 && R < 8) R = 8;                           // deep fusions: tall tiles only
     if (T < 4 && R > 8) R = 8;
     const int strips = (b.y1 - b.y0 + R) / R;
-    unsigned grid;
-    if (tuning("j5xt_order", 0) == 1 && nxw >= 16) {    // XCD column bands (measured: no gain)
-        nband = (nxw + 7) / 8;
-        tpb = tuning("j5_tpb", 0);
-        if (tpb != 1 && tpb != 2 && tpb != 4 && tpb != 8) tpb = 4;
-        grid = (unsigned)(8 * (((long)nband * strips + tpb - 1) / tpb));
-    } else {
-        choose_block_shape(&nxw, &tpb, nxw >= 64 ? 4 : 0);   // wide rows: 4 waves per group measured best
-        if (tpb > 8) tpb = 8;                           // launch bound of the kernel: 512 lanes
-        grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
-    }
+    // (XCD column bands -- XCD k takes tile columns [k*n/8, (k+1)*n/8) of every strip, so that every
+    // vertical re-read is a hit in ITS L2 -- cut the fabric reads to 1.02x compulsory and were slower:
+    // 0.79-0.83 against 0.74-0.78 ms; removed)
+    choose_block_shape(&nxw, &tpb, nxw >= 64 ? 4 : 0);   // wide rows: 4 waves per group measured best
+    if (tpb > 8) tpb = 8;                               // launch bound of the kernel: 512 lanes
+    const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
 #define DLESM_XT(RR)                                                                                          \
     hipLaunchKernelGGL((jacobi5xt_tile<T, RR, DPP>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, ny, b, cb, \
-                       nxw, nband, 0.25)
+                       nxw, 0.25)
     switch (R) {
     case 2: if constexpr (T <= 4) DLESM_XT(2); break;
     case 4: if constexpr (T <= 4) DLESM_XT(4); break;

@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-DEFAULTS = dict(j5xt_march=0, j5xt_march_ring=9, j5xt_march_slots=3072, j5xt_rows=0, j5xt_dpp=1, j5xt_order=0, j5_autoshape=1, j5_kernel=0,j5_tile_rows=0, j5_tpb=0, j5_skew=1, j5_pad_tiles=0, j5_variant=0, j5_rows=0, j5_unroll=4)
+DEFAULTS = dict(j5xt_march=0, j5xt_march_ring=9, j5xt_march_slots=3072, j5xt_rows=0, j5xt_dpp=1, j5_autoshape=1, j5_kernel=0,j5_tile_rows=0, j5_tpb=0, j5_skew=1, j5_pad_tiles=0, j5_variant=0, j5_rows=0, j5_unroll=4)
 
 
 def expand(grid):

@@ -57,11 +57,10 @@ CASES = [(1, 1, None), (2, 3, 2), (4, 10, None), (10, 4, 8), (5, 5, 8), (64, 64,
          (1500, 200, None), (4096, 300, 64), (1930, 37, 2), (2500, 40, 64), (3001, 21, None)]
 STEPS = [2, 3, 4, 5, 6, 7, 8]
 TUNES = [dict(), dict(j5xt_rows=12), dict(j5xt_rows=16, j5xt_dpp=0), dict(j5xt_rows=2, j5xt_dpp=0), dict(j5xt_rows=8, j5_tpb=8), dict(j5xt_rows=4, j5_tpb=2, j5xt_dpp=0),
-         dict(j5xt_order=1), dict(j5xt_order=1, j5xt_rows=4, j5_tpb=8), dict(j5xt_order=1, j5xt_rows=2, j5_tpb=2),
          dict(j5xt_march=1), dict(j5xt_march=1, j5xt_march_ring=6, j5xt_dpp=0),
          dict(j5xt_march=1, j5xt_march_ring=12, j5xt_march_slots=40), dict(j5xt_march=1, j5xt_march_slots=100000),
          dict(j5_variant=4)]
-DEFAULTS = dict(j5xt_rows=0, j5xt_dpp=1, j5xt_order=0, j5_tpb=0, j5_variant=0, j5xt_march=0, j5xt_march_ring=9,
+DEFAULTS = dict(j5xt_rows=0, j5xt_dpp=1, j5_tpb=0, j5_variant=0, j5xt_march=0, j5xt_march_ring=9,
                 j5xt_march_slots=3072)
 # wide and tall enough for the marching kernel to take the interior (8 wave tiles, 4T rows)
 CASES += [(1100, 90, 64), (1100, 90, None), (2047, 150, 2), (5000, 64, 64)]
