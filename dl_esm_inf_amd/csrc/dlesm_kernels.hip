@@ -346,15 +346,19 @@ void choose_block_shape(int *nxw_io, int *tpb_out, int prefer)
         return;
     }
     double best = 1e9;
+    // idle padding tiles leave at once and cost next to nothing: at 2048^2 (17 tiles per row) padding
+    // to 32 tiles = 16 two-wave blocks per row gives 62.5 % against 52.3 % for 4.25 four-wave blocks,
+    // so a candidate is never rejected for its padding alone (j5_reject, in percent, used to be 25)
+    const double padw = tuning("j5_padw", 100) / 100.0, reject = tuning("j5_reject", 100) / 100.0;
     for (int cand : {8, 4, 2, 16}) {
         if (forced && cand != forced) continue;
         const int period = 8 * cand, slack = 3 * cand / 8;   // up to 3/8 of a block past 8k
         if (nxw < period && !forced) continue;        // fewer than 8 blocks per row
         const int r = nxw % period, p = r <= slack ? 0 : period - r;
-        const double cost = (double)p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : cand == 2 ? 0.03 : 0.04);
+        const double cost = padw * p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : cand == 2 ? 0.03 : 0.04);
         if (cost < best) { best = cost; tpb = cand; pad = p; }
     }
-    if (best > 0.25 && !forced) { tpb = 4; pad = 0; } // nothing fits cheaply (narrow boxes)
+    if (best > reject && !forced) { tpb = 4; pad = 0; } // nothing fits cheaply (narrow boxes)
     nxw += pad;
     if (tuning("j5_skew", 1) && nxw >= 128 && nxw % (8 * tpb) == 0) nxw += 1;
     nxw += tuning("j5_pad_tiles", 0);
