@@ -105,6 +105,7 @@ PROTOTYPES = {
     "dlesm_write_to_device": (None, [_vp, _vp, _i, _i, _i, _i, C.c_bool]),
     "dlesm_transfer_sync": (_i, []),
     "dlesm_stencil5_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dlesm_stencil5_autotune_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_stencil5_x2_f64": (_i, [_vp, _vp] + [_i] * 10 + [_vp]),
     "dlesm_stencil5_multi_f64": (_i, [_vp, _vp] + [_i] * 15 + [_vp]),
     "dlesm_shallow_step_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),

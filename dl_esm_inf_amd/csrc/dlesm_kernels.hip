@@ -4,7 +4,10 @@
 // All of them are memory bound (<= 0.25 flop/byte): no MFMA, no GEMM reshaping.
 // What matters is that every cell is fetched from HBM once, in 16-byte-per-lane
 // coalesced requests, with enough requests in flight per CU.
+#include <map>
 #include <mutex>
+#include <tuple>
+#include <vector>
 
 #include "dlesm_internal.h"
 
@@ -329,12 +332,9 @@ __global__ __launch_bounds__(1024) void jacobi5_lds(const double *__restrict__ i
     }
 }
 
-// Block shape of a linear tile sweep.  Workgroups go round-robin to the 8 XCDs, so the tile
-// below a given tile runs on the XCD (blocks per row) mod 8 further on, and the re-read of the
-// rows they share is an L2 hit only when that is ~0.  Rule fitted to measurements
-// (scripts/pad_probe.py, scripts/size_probe.py): blocks per row must sit in [8k, 8k + 1/4];
-// take the block size (2..16 waves) that gets there with the fewest idle padding tiles per
-// row; an exact multiple is skewed by one idle tile for wide rows.
+// Block shape of a linear tile sweep: waves per workgroup and (padded) wave tiles per row.
+// Workgroups go round-robin to the 8 XCDs, so the tile below a given tile runs on the XCD
+// (groups per row) mod 8 further on; the rule below is fitted to measurements, see inside.
 void choose_block_shape(int *nxw_io, int *tpb_out, int prefer)
 {
     int nxw = *nxw_io, tpb = 4, pad = 0;
@@ -345,26 +345,54 @@ void choose_block_shape(int *nxw_io, int *tpb_out, int prefer)
         *nxw_io = nxw + tuning("j5_pad_tiles", 0);
         return;
     }
+    // Exhaustive searches over (waves per group, tiles per row) at 1024^2 .. 16384^2
+    // (scripts/shape_search.py, profiles/r01_shape_search.txt) all show the same thing: the sweep is
+    // fast when a row is A QUARTER OF A WORKGROUP short of, or past, a multiple of 8 workgroups
+    // (7.75, 8.25, 15.75, 16.25, ... groups per row): the tile below a tile then runs on the same XCD
+    // for 3 tiles in 4 (its re-read rows are L2 hits) while the columns an XCD works on still drift
+    // from row to row.  At the exact multiple it is up to 40 % slower (every XCD keeps hitting the
+    // same few L2 channels), at +-1/8 group it is sometimes fast and sometimes 14 % slower, in between
+    // it is slow.  Idle padding tiles leave at once and cost next to nothing (58 % of them at 10000^2
+    // still wins); 8 and 4 waves per group are equally good at the same drift, 2 is worse.
+    // So: the smallest tile count >= nxw that is = +-(waves per group)/4 modulo 8 groups.
+    if (nxw < 8 && !forced) {                         // thin boxes (frames): plain
+        *nxw_io = nxw + tuning("j5_pad_tiles", 0);
+        *tpb_out = 4;
+        return;
+    }
+    const bool skew = tuning("j5_skew", 1);
+    const double padw = tuning("j5_padw", 2) / 100.0;
     double best = 1e9;
-    // idle padding tiles leave at once and cost next to nothing: at 2048^2 (17 tiles per row) padding
-    // to 32 tiles = 16 two-wave blocks per row gives 62.5 % against 52.3 % for 4.25 four-wave blocks,
-    // so a candidate is never rejected for its padding alone (j5_reject, in percent, used to be 25)
-    const double padw = tuning("j5_padw", 100) / 100.0, reject = tuning("j5_reject", 100) / 100.0;
     for (int cand : {8, 4, 2, 16}) {
         if (forced && cand != forced) continue;
-        const int period = 8 * cand, slack = 3 * cand / 8;   // up to 3/8 of a block past 8k
-        if (nxw < period && !forced) continue;        // fewer than 8 blocks per row
-        const int r = nxw % period, p = r <= slack ? 0 : period - r;
-        const double cost = padw * p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : cand == 2 ? 0.03 : 0.04);
+        const int period = 8 * cand, r = nxw % period, base = nxw - r, d = cand >= 4 ? cand / 4 : 1;
+        int target;
+        if (!skew) target = r ? base + period : nxw;                  // experiments: the exact multiple
+        else target = r <= d ? base + d : (r <= period - d ? base + period - d : base + period + d);
+        const int p = target - nxw;
+        const double cost = padw * p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : cand == 2 ? 0.05 : 0.04);
         if (cost < best) { best = cost; tpb = cand; pad = p; }
     }
-    if (best > reject && !forced) { tpb = 4; pad = 0; } // nothing fits cheaply (narrow boxes)
-    nxw += pad;
-    if (tuning("j5_skew", 1) && nxw >= 128 && nxw % (8 * tpb) == 0) nxw += 1;
-    nxw += tuning("j5_pad_tiles", 0);
+    nxw += pad + tuning("j5_pad_tiles", 0);
     *nxw_io = nxw;
     *tpb_out = tpb;
 }
+
+// Measured shapes (dlesm_stencil5_autotune_f64): every shape computes the same bits, so the best
+// (waves per group, tiles per row) for a given (leading dimension, box) can simply be timed once
+// and remembered -- the fine structure of the landscape depends on the row pitch and is not
+// captured by the rule above to better than +-2 %.
+struct ShapeKey {
+    int ld, x0, x1, y0, y1, vec;
+    bool operator<(const ShapeKey &o) const
+    {
+        return std::tie(ld, x0, x1, y0, y1, vec) < std::tie(o.ld, o.x0, o.x1, o.y0, o.y1, o.vec);
+    }
+};
+struct Shape { int tpb, nxw; };
+static std::mutex g_shape_mu;
+static std::map<ShapeKey, Shape> g_shape_cache;
+static Shape g_shape_override = {0, 0};                 // set only while the autotuner is measuring
 
 template <int VEC, bool NT>
 static void launch_tile(const double *in, double *out, int ld, int x0, int x1, int y0, int y1, int R,
@@ -382,7 +410,13 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
     // that is ~0.  Measured (scripts/pad_probe.py): 32.25 blocks per row is the sweet spot at
     // 16384^2, 33 blocks per row costs 19 %.  Pick the block size (2..16 waves) that brings
     // blocks-per-row closest above a multiple of 8, and skew an exact multiple by one idle tile.
-    choose_block_shape(&nxw, &tpb);
+    {
+        std::lock_guard<std::mutex> lk(g_shape_mu);
+        auto it = g_shape_cache.find(ShapeKey{ld, x0, x1, y0, y1, VEC});
+        if (g_shape_override.tpb) { tpb = g_shape_override.tpb; nxw = g_shape_override.nxw; }
+        else if (it != g_shape_cache.end() && tuning("j5_use_tuned", 1)) { tpb = it->second.tpb; nxw = it->second.nxw; }
+        else choose_block_shape(&nxw, &tpb);
+    }
     const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
     // (capping the resident waves with unused LDS -- 32 down to 16 waves per CU -- changes nothing
     // until 16, where it costs 2 %: the band of rows in flight is not a lever)
@@ -700,6 +734,81 @@ extern "C" int dlesm_stencil5_f64(const double *in, double *out, int ld, int ny,
 {
     if (int rc = ensure_device()) return rc;
     return launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, (hipStream_t)stream);
+}
+
+// Plan-style tuning of dlesm_stencil5_f64 for one (leading dimension, box): times ~a dozen launch
+// shapes around the rule's choice on the caller's own arrays (every launch is the same valid
+// step in -> out), remembers the fastest for later calls with that geometry, and returns after a
+// stream synchronisation.  Optional: without it the rule of choose_block_shape() is used.
+extern "C" int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld, int ny, int xstart,
+                                           int xstop, int ystart, int ystop, void *stream)
+{
+    clear_error();
+    if (int rc = ensure_device()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s)) return rc;   // validates, warms
+    const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
+    const int variant = tuning("j5_variant", 0);
+    const bool odd_ok = !(variant & 16) && x1 + 1 <= 2 * (ld / 2) - 1;
+    const bool vec2 = !(variant & 4) && ((ld % 2 == 0) || odd_ok) && ((uintptr_t)in % 16 == 0) &&
+                      ((uintptr_t)out % 16 == 0);
+    if (tuning("j5_kernel", 0) != 0) return DLESM_OK;            // only the default kernel has shapes
+    const int VEC = vec2 ? 2 : 1;
+    const int c_first = (x0 / VEC) & ~(128 / (8 * VEC) - 1), c_last = x1 / VEC;
+    const int nxw = (c_last - c_first + 64) / 64;
+    if (nxw < 8) return DLESM_OK;                                 // thin boxes: nothing to choose
+    std::vector<Shape> cand;
+    auto add = [&](int tpb, int t) {
+        for (const Shape &c : cand)
+            if (c.tpb == tpb && c.nxw == t) return;
+        cand.push_back(Shape{tpb, t});
+    };
+    {
+        int t = nxw, tpb = 4;
+        choose_block_shape(&t, &tpb);
+        add(tpb, t);                                              // the rule's own choice first
+    }
+    for (int tpb : {8, 4}) {
+        const int period = 8 * tpb, dmax = tpb == 8 ? 3 : 1;
+        for (int k = 0; k < 2; k++) {                             // this multiple of 8 groups and the next
+            const int base = (nxw / period + k) * period;
+            for (int d = 1; d <= dmax; d++) {
+                if (base - d >= nxw) add(tpb, base - d);
+                if (base + d >= nxw) add(tpb, base + d);
+            }
+        }
+    }
+    hipEvent_t e0, e1;
+    DLESM_HIP_TRY(hipEventCreate(&e0));
+    DLESM_HIP_TRY(hipEventCreate(&e1));
+    // three interleaved passes over the candidates (so that clock drift hits all of them alike); a
+    // trial is 4 back-to-back launches between two events, the first trial of a pass is a warm-up
+    std::vector<float> best_of(cand.size(), 1e30f);
+    int rc = DLESM_OK;
+    for (int pass = 0; pass < 3 && !rc; pass++)
+        for (size_t k = 0; k <= cand.size() && !rc; k++) {
+            const Shape c = cand[k ? k - 1 : 0];
+            { std::lock_guard<std::mutex> lk(g_shape_mu); g_shape_override = c; }
+            (void)hipEventRecord(e0, s);
+            for (int rep = 0; rep < 4 && !rc; rep++)
+                rc = launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s);
+            (void)hipEventRecord(e1, s);
+            { std::lock_guard<std::mutex> lk(g_shape_mu); g_shape_override = Shape{0, 0}; }
+            if (hipEventSynchronize(e1) != hipSuccess) rc = fail(DLESM_EHIP, "autotune: event synchronisation failed");
+            float ms = 0.f;
+            if (!rc && k > 0 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_of[k - 1]) best_of[k - 1] = ms;
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    Shape best = cand[0];
+    float best_ms = best_of[0] * 0.995f;                 // the rule's choice stays unless beaten by 0.5 %
+    for (size_t k = 1; k < cand.size(); k++)
+        if (best_of[k] < best_ms) { best_ms = best_of[k]; best = cand[k]; }
+    std::lock_guard<std::mutex> lk(g_shape_mu);
+    g_shape_cache[ShapeKey{ld, x0, x1, y0, y1, VEC}] = best;
+    return DLESM_OK;
 }
 
 extern "C" int dlesm_shallow_step_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop,

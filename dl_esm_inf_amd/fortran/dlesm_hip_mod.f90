@@ -239,6 +239,13 @@ module dlesm_hip_mod
        integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
        integer(c_int) :: rc
      end function
+     function dlesm_stencil5_autotune_f64(in, out, ld, ny, xstart, xstop, ystart, ystop, stream) &
+          bind(C, name="dlesm_stencil5_autotune_f64") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: in, out, stream
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       integer(c_int) :: rc
+     end function
      function dlesm_stencil5_multi_f64(in, out, ld, ny, nsteps, xstart, xstop, ystart, ystop, &
           exstart, exstop, eystart, eystop, grow_w, grow_e, grow_s, grow_n, stream) &
           bind(C, name="dlesm_stencil5_multi_f64") result(rc)

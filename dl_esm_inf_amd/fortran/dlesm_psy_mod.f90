@@ -48,7 +48,7 @@ module dlesm_psy_mod
   private
 
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
-  public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi
+  public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
 
 contains
@@ -74,6 +74,24 @@ contains
                             int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_jacobi5: ' // dlesm_error_text())
   end subroutine invoke_jacobi5
+
+  !> Optional planning call (once per field geometry, outside the time loop): lets the library time
+  !! its launch shapes for invoke_jacobi5 / invoke_jacobi5_dm on these fields and keep the fastest.
+  !! `out` receives one valid step of `in`; results never depend on the shape.
+  subroutine plan_jacobi5(out, in)
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(r2d_field), intent(inout), target :: out, in
+    integer(c_int) :: rc, shrink
+    call need_device(in);  call need_device(out)
+    shrink = 0
+    if (DIST_MEM_ENABLED) shrink = 1         ! the distributed step's interior box
+    rc = dlesm_stencil5_autotune_f64(field_device_data(in), field_device_data(out), &
+                                     int(out%grid%nx, c_int), int(out%grid%ny, c_int), &
+                                     int(out%internal%xstart + shrink, c_int), int(out%internal%xstop - shrink, c_int), &
+                                     int(out%internal%ystart + shrink, c_int), int(out%internal%ystop - shrink, c_int), &
+                                     c_null_ptr)
+    if (rc /= 0) call gocean_stop('plan_jacobi5: ' // dlesm_error_text())
+  end subroutine plan_jacobi5
 
   !> Distributed Jacobi step: `in` must have valid halos; on return (asynchronously) `out`
   !! holds the update AND its halos, the exchange having run behind the interior sweep.

@@ -17,6 +17,15 @@ def invoke_jacobi5(out_fld, in_fld, stream=None):
                                          _stream_ptr(stream)))
 
 
+def autotune_jacobi5(out_fld, in_fld, stream=None):
+    """optional planning call: measure the launch shapes of invoke_jacobi5 for this field geometry
+    once (each trial is the same valid step in -> out) and keep the fastest"""
+    g, it = out_fld.grid, out_fld.internal
+    check(_cabi.lib().dlesm_stencil5_autotune_f64(in_fld.device_ptr, out_fld.device_ptr, g.nx, g.ny,
+                                                  it.xstart, it.xstop, it.ystart, it.ystop,
+                                                  _stream_ptr(stream)))
+
+
 def invoke_jacobi5_x2(out_fld, in_fld, ebox=None, stream=None):
     """TWO Jacobi steps in one sweep: out = J(t) on out_fld%internal, t = J(in) on `ebox`
     (default: the same box, i.e. a fixed boundary ring) and in elsewhere"""

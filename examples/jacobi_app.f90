@@ -87,6 +87,10 @@ program jacobi_app
   call a%halo_exchange(1)
   call model_write_log("('initial checksum = ',E24.16)", field_checksum(a))
 
+  if (fuse == 1) then
+     call plan_jacobi5(b, a)            ! optional: the library times its launch shapes once
+     call invoke_copy(b, a)
+  end if
   call device_sync()
   call system_clock(t0, rate)
   do i = 1, ncalls

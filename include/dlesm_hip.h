@@ -190,6 +190,13 @@ int dlesm_transfer_sync(void);
 int dlesm_stencil5_f64(const double *in, double *out, int ld, int ny,
                        int xstart, int xstop, int ystart, int ystop, void *stream);
 
+/* Optional planning call for dlesm_stencil5_f64 (in the manner of an FFT plan): times about a dozen
+ * launch shapes (waves per workgroup, tiles per row) on the caller's own arrays -- each is the same
+ * valid step in -> out, the results do not depend on the shape -- and remembers the fastest for
+ * later calls with this (ld, box).  Synchronises `stream`.  Without it a fitted rule picks the shape. */
+int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld, int ny,
+                                int xstart, int xstop, int ystart, int ystop, void *stream);
+
 /* TWO Jacobi steps in one sweep (temporal blocking; SURVEY section 8 f.4 -- an extension,
  * the reference stops at MAX_HALO_DEPTH = 1, parallel_comms_mod.f90:48):
  *   t   = J(in) on the intermediate box (exstart:exstop, eystart:eystop), in elsewhere

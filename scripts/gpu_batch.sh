@@ -123,6 +123,12 @@ pmccmp)     # counters of the linear-sweep tile kernel against the column-marchi
     done
     python scripts/pmc_table.py $OUT/pmccmp jacobi5_tile jacobi5xt_march > $OUT/pmccmp_table.txt 2>&1
     cat $OUT/pmccmp_table.txt ;;
+shapes)     # exhaustive (waves per group, tiles per row) search per size + what the rule picks
+    : > $OUT/shape_search.txt
+    for t in ${SIZES:-1024 2048 3072 4096 5000 7000 8192 10000 12288 14000 16384}; do
+        step shape$t 200 python scripts/shape_search.py $t 2>&1 | grep -v amdgpu.ids | grep -E "^N |best:" | head -5 >> $OUT/shape_search.txt
+    done
+    cat $OUT/shape_search.txt ;;
 counters)
     step counters 120 rocprofv3 -L > $OUT/counters.txt 2>&1
     grep -c . $OUT/counters.txt ;;

@@ -149,6 +149,33 @@ def test_jacobi5_special_values_follow_ieee_like_the_cpu(D, nsteps):
     assert np.count_nonzero(sub) > 100                       # subnormal results really occur
 
 
+@pytest.mark.parametrize("nx,ny,alignment", [(2000, 300, 64), (1111, 77, None), (40, 30, 8)])
+def test_planned_launch_shape_changes_no_bit(D, nx, ny, alignment):
+    """dlesm_stencil5_autotune_f64 leaves a valid step in `out`, and the shape it remembers for this
+    geometry gives the same bits as the rule's shape and as the oracle"""
+    g = _grid(D, nx, ny, alignment)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    D.psy.hash_init(a, SEED)
+    D.set_field(b, -7.0)
+    hin = a.get_data()
+    want = np.full_like(hin, -7.0)
+    it = b.internal
+    O.jacobi5(hin, want, g.nx, it.xstart, it.xstop, it.ystart, it.ystop)
+    D.psy.autotune_jacobi5(b, a)
+    assert np.array_equal(b.get_data(), want)
+    for use in (1, 0):
+        _set_tuning(D, j5_use_tuned=use)
+        D.set_field(b, -7.0)
+        D.psy.invoke_jacobi5(b, a)
+        assert np.array_equal(b.get_data(), want), use
+    _set_tuning(D, j5_use_tuned=1)
+    # an empty box and a thin box are accepted and tune nothing
+    L = D._cabi.lib()
+    assert L.dlesm_stencil5_autotune_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, 5, 4, 2, 9, None) == 0
+    assert L.dlesm_stencil5_autotune_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, 2, 3, 2, ny + 1, None) == 0
+    assert L.dlesm_stencil5_autotune_f64(a.device_ptr, a.device_ptr, g.nx, g.ny, 2, 3, 2, 9, None) == D._cabi.EINVAL
+
+
 def test_jacobi5_sub_boxes_and_empty(D):
     """arbitrary PSy boxes (what the frame/interior split uses), incl. zero-trip loops"""
     g = _grid(D, 300, 90, 64)
