@@ -161,7 +161,28 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
 {
     const int cb = x0 / 2, c_last = x1 / 2;              // first / last chunk holding an output column
     int nxw = (c_last - cb + 62) / 62, tpb = 4;          // 62 output chunks per wave tile
-    choose_block_shape(&nxw, &tpb);
+    // This kernel's landscape differs from the Jacobi one (nine arrays in flight): an exhaustive search at
+    // 8192^2 (scripts/shallow_probe.py 8192 search; 67 tiles per row) finds 8 waves per group JUST ABOVE a
+    // multiple of 8 groups best (67 tiles 0.844 ms, 68 0.846, 69 0.852), 4 waves at 23.75 groups equal
+    // (0.846), and the region the Jacobi rule would pick -- 15.75 groups per row -- 25 % slower.  So: the
+    // group size whose 8-group multiple lies closest below the row, no padding when the row is within
+    // 3/8 group past it, else padding up to the next multiple (+1 tile when that lands on it exactly).
+    if (!tuning("j5_autoshape", 1) || tuning("j5_tpb", 0) || nxw < 16) {
+        choose_block_shape(&nxw, &tpb);                  // experiments and thin boxes: the shared path
+    } else {
+        double best = 1e9;
+        int pad = 0;
+        for (int cand : {8, 4, 2}) {
+            const int period = 8 * cand, slack = 3 * cand / 8;
+            if (nxw < period) continue;
+            const int r = nxw % period, p = r <= slack ? 0 : period - r;
+            const double cost = (double)p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : 0.03);
+            if (cost < best) { best = cost; tpb = cand; pad = p; }
+        }
+        if (best > 0.25) { tpb = 4; pad = 0; }
+        nxw += pad;
+        if (nxw >= 128 && nxw % (8 * tpb) == 0) nxw += 1;
+    }
     if (tpb > 8) tpb = 8;                                // the kernel is bounded to 512 threads
     int R = tuning("sw_tile_rows", 2);
     if (R != 1 && R != 3) R = 2;

@@ -44,6 +44,10 @@ for rep in range(2):
     for R in (2, 3, 1):
         run(f"tile auto R{R} dpp", sw_tile_rows=R, sw_dpp=1)
         run(f"tile auto R{R} bpermute", sw_tile_rows=R, sw_dpp=0)
-if len(sys.argv) > 2:
-    for tpb, pad, R in itertools.product((1, 2, 4, 8), (0, 1, 2, 5), (2, 1)):
-        run(f"tile plain tpb{tpb} pad{pad} R{R}", j5_autoshape=0, j5_tpb=tpb, j5_pad_tiles=pad, sw_tile_rows=R)
+if len(sys.argv) > 2:      # exhaustive (waves per group, tiles per row) search, as scripts/shape_search.py
+    base = (tile // 2 + 62) // 62
+    print(f"tiles per row without padding: {base}")
+    for tpb in (4, 8):
+        for pad in range(0, 8 * tpb + 4):
+            run(f"plain tpb {tpb} pad {pad:2d} -> {base + pad:3d} tiles = {(base + pad) / tpb:6.2f} groups/row", j5_autoshape=0,
+                j5_tpb=tpb, j5_pad_tiles=pad)
