@@ -35,9 +35,9 @@ prof)
 pmc)
     rm -rf $OUT/pmc_fetch $OUT/pmc_write
     [ -f profiles/traffic.json ] && cp profiles/traffic.json $OUT/traffic.json   # records are merged by key
-    step pmcF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-    step pmcW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-    python scripts/parse_rocprof.py pmc $OUT/pmc_fetch $OUT/pmc_write "16384x16384/A64" $OUT/traffic.json 2>&1 | tail -12 ;;
+    step pmcF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow > $OUT/pmc_fetch.log 2>&1
+    step pmcW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow > $OUT/pmc_write.log 2>&1
+    python scripts/parse_rocprof.py pmc $OUT/pmc_fetch $OUT/pmc_write "16384x16384/A64" $OUT/traffic.json jacobi5_ 20 2>&1 | tail -12 ;;   # the 20 timed launches (planned shape)
 pmcx)    # HBM traffic of the fused kernel, FUSED steps per launch (default 8)
     F=${FUSED:-8}
     rm -rf $OUT/pmcx_fetch $OUT/pmcx_write

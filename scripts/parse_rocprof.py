@@ -63,11 +63,15 @@ def counter_rows(d, counter, kernel_sub):
     return vals
 
 
-def pmc(fetch_dir, write_dir, key, out, kernel_sub="jacobi5_"):
+def pmc(fetch_dir, write_dir, key, out, kernel_sub="jacobi5_", last="0"):
+    """last = N: only the last N launches of the kernel (the warm-up + timed region of bench.py, after
+    the planning call has tried its launch shapes)"""
     fetch = counter_rows(fetch_dir, "FETCH_SIZE", kernel_sub)
     write = counter_rows(write_dir, "WRITE_SIZE", kernel_sub)
     if not fetch or not write:
         sys.exit(f"no counter rows for {kernel_sub}: fetch {len(fetch)} write {len(write)}")
+    if int(last) > 0:
+        fetch, write = fetch[-int(last):], write[-int(last):]
     f_kib, w_kib = statistics.median(fetch), statistics.median(write)
     rec = {
         "kernel": kernel_sub, "launches_seen": [len(fetch), len(write)],
