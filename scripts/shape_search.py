@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """experiment: exhaustive search over (waves per workgroup, idle padding tiles per row) for the
-Jacobi-5 tile sweep at one size, to refit choose_block_shape():  scripts/shape_search.py N [A]"""
+Jacobi-5 tile sweep at one size, to refit choose_block_shape():  scripts/shape_search.py N [A [T]]
+(T > 1: the fused T-step kernel instead of the single-step one)"""
 import ctypes as C
 import os
 import sys
@@ -25,7 +26,9 @@ s = torch.cuda.Stream()
 sp = C.c_void_p(s.cuda_stream)
 D.psy.hash_init(a, 1, stream=s)
 D.copy_field(a, b, stream=s)
-base = (box[1] // 2 - 0 + 64) // 64          # wave tiles per row, tile origin at chunk 0 (x0 = 1)
+FUSED = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+OL = 64 - 2 * ((FUSED + 1) // 2) if FUSED > 1 else 64
+base = (box[1] // 2 - 0 + OL) // OL          # wave tiles per row, tile origin at chunk 0 (x0 = 1)
 
 
 def run(**kw):
@@ -37,7 +40,11 @@ def run(**kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(s)
         for _ in range(10):
-            D._cabi.check(L.dlesm_stencil5_f64(x.device_ptr, y.device_ptr, g.nx, g.ny, *box, sp))
+            if FUSED > 1:
+                D._cabi.check(L.dlesm_stencil5_multi_f64(x.device_ptr, y.device_ptr, g.nx, g.ny, FUSED, *box, *box,
+                                                         0, 0, 0, 0, sp))
+            else:
+                D._cabi.check(L.dlesm_stencil5_f64(x.device_ptr, y.device_ptr, g.nx, g.ny, *box, sp))
             x, y = y, x
         e1.record(s)
         s.synchronize()
@@ -49,13 +56,13 @@ def run(**kw):
 with torch.cuda.stream(s):
     auto = run(j5_autoshape=1, j5_tpb=0, j5_pad_tiles=0)
     rows = []
-    for tpb in (2, 4, 8):
+    for tpb in ((4, 8) if FUSED > 1 else (2, 4, 8)):
         for pad in range(0, 8 * tpb + 2):
             rows.append((run(j5_autoshape=0, j5_tpb=tpb, j5_pad_tiles=pad), tpb, pad))
 gb = 16.0 * tile * tile / 1e9
-print(f"N {tile} ld {g.nx} tiles/row {base}: auto rule {auto:.4f} ms ({gb / auto / 8:.1f} %)")
+print(f"N {tile} fused {FUSED} ld {g.nx} tiles/row {base}: auto rule {auto:.4f} ms ({gb / auto / 8:.1f} %)")
 for t, tpb, pad in sorted(rows)[:8]:
     print(f"   best: tpb {tpb} pad {pad:2d} -> {base + pad:4d} tiles = {(base + pad) / tpb:7.2f} groups/row  {t:.4f} ms ({gb / t / 8:.1f} %)")
-for tpb in (2, 4, 8):
+for tpb in ((4, 8) if FUSED > 1 else (2, 4, 8)):
     line = " ".join(f"{t:.3f}" for t, tp, pad in rows if tp == tpb)
     print(f"   tpb {tpb} pad 0..: {line}")
