@@ -350,8 +350,8 @@ void choose_block_shape(int *nxw_io, int *tpb_out, int prefer)
     // fast when a row is A QUARTER OF A WORKGROUP short of, or past, a multiple of 8 workgroups
     // (7.75, 8.25, 15.75, 16.25, ... groups per row): the tile below a tile then runs on the same XCD
     // for 3 tiles in 4 (its re-read rows are L2 hits) while the columns an XCD works on still drift
-    // from row to row.  At the exact multiple it is up to 40 % slower (every XCD keeps hitting the
-    // same few L2 channels), at +-1/8 group it is sometimes fast and sometimes 14 % slower, in between
+    // from row to row.  At the exact multiple it is up to 40 % slower (presumably every XCD then keeps
+    // working on the same address stripes), at +-1/8 group it is sometimes fast and sometimes 14 % slower, in between
     // it is slow.  Idle padding tiles leave at once and cost next to nothing (58 % of them at 10000^2
     // still wins); 8 and 4 waves per group are equally good at the same drift, 2 is worse.
     // So: the smallest tile count >= nxw that is = +-(waves per group)/4 modulo 8 groups.
