@@ -95,7 +95,10 @@ def main():
     res = {}
     finals = {}
     with torch.cuda.stream(s):
-        for name, fn in (("plain", plain), ("serial", serial), ("overlapped", overlapped)):
+        # the first mode of a process runs on cold clocks (2-3 % slow): measure `plain` twice, keep the second;
+        # then serial / overlapped twice interleaved, keep the faster of each
+        for name, fn in (("cold", plain), ("plain", plain), ("serial", serial), ("overlapped", overlapped),
+                         ("serial2", serial), ("overlapped2", overlapped), ("plain2", plain)):
             a, b = F[0], F[1]                         # the same two buffers for every mode
             init(a, b)
             for _ in range(5):
@@ -110,7 +113,11 @@ def main():
             e1.record(s)
             s.synchronize()
             res[name] = e0.elapsed_time(e1) / args.steps
-            finals[name] = a.data.clone()
+            if name in ("serial", "overlapped"):
+                finals[name] = a.data.clone()
+    for k in ("plain", "serial", "overlapped"):
+        res[k] = min(res[k], res.pop(k + "2"))
+    res.pop("cold")
     same = bool(torch.equal(finals["serial"], finals["overlapped"]))
     cells = args.tile * args.tile
     out = {"tile": args.tile, "launches": args.steps, "time_steps_per_launch": T, "ms_per_launch": res,
