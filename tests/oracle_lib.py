@@ -207,3 +207,12 @@ def jacobi5(inp, out, ld, xs, xe, ys, ye, threads=1):
         lib().orc_jacobi5_omp(inp, out, ld, xs, xe, ys, ye, threads)
     else:
         lib().orc_jacobi5(inp, out, ld, xs, xe, ys, ye)
+
+
+def sw_step(prm, ld, box, u, v, p, uold, vold, pold, unew, vnew, pnew):
+    """orc_sw_step on the 1-based inclusive box (xs, xe, ys, ye); (ny, ld) arrays; the four
+    intermediates live in scratch arrays of the same shape"""
+    scratch = [np.zeros_like(p) for _ in range(4)]
+    op = SwParams(prm.fsdx, prm.fsdy, prm.tdts8, prm.tdtsdx, prm.tdtsdy)
+    xs, xe, ys, ye = box
+    lib().orc_sw_step(C.byref(op), ld, xs, xe, ys, ye, u, v, p, uold, vold, pold, *scratch, unew, vnew, pnew)

@@ -440,6 +440,86 @@ def test_shallow_step_matches_oracle(D, nx, ny, alignment, sw_kernel, sw_rows, s
     _set_tuning(D, sw_kernel=0, sw_tile_rows=2, sw_dpp=1)
 
 
+def _sw_fields(D, g):
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    return names, {n: D.r2d_field(g, pts[n[0]]) for n in names}
+
+
+@pytest.mark.parametrize("sw_kernel,sw_rows", [(0, 2), (0, 3), (1, 2)])
+def test_shallow_ten_steps_numpy_golden(D, sw_kernel, sw_rows):
+    """64x48, leapfrog rotation, against tests/golden/sw_numpy_64x48.json -- generated by the
+    independent numpy evaluation (tests/sw_numpy.py), not by the oracle: every bit of u, v, p after
+    1, 5 and 10 steps (sha256 of the internal region), samples, and the device checksum within 1e-12"""
+    import sw_numpy as N
+    gold = load_golden("sw_numpy_64x48")
+    _set_tuning(D, sw_kernel=sw_kernel, sw_tile_rows=sw_rows)
+    g = _grid(D, gold["nx"], gold["ny"])
+    assert (g.nx, g.ny) == (gold["ld"], gold["ny_arr"])
+    names, F = _sw_fields(D, g)
+    for k, n in enumerate("uvp"):
+        D.psy.hash_init(F[n], gold["seed"] + k)
+        F[n].data.add_(1.0 if n == "p" else -0.5)
+        D.copy_field(F[n], F[n + "old"])
+        D.copy_field(F[n], F[n + "new"])
+    prm = D.psy.shallow_params(gold["dx"], gold["dy"], gold["dt"])
+    cur, old, new = [F[n] for n in "uvp"], [F[n + "old"] for n in "uvp"], [F[n + "new"] for n in "uvp"]
+    box = F["p"].internal.box()
+    for k in range(1, 11):
+        D.psy.invoke_shallow_step(prm, *cur, *old, *new)
+        old, cur, new = cur, new, old
+        rec = gold["steps"].get(str(k))
+        if rec is None:
+            continue
+        for name, f in zip("uvp", cur):
+            h = f.get_data()
+            for (i, j, hx) in rec[name]["samples"]:
+                assert h[j - 1, i - 1] == float.fromhex(hx), (k, name, i, j)
+            assert N.digest(h, box) == rec[name]["sha256"], (k, name)
+            want = float.fromhex(rec[name]["abs_sum"])
+            assert abs(D.field_checksum(f) - want) <= 1e-12 * want, (k, name)
+    _set_tuning(D, sw_kernel=0, sw_tile_rows=2)
+
+
+@pytest.mark.parametrize("n,alignment", [(8192, 64), (4096, None)])
+def test_shallow_full_size_properties(D, n, alignment):
+    """BASELINE configs[3] size: (i) a constant state is a fixed point, exactly; (ii) sampled rows and
+    the edge rows agree bit for bit with the oracle run on 3-row slabs; (iii) nothing outside the
+    box is written"""
+    import torch
+    import sw_numpy as N
+    g = _grid(D, n, n, alignment)
+    names, F = _sw_fields(D, g)
+    it = F["p"].internal
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
+    for nm in names:
+        D.set_field(F[nm], {"u": 0.25, "v": -0.125, "p": 1.5}[nm[0]] if not nm.endswith("new") else 9.0)
+    D.psy.invoke_shallow_step(prm, *[F[nm] for nm in names])
+    for nm, c in (("unew", 0.25), ("vnew", -0.125), ("pnew", 1.5)):
+        inner = F[nm].data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop]
+        assert bool((inner == c).all()), nm
+        assert float(F[nm].data.sum().item()) == c * n * n + 9.0 * (g.nx * g.ny - n * n), nm
+    for k, nm in enumerate(names[:6]):
+        D.psy.hash_init(F[nm], SEED + k)
+        F[nm].data.add_(1.0 if nm[0] == "p" else -0.5)
+    D.psy.invoke_shallow_step(prm, *[F[nm] for nm in names])
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(n)
+    rows = sorted(set([it.ystart, it.ystart + 1, it.ystop - 1, it.ystop] +
+                      [int(r) for r in rng.integers(it.ystart, it.ystop + 1, 12)]))
+    for jj in rows:
+        slab = {nm: F[nm].data[jj - 2:jj + 1, :].cpu().numpy() for nm in names[:6]}      # rows jj-1, jj, jj+1
+        want = [np.full_like(slab["u"], 9.0) for _ in range(3)]
+        O.sw_step(prm, g.nx, (it.xstart, it.xstop, 2, 2), *[slab[nm] for nm in names[:6]], *want)
+        for nm, w in zip(names[6:], want):
+            got = F[nm].data[jj - 1, :].cpu().numpy()
+            assert np.array_equal(got, w[1]), (nm, jj)
+    for nm in names[6:]:
+        d = F[nm].data
+        assert bool((d[0, :] == 9.0).all()) and bool((d[it.ystop:, :] == 9.0).all()), nm
+        assert bool((d[:, 0] == 9.0).all()) and bool((d[:, it.xstop:] == 9.0).all()), nm
+
+
 @pytest.mark.parametrize("nx,ny", [(1, 1), (2, 2), (1, 6), (6, 1), (3, 3), (130, 5), (5, 130), (257, 64)])
 def test_distributed_step_on_small_and_ragged_boxes(D, nx, ny):
     """dlesm_jacobi5_step_dm (frame + side-stream exchange + interior) == stencil followed by the

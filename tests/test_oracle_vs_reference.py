@@ -220,3 +220,77 @@ def test_fortran_psy_loops_equal_the_c_oracle():
             got = np.full_like(a, -7.0)
             O.jacobi5_fortran(a, got, ld, *box, threads=threads)
             assert np.array_equal(got, want), (ny, ld, box, threads)
+
+
+# --------------------------------------------------------------------------- shallow water (S9)
+@pytest.mark.parametrize("nx,ny,ld_extra", [(37, 23, 0), (64, 48, 1), (5, 4, 0), (1, 1, 2), (130, 7, 3),
+                                            (200, 3, 0)])
+def test_sw_step_against_independent_numpy(nx, ny, ld_extra):
+    """PARITY UNPINNED by the reference (it has no stencil).  orc_sw_step -- per-point GOcean kernels
+    called from loop nests -- against tests/sw_numpy.py, a separately written whole-array evaluation of
+    DESIGN.md section 6: bit for bit, on even and odd leading dimensions, full and partial boxes."""
+    import sw_numpy as N
+    ld, nyarr = nx + 3 + ld_extra, ny + 3
+    rng = np.random.default_rng(nx * 1000 + ny)
+    prm = N.Params(1.0e5, 0.7e5, 90.0)                     # dx != dy: fsdx/fsdy and tdtsdx/tdtsdy not interchangeable
+    u, v, uold, vold = (rng.random((nyarr, ld)) - 0.5 for _ in range(4))
+    p, pold = (rng.random((nyarr, ld)) + 1.0 for _ in range(2))
+    boxes = [(2, nx + 1, 2, ny + 1)]
+    if nx > 8 and ny > 4:
+        boxes += [(3, nx - 2, 3, ny), (2, 2, 2, ny + 1), (nx + 1, nx + 1, 4, 4), (5, 4, 2, 3)]
+    for box in boxes:
+        want = [np.full((nyarr, ld), 9.0) for _ in range(3)]
+        got = [np.full((nyarr, ld), 9.0) for _ in range(3)]
+        N.sw_step_numpy(prm, box, u, v, p, uold, vold, pold, *want)
+        O.sw_step(prm, ld, box, u, v, p, uold, vold, pold, *got)
+        for name, g, w in zip(("unew", "vnew", "pnew"), got, want):
+            assert np.array_equal(g, w), (name, box)
+        xs, xe, ys, ye = box
+        if xe >= xs and ye >= ys:
+            inner = got[2][ys - 1:ye, xs - 1:xe]
+            assert np.all(inner != 9.0) and np.all(np.isfinite(inner))
+            got[2][ys - 1:ye, xs - 1:xe] = 9.0
+        assert np.all(got[2] == 9.0)                       # nothing outside the box is written
+
+
+def test_sw_constant_state_is_a_fixed_point():
+    """u = v = c, p = P everywhere: z = 0, h uniform, divergence 0 => new == old exactly"""
+    import sw_numpy as N
+    ld, nyarr, box = 40, 30, (2, 38, 2, 28)
+    prm = N.Params(1.0e5, 1.0e5, 90.0)
+    u = np.full((nyarr, ld), 0.25)
+    p = np.full((nyarr, ld), 1.5)
+    new = [np.full((nyarr, ld), 9.0) for _ in range(3)]
+    O.sw_step(prm, ld, box, u, u, p, u, u, p, *new)
+    assert np.all(new[0][1:28, 1:38] == 0.25) and np.all(new[1][1:28, 1:38] == 0.25)
+    assert np.all(new[2][1:28, 1:38] == 1.5)
+
+
+def test_sw_oracle_reproduces_numpy_golden():
+    """the committed multi-step golden (tests/golden/make_sw_golden.py, numpy path): 64x48, leapfrog
+    rotation, steps 1/5/10 -- every bit of u, v, p (sha256), exact abs-sums and samples"""
+    import sw_numpy as N
+    gold = load_golden("sw_numpy_64x48")
+    nx, ny, ld, nyarr = gold["nx"], gold["ny"], gold["ld"], gold["ny_arr"]
+    assert (ld, nyarr) == O.grid_extents(nx + 2, ny + 2)
+    box, whole = (2, nx + 1, 2, ny + 1), (1, nx + 2, 1, ny + 2)
+    prm = N.Params(gold["dx"], gold["dy"], gold["dt"])
+    cur, old, new = N.initial_state(O.hash_field, gold["seed"], nyarr, ld, whole)
+    seen = []
+
+    def step(c, o, n):
+        O.sw_step(prm, ld, box, *c, *o, *n)
+
+    def on_step(k, c):
+        rec = gold["steps"].get(str(k))
+        if rec is None:
+            return
+        seen.append(k)
+        for name, f in zip("uvp", c):
+            assert N.digest(f, box) == rec[name]["sha256"], (k, name)
+            assert N.abs_sum(f, box) == float.fromhex(rec[name]["abs_sum"]), (k, name)
+            for (i, j, hx) in rec[name]["samples"]:
+                assert f[j - 1, i - 1] == float.fromhex(hx), (k, name, i, j)
+
+    N.leapfrog(step, 10, cur, old, new, on_step)
+    assert seen == [1, 5, 10]
