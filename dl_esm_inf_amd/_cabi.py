@@ -13,6 +13,9 @@ MAXCOMM = 16
 UNIQUE_ID_BYTES = 128
 
 OK, EINVAL, ENODEV, EHIP, ERCCL, EABORT, ECOMMS = 0, -1, -2, -3, -4, -5, -12
+# dirs_mask of dlesm_halo_exchange_f64: bit d-1 per edge direction; 0 exchanges nothing
+DIRS_ALL, DIRS_NO_DIAGONALS = 0xF, 0x10
+DIRS_EDGES_ONLY = DIRS_ALL | DIRS_NO_DIAGONALS
 
 
 class DlesmError(RuntimeError):
@@ -117,6 +120,11 @@ PROTOTYPES = {
     "dlesm_comm_unique_id": (_i, [_vp]),
     "dlesm_comm_init": (_i, [_vp, _i, _i]),
     "dlesm_comm_finalize": (_i, []),
+    "dlesm_rendezvous_remove": (_i, [C.c_char_p]),
+    "dlesm_rendezvous_publish": (_i, [C.c_char_p, _vp, C.c_char_p]),
+    "dlesm_rendezvous_fetch": (_i, [C.c_char_p, _vp, C.c_char_p, _i]),
+    "dlesm_rendezvous_ack": (_i, [C.c_char_p, _i]),
+    "dlesm_rendezvous_wait_acks": (_i, [C.c_char_p, _i, _i]),
     "dlesm_comm_rank": (_i, []),
     "dlesm_comm_size": (_i, []),
     "dlesm_halo_plan_create": (_i, [C.POINTER(CommTables), _i, _i, C.POINTER(_vp)]),

@@ -40,18 +40,35 @@ using namespace dlesm;
                                  ncclGetErrorString(_r), __FILE__, __LINE__);               \
     } while (0)
 
+// Inside an open ncclGroupStart/ncclGroupEnd pair a failed call must not return at once: the
+// thread's group would stay open and swallow every later RCCL call.  Remember the first error,
+// skip the rest, and report after ncclGroupEnd.
+#define DLESM_NCCL_IN_GROUP(first_err, expr)                                                \
+    do {                                                                                    \
+        if ((first_err) == ncclSuccess) (first_err) = (expr);                               \
+    } while (0)
+
 static_assert(sizeof(ncclUniqueId) == DLESM_UNIQUE_ID_BYTES, "ncclUniqueId size");
 
 namespace {
 
 ncclComm_t g_comm = nullptr;
 int g_rank = -1, g_size = 0;
-hipEvent_t g_ev_frame = nullptr, g_ev_comm = nullptr;
 
 struct Strip { // one packed (strided) message
     int i0, j0, nx, ny; // 0-based origin and extent inside the field
     long off;           // offset (doubles) of its slot in the pack buffer
+    int dir;            // direction code, for masked exchanges
 };
+
+int group_end(ncclResult_t first_err, const char *what)
+{
+    const ncclResult_t end = ncclGroupEnd();
+    if (first_err != ncclSuccess)
+        return fail(DLESM_ERCCL, "%s: %s", what, ncclGetErrorString(first_err));
+    if (end != ncclSuccess) return fail(DLESM_ERCCL, "%s: ncclGroupEnd: %s", what, ncclGetErrorString(end));
+    return DLESM_OK;
+}
 
 struct Msg {
     int dir, peer;
@@ -71,14 +88,36 @@ struct dlesm_halo_plan {
     long sendbuf_len = 0, recvbuf_len = 0;   // doubles per field
     int buf_fields = 0;                      // fields the buffers currently have room for
     int max_strip = 0;
+    // frame-done / exchange-done events of the overlapped steps: per plan, so that two grids
+    // stepped on different streams never share one.  ONE exchange per plan may be in flight
+    // (its pack buffers are single): the steps below serialise on the caller's stream.
+    hipEvent_t ev_frame = nullptr, ev_comm = nullptr;
 };
 
+// edge directions follow their bit; diagonals follow their two edges (parallel_comms_mod.f90:
+// 1557-1571) unless DLESM_DIRS_NO_DIAGONALS is set.  mask 0 enables nothing, as there.
+__host__ __device__ static inline bool dir_enabled(unsigned mask, int dir)
+{
+    auto on = [&](int d) { return (mask >> (d - 1)) & 1u; };
+    if (dir >= 1 && dir <= 4) return on(dir);
+    if (mask & DLESM_DIRS_NO_DIAGONALS) return false;
+    switch (dir) {
+    case DLESM_IPLUSJPLUS: return on(DLESM_IPLUS) && on(DLESM_JPLUS);
+    case DLESM_IMINUSJMINUS: return on(DLESM_IMINUS) && on(DLESM_JMINUS);
+    case DLESM_IPLUSJMINUS: return on(DLESM_IPLUS) && on(DLESM_JMINUS);
+    case DLESM_IMINUSJPLUS: return on(DLESM_IMINUS) && on(DLESM_JPLUS);
+    default: return false;
+    }
+}
+
 // gather the strided strips into their slots: grid.y = strip, j outer / i inner
-// exactly like the pack loop of parallel_comms_mod.f90:1678-1683
+// exactly like the pack loop of parallel_comms_mod.f90:1678-1683; strips of a direction the
+// mask disables are skipped (their workgroups leave at once)
 __global__ void pack_strips(const double *__restrict__ f, int ld, const Strip *__restrict__ tab,
-                            double *__restrict__ buf)
+                            double *__restrict__ buf, unsigned mask)
 {
     const Strip s = tab[blockIdx.y];
+    if (!dir_enabled(mask, s.dir)) return;
     const long n = (long)s.nx * s.ny;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
         const int j = (int)(t / s.nx), i = (int)(t % s.nx);
@@ -86,21 +125,12 @@ __global__ void pack_strips(const double *__restrict__ f, int ld, const Strip *_
     }
 }
 
-// inverse, parallel_comms_mod.f90:1788-1793
+// inverse, parallel_comms_mod.f90:1788-1793; a masked-out direction leaves its halo untouched
 __global__ void unpack_strips(double *__restrict__ f, int ld, const Strip *__restrict__ tab,
-                              const double *__restrict__ buf)
+                              const double *__restrict__ buf, unsigned mask)
 {
     const Strip s = tab[blockIdx.y];
-    const long n = (long)s.nx * s.ny;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(t / s.nx), i = (int)(t % s.nx);
-        f[(size_t)(s.j0 + j) * ld + s.i0 + i] = buf[s.off + t];
-    }
-}
-
-// single strip passed by value: used for partial (masked) exchanges
-__global__ void unpack_one(double *__restrict__ f, int ld, Strip s, const double *__restrict__ buf)
-{
+    if (!dir_enabled(mask, s.dir)) return;
     const long n = (long)s.nx * s.ny;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
         const int j = (int)(t / s.nx), i = (int)(t % s.nx);
@@ -172,7 +202,7 @@ extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny
         Msg m{dir, peer, i1 - 1, j1 - 1, nx, nyy, (long)nx * nyy, -1};
         if (nyy > 1 && nx != ld) { // rows of the patch are not adjacent in memory
             m.off = buflen;
-            pk.push_back(Strip{m.i0, m.j0, nx, nyy, buflen});
+            pk.push_back(Strip{m.i0, m.j0, nx, nyy, buflen, dir});
             buflen += m.count;
             if (m.count > p->max_strip) p->max_strip = (int)m.count;
         }
@@ -210,6 +240,11 @@ extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny
         dlesm_halo_plan_destroy(p);
         return rc;
     }
+    if (hipEventCreateWithFlags(&p->ev_frame, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_comm, hipEventDisableTiming) != hipSuccess) {
+        dlesm_halo_plan_destroy(p);
+        return fail(DLESM_EHIP, "halo plan: hipEventCreate failed");
+    }
     *out = p;
     return DLESM_OK;
 }
@@ -222,21 +257,10 @@ extern "C" int dlesm_halo_plan_destroy(dlesm_halo_plan *p)
     if (p->d_rpack) (void)hipFree(p->d_rpack);
     if (p->sendbuf) (void)hipFree(p->sendbuf);
     if (p->recvbuf) (void)hipFree(p->recvbuf);
+    if (p->ev_frame) (void)hipEventDestroy(p->ev_frame);
+    if (p->ev_comm) (void)hipEventDestroy(p->ev_comm);
     delete p;
     return DLESM_OK;
-}
-
-static bool dir_enabled(unsigned mask, int dir)
-{
-    if (mask == 0) return true;
-    auto on = [&](int d) { return (mask >> (d - 1)) & 1u; };
-    switch (dir) { // diagonals follow their two edges, parallel_comms_mod.f90:1568-1571
-    case DLESM_IPLUSJPLUS: return on(DLESM_IPLUS) && on(DLESM_JPLUS);
-    case DLESM_IMINUSJMINUS: return on(DLESM_IMINUS) && on(DLESM_JMINUS);
-    case DLESM_IPLUSJMINUS: return on(DLESM_IPLUS) && on(DLESM_JMINUS);
-    case DLESM_IMINUSJPLUS: return on(DLESM_IMINUS) && on(DLESM_JPLUS);
-    default: return dir >= 1 && dir <= 4 && on(dir);
-    }
 }
 
 // Pack buffers hold one slot set per field of a multi-field exchange.
@@ -255,55 +279,53 @@ static int ensure_buffers(dlesm_halo_plan *p, int nfields)
 
 // The exchange of `nf` fields of the plan's shape in ONE grouped launch.  Between a pair of
 // ranks messages match in issue order: field-major, then ascending direction code, on both sides.
-static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsigned mask, hipStream_t s)
+// `prepacked`: the caller's kernel has already written the enabled strided strips of every field
+// into the send buffer (dlesm_jacobi5_step_dm's frame kernel does), so no pack launch is needed.
+static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsigned mask, hipStream_t s,
+                       bool prepacked = false)
 {
-    const bool any = !p->sends.empty() || !p->recvs.empty();
-    if (!any) return DLESM_OK; // serial run: nothing to do (pcomms:1546)
+    bool any = false, any_spack = false, any_rpack = false;
+    for (const Msg &m : p->sends)
+        if (dir_enabled(mask, m.dir)) { any = true; any_spack |= m.off >= 0; }
+    for (const Msg &m : p->recvs)
+        if (dir_enabled(mask, m.dir)) { any = true; any_rpack |= m.off >= 0; }
+    if (!any) return DLESM_OK; // serial run, or no direction enabled: nothing to do (pcomms:1546,1557-1571)
     DLESM_REQUIRE(g_comm != nullptr, "halo exchange before dlesm_comm_init");
     if (int rc = ensure_buffers(p, nf)) return rc;
     int gx = (p->max_strip + 255) / 256;
     if (gx > 64) gx = 64;
-    if (p->n_spack)
+    if (any_spack && !prepacked)
         for (int k = 0; k < nf; k++)
             hipLaunchKernelGGL(pack_strips, dim3(gx, p->n_spack), dim3(256), 0, s, fields[k], p->ld, p->d_spack,
-                               p->sendbuf + (size_t)k * p->sendbuf_len);
+                               p->sendbuf + (size_t)k * p->sendbuf_len, mask);
     DLESM_NCCL_TRY(ncclGroupStart());
+    ncclResult_t err = ncclSuccess;
     for (int k = 0; k < nf; k++) {
         double *f = fields[k];
         for (const Msg &m : p->recvs) {
             if (!dir_enabled(mask, m.dir)) continue;
             double *dst = m.off >= 0 ? p->recvbuf + (size_t)k * p->recvbuf_len + m.off : f + (size_t)m.j0 * p->ld + m.i0;
-            DLESM_NCCL_TRY(ncclRecv(dst, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
+            DLESM_NCCL_IN_GROUP(err, ncclRecv(dst, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
         }
         for (const Msg &m : p->sends) {
             if (!dir_enabled(mask, m.dir)) continue;
             const double *src = m.off >= 0 ? p->sendbuf + (size_t)k * p->sendbuf_len + m.off : f + (size_t)m.j0 * p->ld + m.i0;
-            DLESM_NCCL_TRY(ncclSend(src, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
+            DLESM_NCCL_IN_GROUP(err, ncclSend(src, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
         }
     }
-    DLESM_NCCL_TRY(ncclGroupEnd());
-    if (p->n_rpack)
-        for (int k = 0; k < nf; k++) {
-            const double *rb = p->recvbuf + (size_t)k * p->recvbuf_len;
-            // a masked-out direction leaves its halo untouched: unpack only what arrived
-            if (mask == 0) {
-                hipLaunchKernelGGL(unpack_strips, dim3(gx, p->n_rpack), dim3(256), 0, s, fields[k], p->ld, p->d_rpack, rb);
-            } else {
-                for (const Msg &m : p->recvs) {
-                    if (m.off < 0 || !dir_enabled(mask, m.dir)) continue;
-                    hipLaunchKernelGGL(unpack_one, dim3(gx, 1), dim3(256), 0, s, fields[k], p->ld,
-                                       Strip{m.i0, m.j0, m.nx, m.ny, m.off}, rb);
-                }
-            }
-        }
+    if (int rc = group_end(err, "halo exchange (ncclSend/ncclRecv)")) return rc;
+    if (any_rpack)
+        for (int k = 0; k < nf; k++)
+            hipLaunchKernelGGL(unpack_strips, dim3(gx, p->n_rpack), dim3(256), 0, s, fields[k], p->ld, p->d_rpack,
+                               p->recvbuf + (size_t)k * p->recvbuf_len, mask);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
 
-static int exchange_on(dlesm_halo_plan *p, double *f, unsigned mask, hipStream_t s)
+static int exchange_on(dlesm_halo_plan *p, double *f, unsigned mask, hipStream_t s, bool prepacked = false)
 {
     double *one[1] = {f};
-    return exchange_on(p, one, 1, mask, s);
+    return exchange_on(p, one, 1, mask, s, prepacked);
 }
 
 extern "C" int dlesm_halo_exchange_multi_f64(dlesm_halo_plan *p, double *const *fields, int nfields,
@@ -312,14 +334,14 @@ extern "C" int dlesm_halo_exchange_multi_f64(dlesm_halo_plan *p, double *const *
     DLESM_REQUIRE(p != nullptr && fields != nullptr && nfields >= 1 && nfields <= 16, "bad arguments");
     for (int k = 0; k < nfields; k++) DLESM_REQUIRE(fields[k] != nullptr, "null field %d", k);
     if (int rc = ensure_device()) return rc;
-    return exchange_on(p, fields, nfields, dirs_mask & 0xFu, (hipStream_t)stream);
+    return exchange_on(p, fields, nfields, dirs_mask & 0x1Fu, (hipStream_t)stream);
 }
 
 extern "C" int dlesm_halo_exchange_f64(dlesm_halo_plan *p, double *field, unsigned dirs_mask, void *stream)
 {
     DLESM_REQUIRE(p != nullptr && field != nullptr, "null pointer");
     if (int rc = ensure_device()) return rc;
-    return exchange_on(p, field, dirs_mask & 0xFu, (hipStream_t)stream);
+    return exchange_on(p, field, dirs_mask & 0x1Fu, (hipStream_t)stream);
 }
 
 extern "C" int dlesm_jacobi5_step_dm(dlesm_halo_plan *p, const double *in, double *out, int ld, int ny,
@@ -329,22 +351,42 @@ extern "C" int dlesm_jacobi5_step_dm(dlesm_halo_plan *p, const double *in, doubl
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
     if (int rc = ensure_device()) return rc;
     hipStream_t s = (hipStream_t)stream, side = side_stream();
-    if (!g_ev_frame) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_frame, hipEventDisableTiming));
-    if (!g_ev_comm) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_comm, hipEventDisableTiming));
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) // single tile: one launch over the whole box
         return launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s);
-    // 1. the frame of `out`: the only cells a neighbour will ask for
-    if (int rc = launch_stencil5_frame(in, out, ld, ny, xstart, xstop, ystart, ystop, s)) return rc;
-    DLESM_HIP_TRY(hipEventRecord(g_ev_frame, s));
+    // The 5-point stencil never reads a corner halo: exchange the four edge directions only
+    // (what passing just the needed comm directions does in the reference, pcomms:1557-1571).
+    // j5_dm_corners=1 keeps the diagonal messages (halos then equal a full halo_exchange).
+    const unsigned mask = tuning("j5_dm_corners", 0) ? DLESM_DIRS_ALL : (DLESM_DIRS_ALL | DLESM_DIRS_NO_DIAGONALS);
+    // 1. the frame of `out`: the only cells a neighbour will ask for.  The west/east columns are
+    //    strided in memory; the frame kernel drops each of their cells straight into its slot of
+    //    the send buffer as well, so no pack launch sits between the frame and the exchange.
+    FramePack fp{};
+    bool prepacked = tuning("j5_dm_frame_pack", 1) != 0;
+    for (const Msg &m : p->sends) {
+        if (m.off < 0 || !dir_enabled(mask, m.dir)) continue;
+        const bool on_frame = m.nx == 1 && (m.i0 == xstart - 1 || m.i0 == xstop - 1) && m.j0 >= ystart - 1 &&
+                              m.j0 + m.ny - 1 <= ystop - 1;
+        if (!on_frame || fp.n == FramePack::MAXS) { prepacked = false; break; }
+        fp.s[fp.n++] = FramePack::Col{m.i0, m.j0, m.ny, m.off};
+    }
+    if (prepacked && fp.n) {
+        if (int rc = ensure_buffers(p, 1)) return rc;
+        fp.buf = p->sendbuf;
+    } else {
+        fp.n = 0;
+    }
+    if (int rc = launch_stencil5_frame(in, out, ld, ny, xstart, xstop, ystart, ystop, s, prepacked ? &fp : nullptr))
+        return rc;
+    DLESM_HIP_TRY(hipEventRecord(p->ev_frame, s));
     // 2. exchange out's frame on the side stream ...
-    DLESM_HIP_TRY(hipStreamWaitEvent(side, g_ev_frame, 0));
-    if (int rc = exchange_on(p, out, 0, side)) return rc;
-    DLESM_HIP_TRY(hipEventRecord(g_ev_comm, side));
+    DLESM_HIP_TRY(hipStreamWaitEvent(side, p->ev_frame, 0));
+    if (int rc = exchange_on(p, out, mask, side, prepacked)) return rc;
+    DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
     // 3. ... while the interior streams through HBM on the caller's stream
     if (int rc = launch_stencil5(in, out, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, s)) return rc;
     // 4. join: the next step reads out's halos
-    DLESM_HIP_TRY(hipStreamWaitEvent(s, g_ev_comm, 0));
+    DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
     return DLESM_OK;
 }
 
@@ -382,12 +424,10 @@ extern "C" int dlesm_jacobi5_multi_step_dm(dlesm_halo_plan *p, const double *in,
     };
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) return box(xstart, xstop, ystart, ystop);
-    if (!g_ev_frame) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_frame, hipEventDisableTiming));
-    if (!g_ev_comm) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_comm, hipEventDisableTiming));
     const int ix0 = xstart + hasW * T, ix1 = xstop - hasE * T, iy0 = ystart + hasS * T, iy1 = ystop - hasN * T;
     if (ix1 < ix0 || iy1 < iy0) { // the tile is all frame: no interior to hide the exchange behind
         if (int rc = box(xstart, xstop, ystart, ystop)) return rc;
-        return exchange_on(p, out, 0, s);
+        return exchange_on(p, out, DLESM_DIRS_ALL, s);
     }
     // 1. frame: the T-deep strips along the sides that have a neighbour
     if (hasS)
@@ -398,14 +438,14 @@ extern "C" int dlesm_jacobi5_multi_step_dm(dlesm_halo_plan *p, const double *in,
         if (int rc = box(xstart, ix0 - 1, iy0, iy1)) return rc;
     if (hasE)
         if (int rc = box(ix1 + 1, xstop, iy0, iy1)) return rc;
-    DLESM_HIP_TRY(hipEventRecord(g_ev_frame, s));
+    DLESM_HIP_TRY(hipEventRecord(p->ev_frame, s));
     // 2. exchange of out's frame on the side stream ...
-    DLESM_HIP_TRY(hipStreamWaitEvent(side, g_ev_frame, 0));
-    if (int rc = exchange_on(p, out, 0, side)) return rc;
-    DLESM_HIP_TRY(hipEventRecord(g_ev_comm, side));
+    DLESM_HIP_TRY(hipStreamWaitEvent(side, p->ev_frame, 0));
+    if (int rc = exchange_on(p, out, DLESM_DIRS_ALL, side)) return rc;
+    DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
     // 3. ... behind the interior
     if (int rc = box(ix0, ix1, iy0, iy1)) return rc;
-    DLESM_HIP_TRY(hipStreamWaitEvent(s, g_ev_comm, 0));
+    DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
     return DLESM_OK;
 }
 
@@ -428,8 +468,6 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     };
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) return box(xstart, xstop, ystart, ystop);
-    if (!g_ev_frame) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_frame, hipEventDisableTiming));
-    if (!g_ev_comm) DLESM_HIP_TRY(hipEventCreateWithFlags(&g_ev_comm, hipEventDisableTiming));
     // 1. frame: south row, north row, west column, east column (empty boxes are no-ops)
     if (int rc = box(xstart, xstop, ystart, ystart)) return rc;
     if (ystop > ystart)
@@ -437,15 +475,15 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     if (int rc = box(xstart, xstart, ystart + 1, ystop - 1)) return rc;
     if (xstop > xstart)
         if (int rc = box(xstop, xstop, ystart + 1, ystop - 1)) return rc;
-    DLESM_HIP_TRY(hipEventRecord(g_ev_frame, s));
+    DLESM_HIP_TRY(hipEventRecord(p->ev_frame, s));
     // 2. grouped exchange of the three new fields on the side stream ...
-    DLESM_HIP_TRY(hipStreamWaitEvent(side, g_ev_frame, 0));
+    DLESM_HIP_TRY(hipStreamWaitEvent(side, p->ev_frame, 0));
     double *fields[3] = {unew, vnew, pnew};
-    if (int rc = exchange_on(p, fields, 3, 0, side)) return rc;
-    DLESM_HIP_TRY(hipEventRecord(g_ev_comm, side));
+    if (int rc = exchange_on(p, fields, 3, DLESM_DIRS_ALL, side)) return rc;
+    DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
     // 3. ... behind the interior
     if (int rc = box(xstart + 1, xstop - 1, ystart + 1, ystop - 1)) return rc;
-    DLESM_HIP_TRY(hipStreamWaitEvent(s, g_ev_comm, 0));
+    DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
     return DLESM_OK;
 }
 
@@ -478,12 +516,13 @@ extern "C" int dlesm_gather_f64(const double *send, double *recv, int n)
     // MPI_Gather to root 0 (parallel_utils_mod.f90:242-255) as grouped send/recv
     DLESM_REQUIRE(g_rank != 0 || recv != nullptr, "null receive buffer on root");
     DLESM_NCCL_TRY(ncclGroupStart());
+    ncclResult_t err = ncclSuccess;
     if (g_rank == 0) {
         for (int r = 0; r < g_size; r++)
-            DLESM_NCCL_TRY(ncclRecv(recv + (size_t)r * n, (size_t)n, ncclDouble, r, g_comm, s));
+            DLESM_NCCL_IN_GROUP(err, ncclRecv(recv + (size_t)r * n, (size_t)n, ncclDouble, r, g_comm, s));
     }
-    DLESM_NCCL_TRY(ncclSend(send, (size_t)n, ncclDouble, 0, g_comm, s));
-    DLESM_NCCL_TRY(ncclGroupEnd());
+    DLESM_NCCL_IN_GROUP(err, ncclSend(send, (size_t)n, ncclDouble, 0, g_comm, s));
+    if (int rc = group_end(err, "gather (ncclSend/ncclRecv)")) return rc;
     DLESM_HIP_TRY(hipStreamSynchronize(s));
     return DLESM_OK;
 }

@@ -69,8 +69,16 @@ __device__ __forceinline__ double from_upper(double x)
 // shared by the frame/interior split of the distributed step (dlesm_halo.hip)
 int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, int xstop,
                     int ystart, int ystop, hipStream_t s);
+// columns of the frame that are also send strips: the frame kernel writes their cells into
+// the halo plan's send buffer as it computes them (no separate pack launch)
+struct FramePack {
+    static constexpr int MAXS = 4;
+    struct Col { int i, j0, nj; long off; } s[MAXS]; // 0-based column, first row, rows, slot offset
+    int n;
+    double *buf;
+};
 int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop,
-                          int ystart, int ystop, hipStream_t s);
+                          int ystart, int ystop, hipStream_t s, const FramePack *pack = nullptr);
 
 // nsteps fused Jacobi steps (dlesm_jacobi_x2.hip); 1-based inclusive output box, last stage box,
 // grow flags -- see dlesm_stencil5_multi_f64

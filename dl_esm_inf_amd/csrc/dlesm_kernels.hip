@@ -440,7 +440,7 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
 // the cells whose values neighbours need first in the distributed step.
 __global__ __launch_bounds__(256) void jacobi5_frame(const double *__restrict__ in,
                                                      double *__restrict__ out, int ld, int x0, int x1,
-                                                     int y0, int y1)
+                                                     int y0, int y1, FramePack pk)
 {
     const int w = x1 - x0 + 1, h = y1 - y0 + 1;
     const int ncol = h > 2 ? h - 2 : 0;
@@ -458,7 +458,13 @@ __global__ __launch_bounds__(256) void jacobi5_frame(const double *__restrict__ 
             else { i = k < ncol ? x0 : x1; j = y0 + 1 + (int)(k % ncol); }
         }
         const size_t o = (size_t)j * ld + i;
-        out[o] = 0.25 * ((in[o - 1] + in[o + 1]) + (in[o - ld] + in[o + ld]));
+        const double r = 0.25 * ((in[o - 1] + in[o + 1]) + (in[o - ld] + in[o + ld]));
+        out[o] = r;
+        // a west/east frame column that a neighbour will receive: also into its send-buffer slot,
+        // in the j order of the pack loop (parallel_comms_mod.f90:1678-1683)
+        for (int k = 0; k < pk.n; k++)
+            if (i == pk.s[k].i && j >= pk.s[k].j0 && j < pk.s[k].j0 + pk.s[k].nj)
+                pk.buf[pk.s[k].off + (j - pk.s[k].j0)] = r;
     }
 }
 
@@ -591,15 +597,17 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
 }
 
 int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop,
-                          int ystart, int ystop, hipStream_t s)
+                          int ystart, int ystop, hipStream_t s, const FramePack *pack)
 {
     if (xstop < xstart || ystop < ystart) return DLESM_OK;
     if (int rc = check_box("stencil5 frame", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     const long cells = 2L * (xstop - xstart + 1) + 2L * (ystop - ystart + 1);
     int blocks = (int)((cells + 255) / 256);
     if (blocks > 1024) blocks = 1024;
+    FramePack pk{};
+    if (pack) pk = *pack;
     hipLaunchKernelGGL(jacobi5_frame, dim3(blocks), dim3(256), 0, s, in, out, ld, xstart - 1, xstop - 1,
-                       ystart - 1, ystop - 1);
+                       ystart - 1, ystop - 1, pk);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }

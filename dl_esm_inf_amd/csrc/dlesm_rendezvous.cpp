@@ -1,0 +1,195 @@
+// File rendezvous for the RCCL unique id: how a Fortran (or any non-torch) job of N processes,
+// started by whatever launcher exported RANK/WORLD_SIZE, hands rank 0's ncclUniqueId to the
+// others without MPI.  It replaces what MPI_Init gives the reference for free
+// (parallel/parallel_utils_mod.f90:77-90).  Host code only: no HIP call, no child process
+// (nothing may fork/exec once the GPU is initialised), testable on a machine without a GPU.
+//
+// Record (256 bytes, written to <path>.tmp.<pid> and published with rename(2), so a reader sees
+// all of it or none):
+//     0  "DLESMRV1"
+//     8  int64   start time of the publishing process, seconds since the epoch
+//    16  char[112] job token, NUL padded  ("<world size>:<launcher run id>")
+//   128  char[128] ncclUniqueId
+// A file left behind by a dead job is rejected twice over: its token differs when the launcher
+// provides a run id, and its publisher did not start within `slack` seconds of the reader (the
+// ranks of one job start together; DLESM_RENDEZVOUS_SLACK_S, default 120).  Rank 0 also removes
+// whatever it finds under the name before it creates the new id.
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "dlesm_error.h"
+#include "dlesm_hip.h"
+
+using dlesm::fail;
+
+#define DLESM_REQUIRE(cond, ...)                                                            \
+    do {                                                                                    \
+        if (!(cond)) return ::dlesm::fail(DLESM_EINVAL, __VA_ARGS__);                       \
+    } while (0)
+
+namespace {
+
+constexpr char MAGIC[8] = {'D', 'L', 'E', 'S', 'M', 'R', 'V', '1'};
+constexpr int TOKEN_BYTES = 112, RECORD_BYTES = 256;
+
+// start of this process in epoch seconds: btime (/proc/stat) + starttime ticks (/proc/self/stat
+// field 22); the time the library was loaded if /proc cannot be read
+long long process_start()
+{
+    static long long cached = 0;
+    if (cached) return cached;
+    long long btime = 0, ticks = -1;
+    if (FILE *f = fopen("/proc/stat", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f))
+            if (sscanf(line, "btime %lld", &btime) == 1) break;
+        fclose(f);
+    }
+    if (FILE *f = fopen("/proc/self/stat", "r")) {
+        char buf[2048];
+        size_t n = fread(buf, 1, sizeof buf - 1, f);
+        fclose(f);
+        buf[n] = 0;
+        if (char *p = strrchr(buf, ')')) { // the command name may contain spaces
+            int field = 2;
+            for (char *tok = strtok(p + 1, " "); tok; tok = strtok(nullptr, " "))
+                if (++field == 22) { ticks = atoll(tok); break; }
+        }
+    }
+    const long hz = sysconf(_SC_CLK_TCK);
+    cached = (btime > 0 && ticks >= 0 && hz > 0) ? btime + ticks / hz : (long long)time(nullptr);
+    return cached;
+}
+
+long long slack_seconds()
+{
+    if (const char *e = getenv("DLESM_RENDEZVOUS_SLACK_S")) {
+        const long long v = atoll(e);
+        if (v > 0) return v;
+    }
+    return 120;
+}
+
+} // namespace
+
+extern "C" int dlesm_rendezvous_remove(const char *path)
+{
+    DLESM_REQUIRE(path != nullptr && path[0], "rendezvous: empty path");
+    if (unlink(path) != 0 && errno != ENOENT)
+        return fail(DLESM_EINVAL, "rendezvous: cannot remove %s: %s", path, strerror(errno));
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_rendezvous_publish(const char *path, const void *id, const char *token)
+{
+    DLESM_REQUIRE(path != nullptr && path[0] && id != nullptr && token != nullptr, "rendezvous: bad arguments");
+    DLESM_REQUIRE(strlen(token) < (size_t)TOKEN_BYTES, "rendezvous: token longer than %d bytes", TOKEN_BYTES - 1);
+    char rec[RECORD_BYTES];
+    memset(rec, 0, sizeof rec);
+    memcpy(rec, MAGIC, 8);
+    const long long t0 = process_start();
+    memcpy(rec + 8, &t0, 8);
+    strncpy(rec + 16, token, TOKEN_BYTES - 1);
+    memcpy(rec + 128, id, DLESM_UNIQUE_ID_BYTES);
+    char tmp[4096];
+    const int n = snprintf(tmp, sizeof tmp, "%s.tmp.%ld", path, (long)getpid());
+    DLESM_REQUIRE(n > 0 && (size_t)n < sizeof tmp, "rendezvous: path too long");
+    const int fd = open(tmp, O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    if (fd < 0) return fail(DLESM_EINVAL, "rendezvous: cannot create %s: %s", tmp, strerror(errno));
+    const ssize_t w = write(fd, rec, sizeof rec);
+    const int sync_rc = fsync(fd), close_rc = close(fd);
+    if (w != (ssize_t)sizeof rec || sync_rc != 0 || close_rc != 0) {
+        unlink(tmp);
+        return fail(DLESM_EINVAL, "rendezvous: short write to %s: %s", tmp, strerror(errno));
+    }
+    if (rename(tmp, path) != 0) {
+        const int e = errno;
+        unlink(tmp);
+        return fail(DLESM_EINVAL, "rendezvous: rename %s -> %s: %s", tmp, path, strerror(e));
+    }
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_rendezvous_fetch(const char *path, void *id, const char *token, int timeout_ms)
+{
+    DLESM_REQUIRE(path != nullptr && path[0] && id != nullptr && token != nullptr, "rendezvous: bad arguments");
+    const long long mine = process_start(), slack = slack_seconds();
+    char why[256] = "no file appeared";
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        const int fd = open(path, O_RDONLY);
+        if (fd >= 0) {
+            char rec[RECORD_BYTES];
+            const ssize_t r = read(fd, rec, sizeof rec);
+            close(fd);
+            long long theirs = 0;
+            if (r == (ssize_t)sizeof rec && memcmp(rec, MAGIC, 8) == 0) {
+                memcpy(&theirs, rec + 8, 8);
+                rec[16 + TOKEN_BYTES - 1] = 0;
+                const long long apart = theirs > mine ? theirs - mine : mine - theirs;
+                if (strcmp(rec + 16, token) != 0)
+                    snprintf(why, sizeof why, "stale file: job token '%.60s', this job is '%.60s'", rec + 16, token);
+                else if (apart > slack)
+                    snprintf(why, sizeof why, "stale file: its publisher started %lld s apart from this process "
+                             "(limit %lld, DLESM_RENDEZVOUS_SLACK_S)", apart, slack);
+                else {
+                    memcpy(id, rec + 128, DLESM_UNIQUE_ID_BYTES);
+                    return DLESM_OK;
+                }
+            } else {
+                snprintf(why, sizeof why, "not a rendezvous record (%zd bytes)", r);
+            }
+        }
+        struct timespec now;
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        const long long waited = (now.tv_sec - t0.tv_sec) * 1000LL + (now.tv_nsec - t0.tv_nsec) / 1000000LL;
+        if (waited >= timeout_ms) break;
+        const struct timespec nap = {0, 10 * 1000 * 1000}; // 10 ms, sleeping (no busy wait)
+        nanosleep(&nap, nullptr);
+    }
+    return fail(DLESM_EINVAL, "rendezvous: no usable RCCL id at %s after %d ms (%s)", path, timeout_ms, why);
+}
+
+// Dry runs (DLESM_DRY_COMMS=2) create no communicator, so nothing holds rank 0 back until the
+// others have read the record (with RCCL, ncclCommInitRank does).  Readers acknowledge with an
+// empty file <path>.ack.<rank>; rank 0 waits for all of them and removes them.
+extern "C" int dlesm_rendezvous_ack(const char *path, int rank0)
+{
+    DLESM_REQUIRE(path != nullptr && path[0] && rank0 > 0, "rendezvous: bad arguments");
+    char name[4096];
+    const int n = snprintf(name, sizeof name, "%s.ack.%d", path, rank0);
+    DLESM_REQUIRE(n > 0 && (size_t)n < sizeof name, "rendezvous: path too long");
+    const int fd = open(name, O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    if (fd < 0) return fail(DLESM_EINVAL, "rendezvous: cannot create %s: %s", name, strerror(errno));
+    close(fd);
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_rendezvous_wait_acks(const char *path, int nranks, int timeout_ms)
+{
+    DLESM_REQUIRE(path != nullptr && path[0] && nranks >= 1, "rendezvous: bad arguments");
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 1; r < nranks; r++) {
+        char name[4096];
+        snprintf(name, sizeof name, "%s.ack.%d", path, r);
+        for (;;) {
+            if (unlink(name) == 0) break;
+            struct timespec now;
+            clock_gettime(CLOCK_MONOTONIC, &now);
+            const long long waited = (now.tv_sec - t0.tv_sec) * 1000LL + (now.tv_nsec - t0.tv_nsec) / 1000000LL;
+            if (waited >= timeout_ms)
+                return fail(DLESM_EINVAL, "rendezvous: rank %d did not pick up the id within %d ms", r, timeout_ms);
+            const struct timespec nap = {0, 10 * 1000 * 1000};
+            nanosleep(&nap, nullptr);
+        }
+    }
+    return DLESM_OK;
+}

@@ -30,6 +30,12 @@ static int g_device = -1;
 static hipStream_t g_side = nullptr, g_xfer = nullptr;
 static std::map<std::string, int> g_tuning;
 
+static int tuning_nolock(const char *key, int fallback)
+{
+    auto it = g_tuning.find(key);
+    return it == g_tuning.end() ? fallback : it->second;
+}
+
 static int bind_device(int device)
 {
     int n = 0;
@@ -41,7 +47,13 @@ static int bind_device(int device)
     }
     if (device < 0 || device >= n) return fail(DLESM_EINVAL, "device %d out of range [0,%d)", device, n);
     DLESM_HIP_TRY(hipSetDevice(device));
-    if (!g_side) DLESM_HIP_TRY(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    if (!g_side) {
+        // the exchange must not queue behind the interior sweep it hides under: highest priority
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        const int prio = tuning_nolock("side_stream_priority", 1) ? hi : 0;
+        DLESM_HIP_TRY(hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, prio));
+    }
     if (!g_xfer) DLESM_HIP_TRY(hipStreamCreateWithFlags(&g_xfer, hipStreamNonBlocking));
     g_device = device;
     g_ready = true;

@@ -78,10 +78,12 @@ class r2d_field:
         return 0
 
     # -- halo exchange -----------------------------------------------------
-    def halo_exchange(self, depth=1, stream=None):
-        """halo_exchange (field_mod.f90:1231-1256); depth is ignored as in the reference"""
+    def halo_exchange(self, depth=1, stream=None, dirs=_cabi.DIRS_ALL):
+        """halo_exchange (field_mod.f90:1231-1256); depth is ignored as in the reference.  `dirs`:
+        the enabled comm directions (bit d-1 for Iplus..Jminus, exchange_generic's comm1..comm4);
+        default all four, hence all diagonals, as field_mod.f90:1247-1248"""
         plan = grid_mod.halo_plan(self.grid)
-        check(_cabi.lib().dlesm_halo_exchange_f64(plan, self.device_ptr, 0, _stream_ptr(stream)))
+        check(_cabi.lib().dlesm_halo_exchange_f64(plan, self.device_ptr, dirs, _stream_ptr(stream)))
 
     def gather_inner_data(self):
         """gather_inner_data (field_mod.f90:1313-1390): global (ny, nx) array on rank 1, else None"""

@@ -10,6 +10,8 @@ module dlesm_hip_mod
        DLESM_EHIP = -3, DLESM_ERCCL = -4, DLESM_EABORT = -5, DLESM_ECOMMS = -12
   integer, parameter :: DLESM_MAXCOMM = 16
   integer, parameter :: DLESM_UNIQUE_ID_BYTES = 128
+  !> dirs_mask values of dlesm_halo_exchange_f64 (include/dlesm_hip.h)
+  integer(c_int), parameter :: DLESM_DIRS_ALL = 15_c_int, DLESM_DIRS_NO_DIAGONALS = 16_c_int
 
   !> struct dlesm_region
   type, bind(C) :: c_region
@@ -200,6 +202,37 @@ module dlesm_hip_mod
      function dlesm_comm_unique_id(id) bind(C, name="dlesm_comm_unique_id") result(rc)
        import :: c_int, c_char
        character(kind=c_char), intent(out) :: id(*)
+       integer(c_int) :: rc
+     end function
+     function dlesm_rendezvous_remove(path) bind(C, name="dlesm_rendezvous_remove") result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), intent(in) :: path(*)
+       integer(c_int) :: rc
+     end function
+     function dlesm_rendezvous_publish(path, id, token) bind(C, name="dlesm_rendezvous_publish") result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), intent(in) :: path(*), id(*), token(*)
+       integer(c_int) :: rc
+     end function
+     function dlesm_rendezvous_fetch(path, id, token, timeout_ms) &
+          bind(C, name="dlesm_rendezvous_fetch") result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), intent(in) :: path(*), token(*)
+       character(kind=c_char), intent(out) :: id(*)
+       integer(c_int), value :: timeout_ms
+       integer(c_int) :: rc
+     end function
+     function dlesm_rendezvous_ack(path, rank0) bind(C, name="dlesm_rendezvous_ack") result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), intent(in) :: path(*)
+       integer(c_int), value :: rank0
+       integer(c_int) :: rc
+     end function
+     function dlesm_rendezvous_wait_acks(path, nranks, timeout_ms) &
+          bind(C, name="dlesm_rendezvous_wait_acks") result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), intent(in) :: path(*)
+       integer(c_int), value :: nranks, timeout_ms
        integer(c_int) :: rc
      end function
      function dlesm_comm_init(id, nranks, rank0) bind(C, name="dlesm_comm_init") result(rc)

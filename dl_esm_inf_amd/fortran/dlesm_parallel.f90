@@ -20,6 +20,7 @@ module parallel_utils_mod
   integer :: local_rank = 0
   logical :: comm_up = .false.
   character(len=512) :: rendezvous_file = ''
+  logical :: publishing = .false.   !< this rank wrote the rendezvous file and must remove it
 
   integer, parameter :: MSG_UNDEFINED = -99
   integer, parameter :: MSG_REQUEST_NULL = 0
@@ -59,6 +60,14 @@ contains
     env_set = (stat == 0 .and. len_trim(buf) > 0 .and. trim(buf) /= '0')
   end function env_set
 
+  logical function env_is(name, value)
+    character(len=*), intent(in) :: name, value
+    character(len=8) :: buf
+    integer :: stat
+    call get_environment_variable(name, buf, status=stat)
+    env_is = (stat == 0 .and. trim(buf) == value)
+  end function env_is
+
   !> Ranks come from the process launcher (torchrun, mpirun, srun: whatever exported them),
   !! one process per GPU; the device is chosen from the node-local rank (the HIP counterpart
   !! of acc_init in the reference's gocean_initialise).
@@ -85,18 +94,27 @@ contains
        rc = dlesm_init(int(mod(local_rank, ndev), c_int))
        if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
     end if
-    ! DLESM_DRY_COMMS: keep the rank bookkeeping (decomposition, message tables) but create
-    ! no communicator -- used to inspect tables on machines without GPUs.
-    if (nranks > 1 .and. .not. env_set('DLESM_DRY_COMMS')) call bootstrap_rccl()
+    ! DLESM_DRY_COMMS: keep the rank bookkeeping (decomposition, message tables) but create no
+    ! communicator -- used to inspect tables on machines without GPUs.  DLESM_DRY_COMMS=2 runs
+    ! the file rendezvous of the id too (with a blank id), which is how the bootstrap is tested
+    ! without GPUs.
+    if (nranks > 1 .and. (.not. env_set('DLESM_DRY_COMMS') .or. env_is('DLESM_DRY_COMMS', '2'))) &
+         call bootstrap_rccl()
   end subroutine parallel_init
 
   !> Rank 0 creates the RCCL unique id and publishes it through a file (default in /dev/shm,
-  !! keyed by MASTER_PORT); the others wait for it. No MPI is needed.
+  !! keyed by MASTER_PORT); the others wait for it. No MPI is needed -- this is what MPI_Init
+  !! does for the reference (parallel/parallel_utils_mod.f90:77-90).  The record carries a job
+  !! token (world size + the launcher's run id when it exports one) and the publisher's start
+  !! time; readers ignore records of other jobs, so a file left by a dead job cannot feed an
+  !! old id to ncclCommInitRank.  Publishing is an in-process write + rename(2) inside
+  !! libdlesm_hip.so: no child process is started once the GPU is initialised.
   subroutine bootstrap_rccl()
     character(kind=c_char) :: id(DLESM_UNIQUE_ID_BYTES)
     character(len=16) :: port
-    integer :: stat, unit, tries, ios
-    logical :: there
+    character(len=64) :: runid
+    character(len=112) :: token
+    integer :: stat, timeout_s
     integer(c_int) :: rc
     call get_environment_variable('DLESM_RENDEZVOUS', rendezvous_file, status=stat)
     if (stat /= 0 .or. len_trim(rendezvous_file) == 0) then
@@ -104,52 +122,75 @@ contains
        if (stat /= 0 .or. len_trim(port) == 0) port = 'default'
        rendezvous_file = '/dev/shm/dlesm_rccl_id_' // trim(port)
     end if
+    runid = env_str([character(len=24) :: 'DLESM_JOB_ID', 'TORCHELASTIC_RUN_ID', 'SLURM_JOB_ID', &
+                     'PBS_JOBID', 'LSB_JOBID'], '-')
+    write (token, "(I0,':',A)") nranks, trim(runid)
+    timeout_s = env_int([character(len=28) :: 'DLESM_RENDEZVOUS_TIMEOUT_S'], 120)
     if (rank == 1) then
-       rc = dlesm_comm_unique_id(id)
+       rc = dlesm_rendezvous_remove(c_string(rendezvous_file))
        if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
-       open(newunit=unit, file=trim(rendezvous_file) // '.tmp', access='stream', &
-            form='unformatted', status='replace', action='write')
-       write(unit) id
-       close(unit)
-       call execute_command_line('mv -f ' // trim(rendezvous_file) // '.tmp ' // trim(rendezvous_file))
+       publishing = .true.
+       if (env_set('DLESM_DRY_COMMS')) then
+          id = c_null_char      ! table-inspection mode: exercise the rendezvous, create no communicator
+       else
+          rc = dlesm_comm_unique_id(id)
+          if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
+       end if
+       rc = dlesm_rendezvous_publish(c_string(rendezvous_file), id, c_string(token))
+       if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
     else
-       do tries = 1, 6000
-          inquire(file=trim(rendezvous_file), exist=there)
-          if (there) exit
-          call sleep_ms(20)
-       end do
-       if (.not. there) call parallel_abort('parallel_init: no RCCL id at ' // trim(rendezvous_file))
-       open(newunit=unit, file=trim(rendezvous_file), access='stream', form='unformatted', &
-            status='old', action='read')
-       read(unit, iostat=ios) id
-       close(unit)
-       if (ios /= 0) call parallel_abort('parallel_init: short RCCL id file')
+       rc = dlesm_rendezvous_fetch(c_string(rendezvous_file), id, c_string(token), &
+                                   int(timeout_s * 1000, c_int))
+       if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
+    end if
+    if (env_set('DLESM_DRY_COMMS')) then
+       ! no ncclCommInitRank to keep rank 0 here until everybody has read the record
+       if (rank == 1) then
+          rc = dlesm_rendezvous_wait_acks(c_string(rendezvous_file), int(nranks, c_int), &
+                                          int(timeout_s * 1000, c_int))
+       else
+          rc = dlesm_rendezvous_ack(c_string(rendezvous_file), int(rank - 1, c_int))
+       end if
+       if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
+       return
     end if
     rc = dlesm_comm_init(id, int(nranks, c_int), int(rank - 1, c_int))
     if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
     comm_up = .true.
   end subroutine bootstrap_rccl
 
-  subroutine sleep_ms(ms)
-    integer, intent(in) :: ms
-    integer(8) :: t0, t1, rate
-    call system_clock(t0, rate)
-    do
-       call system_clock(t1)
-       if ((t1 - t0) * 1000_8 >= int(ms, 8) * rate) exit
+  !> NUL-terminated copy for the C side
+  function c_string(str) result(cs)
+    character(len=*), intent(in) :: str
+    character(kind=c_char) :: cs(len_trim(str) + 1)
+    integer :: i
+    do i = 1, len_trim(str)
+       cs(i) = str(i:i)
     end do
-  end subroutine sleep_ms
+    cs(len_trim(str) + 1) = c_null_char
+  end function c_string
+
+  !> First non-empty value among the named environment variables, else default
+  function env_str(names, default) result(val)
+    character(len=*), intent(in) :: names(:), default
+    character(len=64) :: val
+    integer :: i, stat
+    do i = 1, size(names)
+       call get_environment_variable(trim(names(i)), val, status=stat)
+       if (stat == 0 .and. len_trim(val) > 0) return
+    end do
+    val = default
+  end function env_str
 
   subroutine parallel_finalise()
     integer(c_int) :: rc
-    integer :: unit, ios
     if (comm_up) then
        rc = dlesm_comm_finalize()
        comm_up = .false.
-       if (rank == 1) then
-          open(newunit=unit, file=trim(rendezvous_file), status='old', iostat=ios)
-          if (ios == 0) close(unit, status='delete')
-       end if
+    end if
+    if (publishing) then
+       rc = dlesm_rendezvous_remove(c_string(rendezvous_file))
+       publishing = .false.
     end if
     rc = dlesm_finalize()
   end subroutine parallel_finalise
@@ -159,8 +200,11 @@ contains
   subroutine parallel_abort(msg)
     use iso_fortran_env, only: error_unit
     character(len=*), intent(in) :: msg
+    integer(c_int) :: rc
     write(error_unit, *) msg
     flush(error_unit)
+    ! do not leave this job's id file behind for the next job on the same port to trip over
+    if (publishing) rc = dlesm_rendezvous_remove(c_string(rendezvous_file))
     error stop 1
   end subroutine parallel_abort
 
@@ -433,6 +477,26 @@ contains
     end do
   end function dir_mask
 
+  !> enabled(dir) of the reference (:1557-1571): edges by their bit, diagonals when both edges are
+  logical function dir_enabled(mask, dir)
+    integer(c_int), intent(in) :: mask
+    integer, intent(in) :: dir
+    select case (dir)
+    case (Iplus, Iminus, Jplus, Jminus)
+       dir_enabled = btest(mask, dir - 1)
+    case (IplusJplus)
+       dir_enabled = btest(mask, Iplus - 1) .and. btest(mask, Jplus - 1)
+    case (IminusJminus)
+       dir_enabled = btest(mask, Iminus - 1) .and. btest(mask, Jminus - 1)
+    case (IplusJminus)
+       dir_enabled = btest(mask, Iplus - 1) .and. btest(mask, Jminus - 1)
+    case (IminusJplus)
+       dir_enabled = btest(mask, Iminus - 1) .and. btest(mask, Jplus - 1)
+    case default
+       dir_enabled = .false.
+    end select
+  end function dir_enabled
+
   !> Exchange the halos of a field that already lives on the device (raw device pointer).
   subroutine exchange_device(dev_data, ld, ny, comm1, comm2, comm3, comm4)
     type(c_ptr), intent(in) :: dev_data
@@ -474,16 +538,26 @@ contains
        if (rc /= 0) call parallel_abort('exchange_generic: ' // dlesm_error_text())
     end if
     mask = dir_mask(comm1, comm2, comm3, comm4)
+    if (mask == 0) return   ! no direction enabled: the reference posts nothing either (:1557-1571)
+    ! only the messages of enabled directions travel: host halos of a disabled direction must
+    ! not be overwritten with whatever the persistent scratch field holds
     do k = 1, nsend
+       if (.not. dir_enabled(mask, dirsend(k))) cycle
        call dlesm_write_to_device(c_loc(b2), scratch, int(isrcsend(k), c_int), int(jsrcsend(k), c_int), &
-                                  int(nxsend(k), c_int), int(nysend(k), c_int), logical(k == nsend, c_bool))
+                                  int(nxsend(k), c_int), int(nysend(k), c_int), .false._c_bool)
     end do
+    rc = dlesm_transfer_sync()
+    if (rc /= 0) call parallel_abort('exchange_generic: ' // dlesm_error_text())
     rc = dlesm_halo_exchange_f64(p, dlesm_field_data(scratch), mask, c_null_ptr)
     if (rc /= 0) call parallel_abort('exchange_generic: ' // dlesm_error_text())
+    if (hipDeviceSynchronize() /= 0) call parallel_abort('exchange_generic: device synchronisation failed')
     do k = 1, nrecv
+       if (.not. dir_enabled(mask, dirrecv(k))) cycle
        call dlesm_read_from_device(scratch, c_loc(b2), int(idesrecv(k), c_int), int(jdesrecv(k), c_int), &
-                                   int(nxrecv(k), c_int), int(nyrecv(k), c_int), logical(k == nrecv, c_bool))
+                                   int(nxrecv(k), c_int), int(nyrecv(k), c_int), .false._c_bool)
     end do
+    rc = dlesm_transfer_sync()
+    if (rc /= 0) call parallel_abort('exchange_generic: ' // dlesm_error_text())
   end subroutine exchange_generic
 
 end module parallel_comms_mod

@@ -212,7 +212,7 @@ contains
        call need_device(f3)
        ptrs(3) = field_device_data(f3);  n = 3
     end if
-    rc = dlesm_halo_exchange_multi_f64(halo_plan_for(f1%grid%nx, f1%grid%ny), ptrs, n, 0_c_int, c_null_ptr)
+    rc = dlesm_halo_exchange_multi_f64(halo_plan_for(f1%grid%nx, f1%grid%ny), ptrs, n, DLESM_DIRS_ALL, c_null_ptr)
     if (rc /= 0) call gocean_stop('halo_exchange_multi: ' // dlesm_error_text())
   end subroutine halo_exchange_multi
 

@@ -91,11 +91,11 @@ def invoke_shallow_step_dm(params, u, v, p, uold, vold, pold, unew, vnew, pnew, 
                                             pnew.device_ptr, _stream_ptr(stream)))
 
 
-def halo_exchange_multi(fields, stream=None):
+def halo_exchange_multi(fields, stream=None, dirs=_cabi.DIRS_ALL):
     """halo_exchange(1) of several fields of one grid in a single grouped RCCL launch"""
     g = fields[0].grid
     arr = (C.c_void_p * len(fields))(*[f.device_ptr.value for f in fields])
-    check(_cabi.lib().dlesm_halo_exchange_multi_f64(grid_mod.halo_plan(g), arr, len(fields), 0,
+    check(_cabi.lib().dlesm_halo_exchange_multi_f64(grid_mod.halo_plan(g), arr, len(fields), dirs,
                                                     _stream_ptr(stream)))
 
 

@@ -269,6 +269,21 @@ int dlesm_comm_finalize(void);
 int dlesm_comm_rank(void);   /* 0-based, -1 before init */
 int dlesm_comm_size(void);
 
+/* File rendezvous for the id (dl_esm_inf_amd/csrc/dlesm_rendezvous.cpp): what a job started by
+ * a launcher that only exports RANK/WORLD_SIZE uses instead of MPI_Init
+ * (parallel/parallel_utils_mod.f90:77-90).  Host only, no GPU needed.  Rank 0: remove(path),
+ * dlesm_comm_unique_id, publish(path, id, token) -- atomic (rename).  Others: fetch waits up to
+ * timeout_ms for a record whose job token matches and whose publisher started within
+ * DLESM_RENDEZVOUS_SLACK_S (default 120) seconds of the caller; anything else is a stale file
+ * of a dead job and is ignored.  token: at most 111 characters. */
+int dlesm_rendezvous_remove(const char *path);
+int dlesm_rendezvous_publish(const char *path, const void *id, const char *token);
+int dlesm_rendezvous_fetch(const char *path, void *id, const char *token, int timeout_ms);
+/* dry runs only (no communicator, hence no ncclCommInitRank to hold rank 0 until everybody has the
+ * id): readers acknowledge, rank 0 waits for nranks-1 acknowledgements and removes them */
+int dlesm_rendezvous_ack(const char *path, int rank0);
+int dlesm_rendezvous_wait_acks(const char *path, int nranks, int timeout_ms);
+
 /* Message plan for fields of shape (ld, ny): device copy of the tables, pack
  * buffers for the strided (east/west) strips.  One plan serves every field of
  * that shape (all dl_esm_inf fields share the grid's extents, field_mod.f90:327-333). */
@@ -279,8 +294,15 @@ int dlesm_halo_plan_destroy(dlesm_halo_plan *plan);
 
 /* halo_exchange(depth=1) of one device field: pack -> grouped ncclSend/ncclRecv
  * -> unpack, all enqueued on `stream`.  dirs_mask selects the enabled edge
- * directions (bit d-1 for DLESM_IPLUS..DLESM_JMINUS); diagonals are enabled
- * when both their edges are, parallel_comms_mod.f90:1557-1571.  0 means all. */
+ * directions (bit d-1 for DLESM_IPLUS..DLESM_JMINUS: the comm1..comm4 arguments of
+ * exchange_generic); diagonals are enabled when both their edges are,
+ * parallel_comms_mod.f90:1557-1571.  DLESM_DIRS_ALL is what halo_exchange passes
+ * (field_mod.f90:1247-1248); 0 exchanges nothing, as in the reference; halos of a
+ * disabled direction are left untouched.  DLESM_DIRS_NO_DIAGONALS (an extension)
+ * keeps the four corner messages off whatever the edges say: all a 5-point stencil needs.
+ * One exchange per plan may be in flight at a time (the pack buffers are the plan's). */
+#define DLESM_DIRS_ALL 0xFu
+#define DLESM_DIRS_NO_DIAGONALS 0x10u
 int dlesm_halo_exchange_f64(dlesm_halo_plan *plan, double *field, unsigned dirs_mask,
                             void *stream);
 
@@ -290,10 +312,13 @@ int dlesm_halo_exchange_multi_f64(dlesm_halo_plan *plan, double *const *fields, 
                                   unsigned dirs_mask, void *stream);
 
 /* One distributed Jacobi time step with the exchange hidden behind the
- * interior: frame(out) on `stream`, then [exchange(out) on the library's side
- * stream] || [interior(out) on `stream`], joined on `stream`.  On return
- * (asynchronously) `out` holds the new values AND valid depth-1 halos, i.e. it
- * is ready to be the `in` of the next step.  `in` must have valid halos. */
+ * interior: frame(out) on `stream` (its west/east columns written straight into the
+ * send buffer too), then [exchange(out) on the library's side stream] ||
+ * [interior(out) on `stream`], joined on `stream`.  On return (asynchronously)
+ * `out` holds the new values AND valid depth-1 EDGE halos (west, east, south, north:
+ * DLESM_DIRS_ALL | DLESM_DIRS_NO_DIAGONALS -- the 5-point stencil never reads a corner
+ * halo cell, so the corner messages are not sent), i.e. it is ready to be the `in` of
+ * the next step.  `in` must have valid edge halos. */
 int dlesm_jacobi5_step_dm(dlesm_halo_plan *plan, const double *in, double *out,
                           int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                           void *stream);

@@ -411,7 +411,36 @@ int orc_map_comms(const orc_decomp *d, const orc_subdomain *subs, int nranks, in
 /* exchange_generic for every rank at once: pack pcomms:1664-1691, unpack
  * pcomms:1773-1798; all four comm directions enabled as field:1247-1248 does,
  * hence all diagonals enabled too (pcomms:1568-1571). */
+static int orc_exchange_enabled(int nranks, double **fields, const int *ld, const orc_comms *comms,
+                                const int *enabled);
+
 int orc_exchange_all(int nranks, double **fields, const int *ld, const orc_comms *comms)
+{
+    const int enabled[9] = {0, 1, 1, 1, 1, 1, 1, 1, 1};
+    return orc_exchange_enabled(nranks, fields, ld, comms, enabled);
+}
+
+/* exchange_generic with an explicit choice of comm1..comm4 (pcomms:1557-1571): a direction is
+ * enabled when one of the four arguments names it; a diagonal when both its edges are.  With
+ * no_diagonals != 0 the diagonals stay off whatever the edges say -- no reference call does
+ * that; it states what the distributed 5-point step exchanges (edges only). */
+int orc_exchange_dirs(int nranks, double **fields, const int *ld, const orc_comms *comms,
+                      int comm1, int comm2, int comm3, int comm4, int no_diagonals)
+{
+    int enabled[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int c[4] = {comm1, comm2, comm3, comm4};
+    for (int k = 0; k < 4; k++)
+        if (c[k] >= 0 && c[k] <= 8) enabled[c[k]] = c[k] > 0;                    /* :1561-1564 */
+    enabled[5] = enabled[1] && enabled[3];                                       /* IplusJplus   :1568 */
+    enabled[6] = enabled[2] && enabled[4];                                       /* IminusJminus :1569 */
+    enabled[7] = enabled[1] && enabled[4];                                       /* IplusJminus  :1570 */
+    enabled[8] = enabled[2] && enabled[3];                                       /* IminusJplus  :1571 */
+    if (no_diagonals) enabled[5] = enabled[6] = enabled[7] = enabled[8] = 0;
+    return orc_exchange_enabled(nranks, fields, ld, comms, enabled);
+}
+
+static int orc_exchange_enabled(int nranks, double **fields, const int *ld, const orc_comms *comms,
+                                const int *enabled)
 {
     int unmatched = 0;
     /* stage every send buffer first (sendBuff(ic,isend) = b2(i,j), j outer / i inner) */
@@ -419,6 +448,7 @@ int orc_exchange_all(int nranks, double **fields, const int *ld, const orc_comms
     for (int r = 0; r < nranks; r++) {
         const orc_comms *c = &comms[r];
         for (int s = 0; s < c->nsend; s++) {
+            if (!enabled[c->dirsend[s]]) continue;                                /* :1639 */
             if (c->destination[s] < 0 || c->nxsend[s] <= 0) continue;            /* :1639-1640 */
             size_t n = (size_t)c->nxsend[s] * (size_t)c->nysend[s], ic = 0;
             double *b = (double *)malloc(n * sizeof(double));
@@ -434,6 +464,7 @@ int orc_exchange_all(int nranks, double **fields, const int *ld, const orc_comms
     for (int r = 0; r < nranks; r++) {
         const orc_comms *c = &comms[r];
         for (int q = 0; q < c->nrecv; q++) {
+            if (!enabled[c->dirrecv[q]]) continue;                                /* :1603 */
             if (c->source[q] < 0 || c->nxrecv[q] <= 0) continue;                 /* :1603-1604 */
             int src = c->source[q];
             const orc_comms *cs = &comms[src];

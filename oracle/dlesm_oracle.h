@@ -87,6 +87,10 @@ int orc_map_comms(const orc_decomp *d, const orc_subdomain *subs, int nranks, in
  * exactly what the MPI tags tag_orig+dir do (pcomms:1606,1647). Returns the
  * number of unmatched messages (0 on success). */
 int orc_exchange_all(int nranks, double **fields, const int *ld, const orc_comms *comms);
+/* the same with the reference's comm1..comm4 arguments (direction codes 1..4, 0 = unused);
+ * no_diagonals != 0 additionally switches the four corner messages off */
+int orc_exchange_dirs(int nranks, double **fields, const int *ld, const orc_comms *comms,
+                      int comm1, int comm2, int comm3, int comm4, int no_diagonals);
 
 /* field_mod.f90:1298-1302 (local part; SUM(ABS()) evaluated in j-outer,i-inner order) */
 double orc_checksum(const double *f, int ld, int xstart, int xstop, int ystart, int ystop);

@@ -52,7 +52,7 @@ def shifted_x(x, y):
 
 
 def exch_then_full(x, y):
-    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, 0, C.c_void_p(side.cuda_stream)))
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_EDGES_ONLY, C.c_void_p(side.cuda_stream)))
     full(x, y)
 
 

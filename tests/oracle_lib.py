@@ -82,6 +82,8 @@ def lib():
     L.orc_map_comms.restype = C.c_int
     L.orc_exchange_all.argtypes = [C.c_int, C.POINTER(C.c_void_p), pI, C.POINTER(Comms)]
     L.orc_exchange_all.restype = C.c_int
+    L.orc_exchange_dirs.argtypes = [C.c_int, C.POINTER(C.c_void_p), pI, C.POINTER(Comms)] + [C.c_int] * 5
+    L.orc_exchange_dirs.restype = C.c_int
     L.orc_checksum.argtypes = [_dp] + [C.c_int] * 5
     L.orc_checksum.restype = C.c_double
     L.orc_scatter.argtypes = [_dp, C.c_int, C.POINTER(Subdomain), _dp, C.c_int]
@@ -140,6 +142,15 @@ def exchange_all(fields, lds, comms):
     ldarr = (C.c_int * n)(*lds)
     carr = (Comms * n)(*comms)
     return lib().orc_exchange_all(n, _ptr_array(fields), ldarr, carr)
+
+
+def exchange_dirs(fields, lds, comms, dirs, no_diagonals=False):
+    """exchange_generic(comm1..comm4 = dirs) for every rank at once; diagonals follow their edges
+    (parallel_comms_mod.f90:1557-1571) unless no_diagonals"""
+    n = len(fields)
+    c = (list(dirs) + [0, 0, 0, 0])[:4]
+    return lib().orc_exchange_dirs(n, _ptr_array(fields), (C.c_int * n)(*lds), (Comms * n)(*comms),
+                                   c[0], c[1], c[2], c[3], 1 if no_diagonals else 0)
 
 
 def gather_all(fields, lds, d, subs):

@@ -256,3 +256,37 @@ def test_grid_extents_random_vs_oracle():
         assert L.dlesm_grid_extents(n, m, a, C.byref(nx), C.byref(ny)) == 0
         assert (nx.value, ny.value) == O.grid_extents(n, m, a)
         assert nx.value % max(a, 1) == 0 and nx.value > n
+
+
+# --------------------------------------------------------------------------- id rendezvous (host only)
+def test_rendezvous_roundtrip_and_stale_records(tmp_path):
+    """dlesm_rendezvous_{remove,publish,fetch}: atomic publish, token and start-time checks"""
+    import ctypes as C
+    import struct
+    import time
+    L = D._cabi.lib()
+    path = str(tmp_path / "id").encode()
+    ident = bytes((7 * k + 3) % 256 for k in range(128))
+    got = C.create_string_buffer(128)
+    assert L.dlesm_rendezvous_remove(path) == 0                       # nothing there: fine
+    assert L.dlesm_rendezvous_fetch(path, got, b"4:run1", 50) == D._cabi.EINVAL
+    assert b"no file appeared" in L.dlesm_last_error()
+    assert L.dlesm_rendezvous_publish(path, ident, b"4:run1") == 0
+    assert os.path.getsize(path) == 256 and not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+    assert L.dlesm_rendezvous_fetch(path, got, b"4:run1", 50) == 0 and got.raw == ident
+    # another job's token, or another world size: ignored
+    assert L.dlesm_rendezvous_fetch(path, got, b"4:run2", 50) == D._cabi.EINVAL
+    assert b"stale file: job token '4:run1'" in L.dlesm_last_error()
+    assert L.dlesm_rendezvous_fetch(path, got, b"8:run1", 50) == D._cabi.EINVAL
+    # right token but a publisher that started long before this process: a dead job's leftover
+    rec = open(path, "rb").read()
+    open(path, "wb").write(rec[:8] + struct.pack("<q", int(time.time()) - 5000) + rec[16:])
+    assert L.dlesm_rendezvous_fetch(path, got, b"4:run1", 50) == D._cabi.EINVAL
+    assert b"started" in L.dlesm_last_error()
+    # a truncated record is not taken either; a fresh publish replaces it
+    open(path, "wb").write(rec[:100])
+    assert L.dlesm_rendezvous_fetch(path, got, b"4:run1", 50) == D._cabi.EINVAL
+    assert L.dlesm_rendezvous_publish(path, ident[::-1], b"4:run1") == 0
+    assert L.dlesm_rendezvous_fetch(path, got, b"4:run1", 50) == 0 and got.raw == ident[::-1]
+    assert L.dlesm_rendezvous_publish(path, ident, ("x" * 112).encode()) == D._cabi.EINVAL   # token too long
+    assert L.dlesm_rendezvous_remove(path) == 0 and not os.path.exists(path)

@@ -135,6 +135,61 @@ def test_fortran_deep_halo_tables_match_the_c_abi(exe, nx, ny, nranks, hw):
         assert any(s["nx"] == hw or s["ny"] == hw for s in c.sends())
 
 
+def _plant_stale(path, token, age_s):
+    """a rendezvous record as a dead job would have left it (format: dlesm_rendezvous.cpp)"""
+    import struct
+    import time
+    rec = b"DLESMRV1" + struct.pack("<q", int(time.time()) - age_s) + token.encode().ljust(112, b"\0") + \
+        bytes(range(128))
+    with open(path, "wb") as f:
+        f.write(rec)
+
+
+@pytest.mark.parametrize("stale", ["none", "other_job_token", "old_publisher", "garbage"])
+def test_fortran_bootstrap_rendezvous_ignores_stale_files(exe, tmp_path, stale):
+    """parallel_init's id rendezvous with two real processes (DLESM_DRY_COMMS=2: blank id, no
+    communicator, no GPU): rank 0 replaces whatever it finds, a reader that starts FIRST and sees a
+    stale record of a dead job (other token / a publisher that started long ago / not a record)
+    keeps waiting for this job's record instead of taking the old id; both leave cleanly and the
+    file is removed at parallel_finalise"""
+    import time
+    path = str(tmp_path / "rv")
+    env = {"WORLD_SIZE": "2", "DLESM_DRY_COMMS": "2", "DLESM_RENDEZVOUS": path, "DLESM_JOB_ID": "job-B",
+           "DLESM_RENDEZVOUS_TIMEOUT_S": "20"}
+    if stale == "other_job_token":
+        _plant_stale(path, "2:job-A", 0)
+    elif stale == "old_publisher":
+        _plant_stale(path, "2:job-B", 100000)
+    elif stale == "garbage":
+        open(path, "wb").write(b"x" * 300)
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "DL_ESM_ALIGNMENT"):
+        e.pop(k, None)
+    e.update(env)
+    cmd = [os.path.join(BUILD, "ftest_dump.exe"), "comms", "10", "4"]
+    reader = subprocess.Popen(cmd, env={**e, "RANK": "1"}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(0.5)                                     # the reader is polling the (possibly stale) file by now
+    assert reader.poll() is None, reader.stderr.read()
+    root = subprocess.run(cmd, env={**e, "RANK": "0"}, capture_output=True, text=True, timeout=60)
+    out, err = reader.communicate(timeout=60)
+    assert root.returncode == 0, root.stderr[-1000:]
+    assert reader.returncode == 0, err[-1000:]
+    assert "G: rank 2 2" in out and "G: rank 1 2" in root.stdout
+    assert not os.path.exists(path)                     # rank 0 removed it on the way out
+
+
+def test_fortran_bootstrap_times_out_with_a_reason(exe, tmp_path):
+    """no rank 0 ever shows up: the reader stops with the reason, it does not hang"""
+    path = str(tmp_path / "rv")
+    _plant_stale(path, "2:job-A", 0)
+    rc, _, err = exe("ftest_dump.exe", "comms", 10, 4, check=False,
+                     env={"RANK": "1", "WORLD_SIZE": "2", "DLESM_DRY_COMMS": "2", "DLESM_RENDEZVOUS": path,
+                          "DLESM_JOB_ID": "job-B", "DLESM_RENDEZVOUS_TIMEOUT_S": "1"})
+    assert rc != 0
+    flat = err.replace("\n ", "")                       # list-directed output wraps long lines
+    assert "no usable RCCL id" in flat and "stale file" in flat and "job-A" in flat
+
+
 @pytest.mark.gpu
 def test_fortran_device_io_and_jacobi_on_gpu(exe):
     nx, ny, nsteps = 300, 171, 5

@@ -387,7 +387,7 @@ def test_halo_exchange_loopback_on_one_gpu(D):
     assert O.exchange_all([want], [g.nx], [oc]) == 0
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        D._cabi.check(L.dlesm_halo_exchange_f64(plan, f.device_ptr, 0, C.c_void_p(s.cuda_stream)))
+        D._cabi.check(L.dlesm_halo_exchange_f64(plan, f.device_ptr, D._cabi.DIRS_ALL, C.c_void_p(s.cuda_stream)))
     s.synchronize()
     assert np.array_equal(f.get_data(), want)
     # distributed step on the same plan == plain stencil followed by the exchange of `out`
@@ -395,9 +395,87 @@ def test_halo_exchange_loopback_on_one_gpu(D):
     D.psy.hash_init(a, SEED + 1)
     D._cabi.check(L.dlesm_jacobi5_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), None))
     D.psy.invoke_jacobi5(c, a)
-    D._cabi.check(L.dlesm_halo_exchange_f64(plan, c.device_ptr, 0, None))
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, c.device_ptr, D._cabi.DIRS_EDGES_ONLY, None))
     torch.cuda.synchronize()
     assert np.array_equal(b.get_data(), c.get_data())
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+@pytest.mark.parametrize("dirs,no_diag", [((), False), ((1,), False), ((1, 4), False), ((2, 3), False),
+                                          ((3, 4), False), ((1, 2, 3), False), ((1, 2, 3, 4), False),
+                                          ((1, 2, 3, 4), True), ((2, 4), True)])
+@pytest.mark.parametrize("nx,ny,alignment", [(37, 23, 8), (130, 6, None)])
+def test_masked_halo_exchange_loopback(D, nx, ny, alignment, dirs, no_diag):
+    """exchange_generic with a choice of comm1..comm4 (parallel_comms_mod.f90:1557-1571) on the
+    device: only the enabled edge directions travel, a diagonal when both its edges are enabled,
+    mask 0 exchanges nothing, halos of disabled directions keep their contents.  Loop-back tables
+    with all eight directions; checked against the oracle's exchange with the same arguments."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dm_overhead import loopback_tables
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    g = _grid(D, nx, ny, alignment)
+    f = D.r2d_field(g, D.GO_T_POINTS)
+    D.psy.hash_init(f, SEED + 7)
+    t = loopback_tables(D, f.internal)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    before = f.get_data()
+    want = before.copy()
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    assert O.exchange_dirs([want], [g.nx], [oc], dirs, no_diagonals=no_diag) == 0
+    mask = sum(1 << (d - 1) for d in dirs) | (D._cabi.DIRS_NO_DIAGONALS if no_diag else 0)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, f.device_ptr, mask, None))
+    torch.cuda.synchronize()
+    got = f.get_data()
+    assert np.array_equal(got, want)
+    if not dirs:
+        assert np.array_equal(got, before)
+    else:
+        assert not np.array_equal(got, before)
+    if len(dirs) == 4 and not no_diag:       # the full exchange, as halo_exchange does it
+        full = before.copy()
+        assert O.exchange_all([full], [g.nx], [oc]) == 0
+        assert np.array_equal(got, full)
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+@pytest.mark.parametrize("corners,frame_pack", [(0, 1), (0, 0), (1, 1), (1, 0)])
+def test_distributed_step_variants(D, corners, frame_pack):
+    """the distributed Jacobi step with/without the corner messages and with/without the frame
+    kernel writing the west/east columns straight into the send buffer: always stencil + the
+    matching exchange, bit for bit, over several steps (the send buffer is reused every step)"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dm_overhead import loopback_tables
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    _set_tuning(D, j5_dm_corners=corners, j5_dm_frame_pack=frame_pack)
+    g = _grid(D, 300, 41, 64)
+    x, y = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = x.internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    D.psy.hash_init(x, SEED + 11)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+    D.copy_field(x, y)
+    for _ in range(4):
+        hx = x.get_data()
+        want = y.get_data()
+        O.jacobi5(hx, want, g.nx, *it.box())
+        assert O.exchange_dirs([want], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=not corners) == 0
+        D._cabi.check(L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(y.get_data(), want)
+        x, y = y, x
+    _set_tuning(D, j5_dm_corners=0, j5_dm_frame_pack=1)
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
@@ -538,7 +616,7 @@ def test_distributed_step_on_small_and_ragged_boxes(D, nx, ny):
     plan = C.c_void_p()
     D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
     D.psy.hash_init(a, SEED + 3)
-    D._cabi.check(L.dlesm_halo_exchange_f64(plan, a.device_ptr, 0, None))
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, a.device_ptr, D._cabi.DIRS_ALL, None))
     D.copy_field(a, b)
     D.copy_field(a, c)
     x, y, z = a, b, c
@@ -546,7 +624,7 @@ def test_distributed_step_on_small_and_ragged_boxes(D, nx, ny):
         D._cabi.check(L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), None))
         torch.cuda.synchronize()
         D.psy.invoke_jacobi5(z, x)
-        D._cabi.check(L.dlesm_halo_exchange_f64(plan, z.device_ptr, 0, None))
+        D._cabi.check(L.dlesm_halo_exchange_f64(plan, z.device_ptr, D._cabi.DIRS_EDGES_ONLY, None))
         torch.cuda.synchronize()
         assert np.array_equal(y.get_data(), z.get_data())
         # and both equal the oracle: stencil, then the same exchange on the host
@@ -555,7 +633,7 @@ def test_distributed_step_on_small_and_ragged_boxes(D, nx, ny):
         O.jacobi5(hx, want, g.nx, *it.box())
         oc = O.Comms()
         C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
-        assert O.exchange_all([want], [g.nx], [oc]) == 0
+        assert O.exchange_dirs([want], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0   # edges only
         assert np.array_equal(y.get_data(), want)
         x, y = y, x
         D.copy_field(x, z)
