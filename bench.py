@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-temporal-blocking", action="store_true", help="skip the secondary fused-steps figure")
     ap.add_argument("--no-plan", action="store_true", help="skip the launch-shape planning call before the warm-up")
     ap.add_argument("--no-shallow", action="store_true", help="skip the secondary shallow-water figure")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE Jacobi configurations")
+    ap.add_argument("--no-weak-tile", action="store_true",
+                    help="skip the 8192^2-per-GPU weak-scaling object (BASELINE configs[4]'s tile)")
     ap.add_argument("--force-dm-leg", action="store_true",
                     help="rehearsal on 1 GPU: run the N>1 secondary leg with a 1-rank process group")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
@@ -108,6 +111,75 @@ def cpu_baseline(host_in, ld, box, budget_s):
 
 XT_ROWS = {2: 4, 3: 6, 4: 8, 5: 8, 6: 12, 7: 16, 8: 16}      # rows per wave tile the library picks per T
 TB_STEPS = 8                                                 # time steps per launch of the secondary legs
+SW_KERNEL = "shallow_tile<2,dpp>"                             # what dlesm_shallow_step_f64 launches by default
+WEAK_TILE = 8192                                             # the per-GPU tile BASELINE configs[4] names
+MIN_SECONDARY_LAUNCHES = 24                                  # every secondary leg times at least this many launches
+TRAFFIC_SOURCE = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with the "
+                  "guide's gfx950 correction (FETCH_SIZE x 2), per launch; read from the committed file, "
+                  "NOT re-measured in this run")
+
+
+def baseline_config(tile, world=1):
+    """which entry of BASELINE.json `configs` a Jacobi tile corresponds to"""
+    if world > 1:
+        return "BASELINE configs[4] form" + ("" if tile == 8192 else f" with a {tile}^2 tile (configs[4] names 8192^2)")
+    return {4096: "BASELINE configs[1]", 16384: "BASELINE configs[2]",
+            8192: "the per-GPU tile of BASELINE configs[4], on one GPU"}.get(tile, "not a BASELINE size")
+
+
+def traffic_for(tile, alignment, fused=1):
+    """PMC-measured fabric bytes per launch for this configuration, if profiles/traffic.json has it"""
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(tj))
+        key = f"{tile}x{tile}/A{alignment}" + (f"/fused{fused}" if fused > 1 else "")
+        return rec.get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:                                        # noqa: BLE001
+        return None
+
+
+def make_grid(D, nx, ny, alignment, halo_width=1):
+    os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
+    g.decompose(nx, ny, halo_width=halo_width)
+    D.grid_init(g, 1.0, 1.0)
+    return g
+
+
+def jacobi_config(D, torch, stream, tile, alignment, steps, warmup=10):
+    """Secondary figure (never `value`): one more BASELINE Jacobi configuration on this GPU, timed
+    like the headline (planning call, warm-up, HIP events on the launch stream)."""
+    steps = max(steps, MIN_SECONDARY_LAUNCHES)
+    g = make_grid(D, tile, tile, alignment)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        D.psy.hash_init(a, SEED, stream=stream)
+        D.copy_field(a, b, stream=stream)
+        D.psy.autotune_jacobi5(b, a, stream=stream)
+        D.copy_field(a, b, stream=stream)
+        for _ in range(warmup):
+            D.psy.invoke_jacobi5(b, a, stream=stream)
+            a, b = b, a
+        e0.record(stream)
+        for _ in range(steps):
+            D.psy.invoke_jacobi5(b, a, stream=stream)
+            a, b = b, a
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    cells = tile * tile
+    gbs = BYTES_PER_CELL * cells / (ms * 1e-3) / 1e9
+    out = {"workload": f"jacobi5 {tile}x{tile} fp64, DL_ESM_ALIGNMENT={alignment} (ld {g.nx}; {baseline_config(tile)})",
+           "tile": tile, "DL_ESM_ALIGNMENT": alignment, "ld": g.nx, "steps": steps,
+           "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic_for(tile, alignment),
+                        "traffic_source": TRAFFIC_SOURCE, "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells},
+           "checksum": D.field_checksum(a)}
+    del a, b
+    torch.cuda.empty_cache()
+    return out
 
 
 def temporal_blocking(D, torch, grid, a, stream, steps, tile, T=TB_STEPS):
@@ -126,10 +198,10 @@ def temporal_blocking(D, torch, grid, a, stream, steps, tile, T=TB_STEPS):
     stream.synchronize()
     same = bool(torch.equal(src.data, z.data))
     # the clocks drop while the host compares the arrays: warm up again, and time enough launches
-    launches = max(24, steps // T) if steps >= 24 else max(1, steps // T)
+    launches = max(MIN_SECONDARY_LAUNCHES, steps // T)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(stream):
-        for _ in range(10 if steps >= 24 else 2):
+        for _ in range(10):
             D.psy.invoke_jacobi5_multi(y, x, T, stream=stream)
             x, y = y, x
         e0.record(stream)
@@ -147,25 +219,37 @@ def temporal_blocking(D, torch, grid, a, stream, steps, tile, T=TB_STEPS):
             "bit_identical_to_single_steps": same, "kernel": f"jacobi5xt_tile<{T},{XT_ROWS[T]},dpp>"}
 
 
-def shallow_water(D, torch, stream, alignment, tile=8192, steps=40):
+def shallow_water(D, torch, stream, alignment, tile=8192, steps=40, cpu_seconds=0.0):
     """Secondary figure (never `value`): BASELINE configs[3], the fused shallow-water u/v/h step
     (9-point composite footprint, 72 B/cell algorithmic) on a tile x tile C-grid, leapfrog rotation
-    of the three time levels between steps."""
-    os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
-    g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
-    g.decompose(tile, tile)
-    D.grid_init(g, 1.0, 1.0)
+    of the three time levels between steps.  With cpu_seconds > 0 its own cpu_baseline: the oracle's
+    GOcean kernel sequence (orc_sw_step, 1 core) on a 256-row slab of the same initial state, whose
+    result rows must equal the GPU's bit for bit."""
+    steps = max(steps, MIN_SECONDARY_LAUNCHES)
+    g = make_grid(D, tile, tile, alignment)
     pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
     F = {}
     with torch.cuda.stream(stream):
-        for k, name in enumerate(["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]):
+        for k, name in enumerate(names):
             F[name] = D.r2d_field(g, pts[name[0]])
             D.psy.hash_init(F[name], SEED + k, stream=stream)
             F[name].data.add_(1.0 if name[0] == "p" else -0.5)     # p in [1,2), u, v in [-0.5,0.5)
     prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
+    it = F["p"].internal
     cur, old, new = [F["u"], F["v"], F["p"]], [F["uold"], F["vold"], F["pold"]], [F["unew"], F["vnew"], F["pnew"]]
+    # slab kept for the CPU leg: inputs rows j0-1 .. j0+h, first-step outputs rows j0 .. j0+h-1 (1-based j0)
+    h = min(256, it.ny)
+    j0 = it.ystart + (it.ny - h) // 2
+    slab_in = slab_out = None
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(stream):
+        if cpu_seconds > 0:
+            slab_in = [f.data[j0 - 2:j0 + h, :].clone() for f in cur + old]
+        D.psy.invoke_shallow_step(prm, *cur, *old, *new, stream=stream)
+        if cpu_seconds > 0:
+            slab_out = [f.data[j0 - 1:j0 + h - 1, :].clone() for f in new]
+        old, cur, new = cur, new, old
         for _ in range(5):
             D.psy.invoke_shallow_step(prm, *cur, *old, *new, stream=stream)
             old, cur, new = cur, new, old
@@ -178,12 +262,38 @@ def shallow_water(D, torch, stream, alignment, tile=8192, steps=40):
     ms = e0.elapsed_time(e1) / steps
     cells, bpc = tile * tile, 72
     gbs = bpc * cells / (ms * 1e-3) / 1e9
-    return {"workload": f"shallow-water u/v/h fused step {tile}x{tile} fp64 (BASELINE configs[3])", "steps": steps,
-            "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),
-            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_cell": bpc,
-                         "kernel": "shallow_tile<2,dpp>"},
-            "checksum_pnew": D.field_checksum(cur[2])}
+    out = {"workload": f"shallow-water u/v/h fused step {tile}x{tile} fp64 (BASELINE configs[3])", "steps": steps,
+           "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_cell": bpc,
+                        "algorithmic_bytes_per_launch": bpc * cells, "kernel": SW_KERNEL},
+           "checksum_pnew": D.field_checksum(cur[2])}
+    if cpu_seconds > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import numpy as np
+        import oracle_lib as O
+        hin = [t.cpu().numpy() for t in slab_in]
+        want = [np.zeros_like(hin[0]) for _ in range(3)]
+        box = (it.xstart, it.xstop, 2, h + 1)
+        O.sw_step(prm, g.nx, box, *hin, *want)                      # warm + the check
+        got = [t.cpu().numpy() for t in slab_out]
+        same = all(np.array_equal(w[1:h + 1, it.xstart - 1:it.xstop], gg[:, it.xstart - 1:it.xstop])
+                   for w, gg in zip(want, got))
+        t0, n = time.perf_counter(), 0
+        while True:
+            O.sw_step(prm, g.nx, box, *hin, *want)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > cpu_seconds or n >= 500:
+                break
+        out["cpu_baseline"] = {"value": round(it.nx * h * n / dt / 1e6, 1), "unit": "Mcells/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle orc_sw_step (C, gcc -O3, the un-fused GOcean kernel sequence cu, cv, z, "
+                                         f"h, unew, vnew, pnew) on a {it.nx}x{h} slab of the same initial state: {n} "
+                                         f"steps in {dt:.1f}s on 1 core",
+                               "gpu_first_step_equals_oracle_on_slab": bool(same)}
+    del F, cur, old, new
+    torch.cuda.empty_cache()
+    return out
 
 
 def temporal_blocking_dm(D, torch, dist, tile, P, Q, stream, steps, T=TB_STEPS):
@@ -208,9 +318,9 @@ def temporal_blocking_dm(D, torch, dist, tile, P, Q, stream, steps, T=TB_STEPS):
     stream.synchronize()
     ok = torch.tensor([1 if torch.equal(u.data, y.data) else 0], device="cuda")
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    launches = max(24, steps // T) if steps >= 24 else max(1, steps // T)
+    launches = max(MIN_SECONDARY_LAUNCHES, steps // T)
     with torch.cuda.stream(stream):
-        for _ in range(10 if steps >= 24 else 2):
+        for _ in range(10):
             D.psy.invoke_jacobi5_multi_dm(y, x, T, stream=stream)
             x, y = y, x
     torch.cuda.synchronize()
@@ -236,6 +346,85 @@ def temporal_blocking_dm(D, torch, dist, tile, P, Q, stream, steps, T=TB_STEPS):
             "kernel": f"jacobi5xt_tile<{T},{XT_ROWS[T]},dpp> + one depth-{T} RCCL exchange per launch"}
 
 
+def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, steps, warmup=10):
+    """Secondary object on EVERY line (N = 1, 2, 4, 8): the Jacobi step on the per-GPU tile BASELINE
+    configs[4] names (8192^2), global domain (tile*P) x (tile*Q) cut by go_decompose, RCCL halo exchange
+    hidden behind the interior when N > 1 -- so that t(1)/t(N) for THAT tile can be read off the driver's
+    own lines.  Timed like the headline: barrier + synchronize on both sides, max over ranks."""
+    steps = max(steps, MIN_SECONDARY_LAUNCHES)
+    g = make_grid(D, tile * P, tile * Q, alignment)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = a.internal
+    assert (it.nx, it.ny) == (tile, tile) and (g.decomp.nx, g.decomp.ny) == (P, Q)
+    step = D.psy.invoke_jacobi5_dm if world > 1 else D.psy.invoke_jacobi5
+    L = D._cabi.lib()
+    with torch.cuda.stream(stream):
+        D.psy.hash_init(a, SEED, stream=stream)
+        D.copy_field(a, b, stream=stream)
+        a.halo_exchange(1, stream=stream)
+        if world == 1:
+            D.psy.autotune_jacobi5(b, a, stream=stream)
+        else:
+            D._cabi.check(L.dlesm_stencil5_autotune_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, it.xstart + 1,
+                                                        it.xstop - 1, it.ystart + 1, it.ystop - 1,
+                                                        C.c_void_p(stream.cuda_stream)))
+        D.copy_field(a, b, stream=stream)
+    stream.synchronize()
+    same = None
+    if world > 1:       # overlapped step == stencil + edge exchange, on every rank, before timing
+        x, y = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+        with torch.cuda.stream(stream):
+            D.copy_field(a, x, stream=stream)
+            D.copy_field(a, y, stream=stream)
+            D.psy.invoke_jacobi5(y, x, stream=stream)
+            y.halo_exchange(1, stream=stream, dirs=D._cabi.DIRS_EDGES_ONLY)
+            D.psy.invoke_jacobi5_dm(b, a, stream=stream)
+        stream.synchronize()
+        ok = torch.tensor([1 if torch.equal(b.data, y.data) else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        same = bool(int(ok[0]))
+        with torch.cuda.stream(stream):
+            D.copy_field(a, b, stream=stream)
+        del x, y
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            step(b, a, stream=stream)
+            a, b = b, a
+    barrier()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(steps):
+            step(b, a, stream=stream)
+            a, b = b, a
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt[0])
+    cells = tile * tile * world
+    ms = wall / steps * 1e3
+    gbs = BYTES_PER_CELL * tile * tile / (ms * 1e-3) / 1e9
+    out = {"workload": f"jacobi5 {tile}x{tile} fp64 T-field per GPU, {P}x{Q} decomposition "
+                       f"({baseline_config(tile, world) if world > 1 else baseline_config(tile)})",
+           "tile": tile, "n_gpus": world, "decomposition": f"{P}x{Q}", "global": [tile * P, tile * Q],
+           "DL_ESM_ALIGNMENT": alignment, "steps": steps, "value": round(cells * steps / wall / 1e6, 1),
+           "unit": "Mcells/s", "ms_per_step": round(ms, 5), "hbm_gbs_per_gpu": round(gbs, 1),
+           "frac_of_hbm_peak_per_gpu": round(gbs / HBM_PEAK_GBS, 4), "scaling": "weak",
+           "halo_exchange": "rccl send/recv of the four edges, overlapped" if world > 1 else "none (1 tile)",
+           "dm_step_equals_stencil_plus_exchange": same, "checksum": D.field_checksum(a)}
+    del a, b
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -257,7 +446,6 @@ def main():
 
     import dl_esm_inf_amd as D
     L = D._cabi.lib()
-    D._cabi.check(L.dlesm_init(local))
     if args.rows is not None:
         L.dlesm_set_tuning(b"j5_rows", args.rows)
     if args.variant is not None:
@@ -265,6 +453,7 @@ def main():
     for kv in args.tune:
         k, v = kv.split("=")
         L.dlesm_set_tuning(k.encode(), int(v))     # returns the previous value
+    D._cabi.check(L.dlesm_init(local))             # after the knobs: the side stream's priority is one of them
     os.environ["DL_ESM_ALIGNMENT"] = str(args.alignment)
     D.parallel_init(rank, world)
 
@@ -369,82 +558,109 @@ def main():
     value = cells_step * args.steps / wall / 1e6
     launch_ms = ev_ms / launches
     achieved =BYTES_PER_CELL * args.tile * args.tile / (launch_ms * 1e-3) / 1e9   # per GPU, GB/s
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-measured HBM bytes per launch
-    if os.path.exists(tj):
-        try:
-            rec = json.load(open(tj))
-            key = f"{args.tile}x{args.tile}/A{args.alignment}" + (f"/fused{fused}" if fused > 1 else "")
-            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
     out = {
         "metric": "stencil Mcells/s", "value": round(value, 1), "unit": "Mcells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"jacobi5 {args.tile}x{args.tile} fp64 T-field per GPU "
-                               "(BASELINE configs[2]; NE offset, external BCs, fixed boundary ring)",
+                               f"({baseline_config(args.tile, world)}; NE offset, external BCs, fixed boundary ring)",
                    "tile": args.tile, "decomposition": f"{P}x{Q}",
                    "global": [args.tile * P, args.tile * Q], "DL_ESM_ALIGNMENT": args.alignment,
-                   "ld": grid.nx, "halo_exchange": "rccl send/recv, overlapped" if world > 1 else "none (1 tile)",
+                   "ld": grid.nx,
+                   "halo_exchange": "rccl send/recv of the four edges, overlapped" if world > 1 else "none (1 tile)",
                    "launch_shape": "planned (dlesm_stencil5_autotune_f64, before the warm-up)" if planned else "rule"},
         "hbm_gbs_per_gpu": round(achieved, 1),
         "checksum": checksum, "dm_step_equals_stencil_plus_exchange": selfcheck,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic_for(args.tile, args.alignment, fused), "traffic_source": TRAFFIC_SOURCE,
                      "kernel": "jacobi5_tile<2,2>" if fused == 1 else f"jacobi5xt_tile<{fused},{XT_ROWS[fused]},dpp>",
                      "launch_ms": round(launch_ms, 5),
                      "algorithmic_bytes_per_launch": BYTES_PER_CELL * args.tile * args.tile},
     }
+    secondary = fused == 1 and not args.force_dm_leg
+    failed = []                                              # names of secondary legs that raised
+
+    def guarded(name, fn):
+        """a secondary leg must never cost the headline line: its error text is reported instead"""
+        try:
+            out[name] = fn()
+        except Exception as e:                               # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            failed.append(name)
+
     if fused > 1:
         out["config"]["fused_steps_per_launch"] = fused
         out["roofline"]["note"] = (f"one launch advances {fused} time steps; bytes are per launch, so Mcells/s "
                                    f"exceeds what 16 B/cell/step allows at this bandwidth")
-    elif world == 1 and not args.no_temporal_blocking and not args.force_dm_leg:
-        out["temporal_blocking"] = temporal_blocking(D, torch, grid, a, stream, args.steps, args.tile)
-    elif not args.no_temporal_blocking:
-        # The secondary leg must never cost the headline line: if it raises, its error text is
-        # reported; if it has not finished in 120 s, the line goes out without it and the rank leaves.
+    elif world == 1 and not args.force_dm_leg:
+        if not args.no_temporal_blocking:
+            guarded("temporal_blocking", lambda: temporal_blocking(D, torch, grid, a, stream, args.steps, args.tile))
+    else:
+        # N > 1 (or its 1-rank rehearsal): every secondary leg contains collectives, so a rank that
+        # fails would leave the others waiting.  If a leg raises, or the legs have not finished in
+        # 180 s, rank 0 prints the line with what it has and EVERY rank leaves with a non-zero status:
+        # a hung or failed leg must not look like a clean run.
         import threading
 
-        def bail():
+        def bail(why, code):
             if rank == 0:
-                out["cpu_baseline"] = None
-                out["temporal_blocking"] = {"error": "secondary leg did not finish in 120 s"}
+                out.setdefault("cpu_baseline", None)
+                out["secondary_legs_error"] = why
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(code)
 
-        dog = threading.Timer(120.0, bail)
+        dog = threading.Timer(180.0, bail, args=("secondary legs did not finish in 180 s", 3))
         dog.daemon = True
         dog.start()
         try:
-            out["temporal_blocking"] = temporal_blocking_dm(D, torch, dist, args.tile, P, Q, stream, args.steps)
-        except Exception as e:                            # noqa: BLE001
+            if not args.no_weak_tile and args.tile != WEAK_TILE:
+                out["weak_scaling_tile"] = weak_scaling_tile(D, torch, dist, WEAK_TILE, args.alignment, world, P, Q,
+                                                             stream, args.steps)
+            if not args.no_temporal_blocking:
+                out["temporal_blocking"] = temporal_blocking_dm(D, torch, dist, args.tile, P, Q, stream, args.steps)
+        except Exception as e:                               # noqa: BLE001
             dog.cancel()
-            if rank == 0:
-                out["cpu_baseline"] = None
-                out["temporal_blocking"] = {"error": f"{type(e).__name__}: {e}"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)                                   # the other ranks may be stuck in a collective
+            bail(f"{type(e).__name__}: {e}", 4)              # the other ranks may be stuck in a collective
         dog.cancel()
-    if world == 1 and not args.no_shallow and fused == 1 and not args.force_dm_leg:
-        try:
-            out["shallow_water"] = shallow_water(D, torch, stream, args.alignment,
-                                                 tile=min(8192, args.tile), steps=max(8, min(40, args.steps)))
-        except Exception as e:                            # noqa: BLE001  (never at the cost of the headline line)
-            out["shallow_water"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if world == 1 and secondary:
+        if not args.no_shallow:
+            guarded("shallow_water", lambda: shallow_water(
+                D, torch, stream, args.alignment, tile=min(8192, args.tile), steps=min(40, args.steps),
+                cpu_seconds=0.0 if args.no_cpu_baseline else min(4.0, args.cpu_seconds)))
+        if not args.no_weak_tile and args.tile != WEAK_TILE:
+            guarded("weak_scaling_tile", lambda: weak_scaling_tile(D, torch, None, WEAK_TILE, args.alignment, 1, 1, 1,
+                                                                   stream, args.steps))
+        if not args.no_configs:
+            # the other BASELINE Jacobi configurations, timed in the same process
+            legs = [(4096, 64), (16384, 1), (4096, 1)]
+            out["configs"] = []
+            for (t, al) in legs:
+                if (t, al) == (args.tile, args.alignment):
+                    continue
+                try:
+                    out["configs"].append(jacobi_config(D, torch, stream, t, al, args.steps))
+                except Exception as e:                       # noqa: BLE001
+                    out["configs"].append({"tile": t, "DL_ESM_ALIGNMENT": al, "error": f"{type(e).__name__}: {e}"})
+                    failed.append(f"configs[{t},A{al}]")
+    if rank == 0 and not args.no_cpu_baseline:
+        # N > 1: a shorter sample (the other ranks wait at the barrier below), same tile, rank 0's cores
         host = a.get_data()
-        out["cpu_baseline"] = cpu_baseline(host, grid.nx, it.box(), args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(host, grid.nx, it.box(), args.cpu_seconds if world == 1
+                                           else min(args.cpu_seconds, 5.0))
     elif rank == 0:
         out["cpu_baseline"] = None
+    if failed:
+        out["secondary_legs_error"] = "failed: " + ", ".join(failed)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_dm_leg:
         dist.barrier()
         D.parallel_finalise()
         dist.destroy_process_group()
+    if failed:
+        sys.exit(5)
 
 
 if __name__ == "__main__":

@@ -92,6 +92,14 @@ struct dlesm_halo_plan {
     // stepped on different streams never share one.  ONE exchange per plan may be in flight
     // (its pack buffers are single): the steps below serialise on the caller's stream.
     hipEvent_t ev_frame = nullptr, ev_comm = nullptr;
+    // frame-done flag of the one-launch step (jacobi5_tile_framed): a device word the side stream's
+    // frame_flag_wait kernel sleeps on, a device word counting finished frame workgroups, the value
+    // the next launch will store (monotonic, so "flag >= seq" can never be missed), and a pinned
+    // host word the wait kernel raises if it ever gives up
+    unsigned long long *frame_flag = nullptr;
+    unsigned *frame_counter = nullptr;
+    unsigned long long frame_seq = 0;
+    int *frame_timed_out = nullptr;
 };
 
 // edge directions follow their bit; diagonals follow their two edges (parallel_comms_mod.f90:
@@ -240,10 +248,25 @@ extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny
         dlesm_halo_plan_destroy(p);
         return rc;
     }
-    if (hipEventCreateWithFlags(&p->ev_frame, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&p->ev_comm, hipEventDisableTiming) != hipSuccess) {
+    // The events order work of two streams of ONE device: no system-scope fence (L2 write-back) is
+    // needed when they are recorded -- 3 us less per step on the caller's stream (scripts/syncbench.hip)
+    const unsigned evflags = hipEventDisableTiming | (tuning("dm_event_system_fence", 0) ? 0u : hipEventDisableSystemFence);
+    if (hipEventCreateWithFlags(&p->ev_frame, evflags) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_comm, evflags) != hipSuccess) {
         dlesm_halo_plan_destroy(p);
         return fail(DLESM_EHIP, "halo plan: hipEventCreate failed");
+    }
+    if (!p->sends.empty() || !p->recvs.empty()) {
+        void *words = nullptr;
+        if (hipMalloc(&words, 256) != hipSuccess || hipMemset(words, 0, 256) != hipSuccess ||
+            hipHostMalloc((void **)&p->frame_timed_out, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
+            dlesm_halo_plan_destroy(p);
+            return fail(DLESM_EHIP, "halo plan: cannot allocate the frame flag");
+        }
+        p->frame_flag = (unsigned long long *)words;                 // two words, 128 bytes apart
+        p->frame_counter = (unsigned *)((char *)words + 128);
+        *p->frame_timed_out = 0;
     }
     *out = p;
     return DLESM_OK;
@@ -257,6 +280,8 @@ extern "C" int dlesm_halo_plan_destroy(dlesm_halo_plan *p)
     if (p->d_rpack) (void)hipFree(p->d_rpack);
     if (p->sendbuf) (void)hipFree(p->sendbuf);
     if (p->recvbuf) (void)hipFree(p->recvbuf);
+    if (p->frame_flag) (void)hipFree(p->frame_flag);
+    if (p->frame_timed_out) (void)hipHostFree(p->frame_timed_out);
     if (p->ev_frame) (void)hipEventDestroy(p->ev_frame);
     if (p->ev_comm) (void)hipEventDestroy(p->ev_comm);
     delete p;
@@ -376,15 +401,37 @@ extern "C" int dlesm_jacobi5_step_dm(dlesm_halo_plan *p, const double *in, doubl
     } else {
         fp.n = 0;
     }
-    if (int rc = launch_stencil5_frame(in, out, ld, ny, xstart, xstop, ystart, ystop, s, prepacked ? &fp : nullptr))
-        return rc;
-    DLESM_HIP_TRY(hipEventRecord(p->ev_frame, s));
-    // 2. exchange out's frame on the side stream ...
-    DLESM_HIP_TRY(hipStreamWaitEvent(side, p->ev_frame, 0));
-    if (int rc = exchange_on(p, out, mask, side, prepacked)) return rc;
-    DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
-    // 3. ... while the interior streams through HBM on the caller's stream
-    if (int rc = launch_stencil5(in, out, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, s)) return rc;
+    // One launch: the frame as the first workgroups of the interior sweep, its completion published
+    // through a flag the side stream is parked on -- no frame launch and no event record on the
+    // caller's stream (each costs it microseconds of a ~180 us step, scripts/syncbench.hip).
+    bool fused = false;
+    DLESM_REQUIRE(!p->frame_timed_out || *p->frame_timed_out == 0,
+                  "an earlier distributed step never reported its frame (frame flag wait timed out)");
+    if (p->frame_flag && tuning("j5_dm_fused", 1)) {
+        FrameJob job{};
+        job.pk = fp;
+        job.counter = p->frame_counter;
+        job.flag = p->frame_flag;
+        job.seq = p->frame_seq + 1;
+        if (int rc = launch_stencil5_framed(in, out, ld, ny, xstart, xstop, ystart, ystop, job, s, &fused)) return rc;
+        if (fused) {
+            p->frame_seq = job.seq;
+            if (int rc = launch_frame_flag_wait(p->frame_flag, job.seq, p->frame_timed_out, side)) return rc;
+            if (int rc = exchange_on(p, out, mask, side, prepacked)) return rc;
+            DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
+        }
+    }
+    if (!fused) {
+        if (int rc = launch_stencil5_frame(in, out, ld, ny, xstart, xstop, ystart, ystop, s, prepacked ? &fp : nullptr))
+            return rc;
+        DLESM_HIP_TRY(hipEventRecord(p->ev_frame, s));
+        // 2. exchange out's frame on the side stream ...
+        DLESM_HIP_TRY(hipStreamWaitEvent(side, p->ev_frame, 0));
+        if (int rc = exchange_on(p, out, mask, side, prepacked)) return rc;
+        DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
+        // 3. ... while the interior streams through HBM on the caller's stream
+        if (int rc = launch_stencil5(in, out, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, s)) return rc;
+    }
     // 4. join: the next step reads out's halos
     DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
     return DLESM_OK;

@@ -79,6 +79,22 @@ struct FramePack {
 };
 int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop,
                           int ystart, int ystop, hipStream_t s, const FramePack *pack = nullptr);
+// the frame as the first workgroups of the interior launch (jacobi5_tile_framed): when their last
+// one is done, `seq` is stored to `flag` (device memory; frame_flag_wait sleeps on it)
+struct FrameJob {
+    FramePack pk;
+    int fx0, fx1, fy0, fy1;       // 0-based frame box (filled in by launch_stencil5_framed)
+    int nblocks;                  // workgroups that do frame cells (filled in by the launcher)
+    unsigned *counter;            // device word, 0 between launches
+    unsigned long long *flag;
+    unsigned long long seq;
+};
+// Frame of the box + interior sweep in ONE launch.  *fused = false (and nothing launched) when the
+// arrays do not qualify for the 16-byte-lane tile kernel: the caller then takes the two-launch path.
+int launch_stencil5_framed(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart,
+                           int ystop, FrameJob job, hipStream_t s, bool *fused);
+// park stream `s` (one sleeping wave) until *flag >= seq; bounded, see frame_flag_wait
+int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s);
 
 // nsteps fused Jacobi steps (dlesm_jacobi_x2.hip); 1-based inclusive output box, last stage box,
 // grow flags -- see dlesm_stencil5_multi_f64

@@ -223,9 +223,9 @@ __global__ __launch_bounds__(256) void jacobi5_march(const double *__restrict__ 
 // (70 %, 69-70 % against 75-78 %; profiles/r01_sweep_tile_group.txt) and removed.
 // ===========================================================================
 template <int VEC, int R, bool NT>
-__global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ in,
-                                                    double *__restrict__ out, int ld, int x0, int x1,
-                                                    int y0, int y1, int c_first, int nxw, int flags)
+__device__ __forceinline__ void jacobi5_tile_body(const double *__restrict__ in, double *__restrict__ out,
+                                                  int ld, int x0, int x1, int y0, int y1, int c_first,
+                                                  int nxw, int flags, unsigned block)
 {
     const int lane = threadIdx.x & 63;
 #if DLESM_J5_SCALAR
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ 
 #else
     const int wv = threadIdx.x >> 6;
 #endif
-    const int w = blockIdx.x * (blockDim.x >> 6) + wv;  // wave-tile number
+    const int w = block * (blockDim.x >> 6) + wv;       // wave-tile number
     int xw = w % nxw, jb = y0 + (w / nxw) * R;
     const int by1 = y1;
 #if DLESM_J5_SCALAR
@@ -275,6 +275,88 @@ __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ 
             double o[VEC];
             jacobi_row<VEC>(r[u], r[u + 1], r[u + 2], e[u + 1], lane, o);
             store_chunk<VEC, NT>(pout + (size_t)(jb + u) * ld, o, m0, m1);
+        }
+    }
+}
+
+template <int VEC, int R, bool NT>
+__global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ in,
+                                                    double *__restrict__ out, int ld, int x0, int x1,
+                                                    int y0, int y1, int c_first, int nxw, int flags)
+{
+    jacobi5_tile_body<VEC, R, NT>(in, out, ld, x0, x1, y0, y1, c_first, nxw, flags, blockIdx.x);
+}
+
+// One cell of the one-cell-wide frame of the box (x0:x1, y0:y1), numbered t = 0 .. frame_cells-1:
+// south row, north row, then the west and east columns between them.  Cells of a west/east column
+// that a neighbour will receive also go into their send-buffer slot, in the j order of the pack
+// loop (parallel_comms_mod.f90:1678-1683).
+__device__ __forceinline__ long frame_cells(int w, int h)
+{
+    const int ncol = h > 2 ? h - 2 : 0, nrows = h > 1 ? 2 : 1;
+    return (long)nrows * w + 2L * ncol * (w > 1 ? 1 : 0) + (w == 1 ? ncol : 0);
+}
+// WT: store with device-scope write-through (relaxed agent-scope atomic stores), for frame cells that
+// another kernel reads while this one is still running.
+template <bool WT>
+__device__ __forceinline__ void frame_cell(long t, const double *__restrict__ in, double *__restrict__ out,
+                                           int ld, int x0, int x1, int y0, int y1, const FramePack &pk)
+{
+    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+    const int ncol = h > 2 ? h - 2 : 0, nrows = h > 1 ? 2 : 1;
+    int i, j;
+    if (t < (long)nrows * w) {
+        j = t < w ? y0 : y1;
+        i = x0 + (int)(t % w);
+    } else {
+        long k = t - (long)nrows * w;
+        if (w == 1) { i = x0; j = y0 + 1 + (int)k; }
+        else { i = k < ncol ? x0 : x1; j = y0 + 1 + (int)(k % ncol); }
+    }
+    const size_t o = (size_t)j * ld + i;
+    const double r = 0.25 * ((in[o - 1] + in[o + 1]) + (in[o - ld] + in[o + ld]));
+    auto put = [](double *p, double v) {
+        if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
+    put(out + o, r);
+    for (int k = 0; k < pk.n; k++)
+        if (i == pk.s[k].i && j >= pk.s[k].j0 && j < pk.s[k].j0 + pk.s[k].nj)
+            put(pk.buf + pk.s[k].off + (j - pk.s[k].j0), r);
+}
+
+// The distributed step in ONE launch on the caller's stream: the first fj.nblocks workgroups
+// compute the frame of the box (fx0:fx1, fy0:fy1) -- the cells the neighbours are waiting for --
+// and publish `seq` in a device-memory flag when the last of them is done (the library's side
+// stream holds a one-wave kernel that sleeps on that flag, frame_flag_wait, and starts the exchange
+// then); all other workgroups are the ordinary linear tile sweep over the interior (x0:x1, y0:y1).
+// No frame launch and no event record between frame and interior on the caller's stream: measured,
+// those cost it ~5 us of a 180 us step (scripts/syncbench.hip, profiles/r02_syncbench.txt).
+template <int VEC, int R, bool NT>
+__global__ __launch_bounds__(1024) void jacobi5_tile_framed(const double *__restrict__ in,
+                                                           double *__restrict__ out, int ld, int x0, int x1,
+                                                           int y0, int y1, int c_first, int nxw, int flags,
+                                                           FrameJob fj)
+{
+    if (blockIdx.x >= (unsigned)fj.nblocks) {
+        jacobi5_tile_body<VEC, R, NT>(in, out, ld, x0, x1, y0, y1, c_first, nxw, flags, blockIdx.x - fj.nblocks);
+        return;
+    }
+    const long total = frame_cells(fj.fx1 - fj.fx0 + 1, fj.fy1 - fj.fy0 + 1);
+    // The frame cells are read by the exchange while this kernel is still running, possibly from
+    // another XCD (whose L2 is not coherent with this one): they are stored write-through at device
+    // scope.  A per-thread __threadfence() instead would be a whole-L2 write-back + invalidate per
+    // wave, in the middle of the interior sweep -- measured: +35 us on a 180 us step.
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)fj.nblocks * blockDim.x)
+        frame_cell<true>(t, in, out, ld, fj.fx0, fj.fx1, fj.fy0, fj.fy1, fj.pk);
+    __builtin_amdgcn_s_waitcnt(0);        // this wave's stores have been acknowledged ...
+    __syncthreads();                      // ... and those of every wave of the group ...
+    if (threadIdx.x == 0) {               // ... before the group is counted as done
+        const unsigned done = __hip_atomic_fetch_add(fj.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (unsigned)fj.nblocks - 1) {
+            // ready for the next launch (launches on one plan are stream ordered)
+            __hip_atomic_store(fj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fj.flag, fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -396,7 +478,7 @@ static Shape g_shape_override = {0, 0};                 // set only while the au
 
 template <int VEC, bool NT>
 static void launch_tile(const double *in, double *out, int ld, int x0, int x1, int y0, int y1, int R,
-                        int flags, hipStream_t s)
+                        int flags, hipStream_t s, FrameJob *fj = nullptr)
 {
     if (R != 1 && R != 2 && R != 3 && R != 4 && R != 6 && R != 12 && R != 16) R = 8;
     // tiles are anchored on a 128-byte line of the row (not on the first interior column), so
@@ -418,6 +500,18 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
         else choose_block_shape(&nxw, &tpb);
     }
     const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
+    if (fj) {
+        // frame workgroups first (they are dispatched first): a multiple of 8 of them, so that the tile
+        // workgroups keep the XCD each would have had in the plain launch (round-robin dealing)
+        if constexpr (VEC == 2 && !NT) {
+            const long cells = 2L * (fj->fx1 - fj->fx0 + 1) + 2L * (fj->fy1 - fj->fy0 + 1);
+            long nb = ((cells + 64 * tpb - 1) / (64 * tpb) + 7) & ~7L;
+            fj->nblocks = (int)(nb < 8 ? 8 : nb > 256 ? 256 : nb);
+            hipLaunchKernelGGL((jacobi5_tile_framed<2, 2, false>), dim3(grid + fj->nblocks), dim3(64 * tpb), 0, s, in,
+                               out, ld, x0, x1, y0, y1, c_first, nxw, flags, *fj);
+        }
+        return;
+    }
     // (capping the resident waves with unused LDS -- 32 down to 16 waves per CU -- changes nothing
     // until 16, where it costs 2 %: the band of rows in flight is not a lever)
 #define DLESM_TILE(RR)                                                                               \
@@ -442,30 +536,10 @@ __global__ __launch_bounds__(256) void jacobi5_frame(const double *__restrict__ 
                                                      double *__restrict__ out, int ld, int x0, int x1,
                                                      int y0, int y1, FramePack pk)
 {
-    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-    const int ncol = h > 2 ? h - 2 : 0;
-    const int nrows = h > 1 ? 2 : 1;
-    const long total = (long)nrows * w + 2L * ncol * (w > 1 ? 1 : 0) + (w == 1 ? ncol : 0);
+    const long total = frame_cells(x1 - x0 + 1, y1 - y0 + 1);
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (long)gridDim.x * blockDim.x) {
-        int i, j;
-        if (t < (long)nrows * w) {
-            j = t < w ? y0 : y1;
-            i = x0 + (int)(t % w);
-        } else {
-            long k = t - (long)nrows * w;
-            if (w == 1) { i = x0; j = y0 + 1 + (int)k; }
-            else { i = k < ncol ? x0 : x1; j = y0 + 1 + (int)(k % ncol); }
-        }
-        const size_t o = (size_t)j * ld + i;
-        const double r = 0.25 * ((in[o - 1] + in[o + 1]) + (in[o - ld] + in[o + ld]));
-        out[o] = r;
-        // a west/east frame column that a neighbour will receive: also into its send-buffer slot,
-        // in the j order of the pack loop (parallel_comms_mod.f90:1678-1683)
-        for (int k = 0; k < pk.n; k++)
-            if (i == pk.s[k].i && j >= pk.s[k].j0 && j < pk.s[k].j0 + pk.s[k].nj)
-                pk.buf[pk.s[k].off + (j - pk.s[k].j0)] = r;
-    }
+         t += (long)gridDim.x * blockDim.x)
+        frame_cell<false>(t, in, out, ld, x0, x1, y0, y1, pk);
 }
 
 int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
@@ -593,6 +667,54 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
     }
 #undef DLESM_J5
     DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+// One wave parked on the frame flag: lane 0 sleeps until the flag reaches `seq`.  It holds one wave
+// slot and issues one load per sleep period; it never spins hot.  The wait is
+// bounded (about 2 s of the 100 MHz real-time counter): if the frame never reports -- which only a
+// failed launch could cause -- the kernel gives up, raises *timed_out (pinned host memory, checked
+// by the next step call) and lets the stream drain instead of hanging the device.
+__global__ void frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+        __builtin_amdgcn_s_sleep(64);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+            __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
+
+int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(frame_flag_wait, dim3(1), dim3(64), 0, s, flag, seq, timed_out);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+int launch_stencil5_framed(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart,
+                           int ystop, FrameJob job, hipStream_t s, bool *fused)
+{
+    *fused = false;
+    if (xstop - xstart < 2 || ystop - ystart < 2) return DLESM_OK;          // no interior: two-launch path
+    if (int rc = check_box("dlesm_jacobi5_step_dm", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    DLESM_REQUIRE(in != nullptr && out != nullptr && in != out, "stencil5: null or aliased arrays");
+    DLESM_REQUIRE(job.counter != nullptr && job.flag != nullptr, "stencil5 framed: no signal words");
+    const int variant = tuning("j5_variant", 0);
+    const int x1i = xstop - 2;                                              // east end of the interior, 0-based
+    const bool odd_ok = !(variant & 16) && x1i + 1 <= 2 * (ld / 2) - 1;
+    const bool vec2 = !(variant & 4) && ((ld % 2 == 0) || odd_ok) && ((uintptr_t)in % 16 == 0) &&
+                      ((uintptr_t)out % 16 == 0);
+    int R = tuning("j5_tile_rows", 0);
+    if (R < 1) R = 2;
+    if (!vec2 || (variant & 1) || tuning("j5_kernel", 0) != 0 || R != 2) return DLESM_OK;
+    job.fx0 = xstart - 1, job.fx1 = xstop - 1, job.fy0 = ystart - 1, job.fy1 = ystop - 1;
+    launch_tile<2, false>(in, out, ld, xstart, xstop - 2, ystart, ystop - 2, 2, (variant >> 3) & 1, s, &job);
+    DLESM_HIP_TRY(hipGetLastError());
+    *fused = true;
     return DLESM_OK;
 }
 

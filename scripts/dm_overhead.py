@@ -49,10 +49,14 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--out", default="gpurun_out/dm_overhead.json")
     ap.add_argument("--fused", type=int, default=1, help="T > 1: the fused T-step forms, depth-T halos")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="dlesm_set_tuning before init")
     args = ap.parse_args()
     import torch
     import dl_esm_inf_amd as D
     L = D._cabi.lib()
+    for kv in args.tune:
+        k, v = kv.split("=")
+        L.dlesm_set_tuning(k.encode(), int(v))
     torch.cuda.set_device(0)
     os.environ["DL_ESM_ALIGNMENT"] = "64"
     D.parallel_init(0, 1, use_rccl=True)
@@ -123,7 +127,7 @@ def main():
     res.pop("cold")
     same = bool(torch.equal(finals["serial"], finals["overlapped"]))
     cells = args.tile * args.tile
-    out = {"tile": args.tile, "launches": args.steps, "time_steps_per_launch": T, "ms_per_launch": res,
+    out = {"tile": args.tile, "tuning": args.tune, "launches": args.steps, "time_steps_per_launch": T, "ms_per_launch": res,
            "mcells_per_s": {k: cells * T / v / 1e3 for k, v in res.items()},
            "overlapped_equals_serial_bitwise": same,
            "overlap_efficiency_vs_plain": res["plain"] / res["overlapped"]}
