@@ -14,6 +14,11 @@
 // The expression trees are exactly those of the specification in DESIGN.md section 6 and the
 // file is compiled with -ffp-contract=off, so results agree bit for bit with the CPU checker
 // used by the tests.
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
 #include "dlesm_internal.h"
 
 namespace dlesm {
@@ -26,10 +31,17 @@ struct V2 {
     double x, y;
 };
 
+template <bool NT = false>
 __device__ __forceinline__ V2 ld2(const double *p)
 {
-    d2 t = *(const d2 *)p;
+    d2 t = NT ? __builtin_nontemporal_load((const d2 *)p) : *(const d2 *)p;
     return V2{t.x, t.y};
+}
+template <bool NT>
+__device__ __forceinline__ void st2(double *p, const V2 &v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(d2{v.x, v.y}, (d2 *)p);
+    else *(d2 *)p = d2{v.x, v.y};
 }
 // value of the column to the east / west of each of the lane's two columns
 // (DPP: whole-wave shift on the VALU instead of ds_bpermute, see dlesm_internal.h)
@@ -37,8 +49,13 @@ template <bool DPP> __device__ __forceinline__ V2 east_of(const V2 &a) { return 
 template <bool DPP> __device__ __forceinline__ V2 west_of(const V2 &a) { return V2{from_lower<DPP>(a.y), a.x}; }
 
 #define EW(expr_x, expr_y) V2{(expr_x), (expr_y)}
+// new time level stored non-temporally by default: +1.2 % at 8192^2 (profiles/r02_shallow_variants.txt)
+#define SW_NT_DEFAULT 2
 
-template <int R, bool DPP>
+// NTM bit 0: the old time level (read exactly once, by one lane) is loaded non-temporally;
+// bit 1: the new time level is stored non-temporally.  u, v, p keep the default policy: their
+// rows are re-read by the tile below.
+template <int R, bool DPP, int NTM>
 __global__ __launch_bounds__(512) void shallow_tile(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
@@ -79,9 +96,9 @@ __global__ __launch_bounds__(512) void shallow_tile(
         int jj = jb + k;
         if (jj > je) jj = je;
         const size_t o = (size_t)jj * ld + col;
-        UO[k] = ld2(uold + o);
-        VO[k] = ld2(vold + o);
-        PO[k] = ld2(pold + o);
+        UO[k] = ld2<(NTM & 1) != 0>(uold + o);
+        VO[k] = ld2<(NTM & 1) != 0>(vold + o);
+        PO[k] = ld2<(NTM & 1) != 0>(pold + o);
     }
 
     // raw neighbours
@@ -142,9 +159,9 @@ __global__ __launch_bounds__(512) void shallow_tile(
                          PO[k - 1].y - q.tdtsdx * (CU[k].y - CUw[k].y) - q.tdtsdy * (CV[k].y - CV[k - 1].y));
         const size_t o = (size_t)jj * ld + (size_t)c * 2;
         if (m0 && m1) {
-            *(d2 *)(unew + o) = d2{un.x, un.y};
-            *(d2 *)(vnew + o) = d2{vn.x, vn.y};
-            *(d2 *)(pnew + o) = d2{pn.x, pn.y};
+            st2<(NTM & 2) != 0>(unew + o, un);
+            st2<(NTM & 2) != 0>(vnew + o, vn);
+            st2<(NTM & 2) != 0>(pnew + o, pn);
         } else {
             if (m0) { unew[o] = un.x; vnew[o] = vn.x; pnew[o] = pn.x; }
             if (m1) { unew[o + 1] = un.y; vnew[o + 1] = vn.y; pnew[o + 1] = pn.y; }
@@ -154,12 +171,21 @@ __global__ __launch_bounds__(512) void shallow_tile(
 
 } // namespace
 
-void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,
-                         const double *u, const double *v, const double *p, const double *uold,
-                         const double *vold, const double *pold, double *unew, double *vnew,
-                         double *pnew, hipStream_t s)
+// Measured launch shapes (dlesm_shallow_autotune_f64), as for the Jacobi sweep: every shape and
+// cache policy computes the same bits, so the fastest for a given (leading dimension, box) is
+// simply timed once and remembered.
+struct SwKey {
+    int ld, x0, x1, y0, y1;
+    bool operator<(const SwKey &o) const { return std::tie(ld, x0, x1, y0, y1) < std::tie(o.ld, o.x0, o.x1, o.y0, o.y1); }
+};
+struct SwShape { int tpb, nxw, ntm; };
+static std::mutex g_sw_mu;
+static std::map<SwKey, SwShape> g_sw_cache;
+static SwShape g_sw_override = {0, 0, 0};
+
+static void sw_rule_shape(int ld, int x0, int x1, int *nxw_out, int *tpb_out)
 {
-    const int cb = x0 / 2, c_last = x1 / 2;              // first / last chunk holding an output column
+    const int cb = x0 / 2, c_last = x1 / 2;
     int nxw = (c_last - cb + 62) / 62, tpb = 4;          // 62 output chunks per wave tile
     // This kernel's landscape differs from the Jacobi one (nine arrays in flight): an exhaustive search at
     // 8192^2 (scripts/shallow_probe.py 8192 search; 67 tiles per row) finds 8 waves per group JUST ABOVE a
@@ -183,6 +209,24 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
         nxw += pad;
         if (nxw >= 128 && nxw % (8 * tpb) == 0) nxw += 1;
     }
+    *nxw_out = nxw;
+    *tpb_out = tpb;
+}
+
+void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,
+                         const double *u, const double *v, const double *p, const double *uold,
+                         const double *vold, const double *pold, double *unew, double *vnew,
+                         double *pnew, hipStream_t s)
+{
+    const int cb = x0 / 2;                               // first chunk holding an output column
+    int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & 3;
+    {
+        std::lock_guard<std::mutex> lk(g_sw_mu);
+        auto it = g_sw_cache.find(SwKey{ld, x0, x1, y0, y1});
+        if (g_sw_override.tpb) { tpb = g_sw_override.tpb; nxw = g_sw_override.nxw; ntm = g_sw_override.ntm; }
+        else if (it != g_sw_cache.end() && tuning("j5_use_tuned", 1)) { tpb = it->second.tpb; nxw = it->second.nxw; ntm = it->second.ntm; }
+        else sw_rule_shape(ld, x0, x1, &nxw, &tpb);
+    }
     if (tpb > 8) tpb = 8;                                // the kernel is bounded to 512 threads
     int R = tuning("sw_tile_rows", 2);
     if (R != 1 && R != 3) R = 2;
@@ -190,19 +234,116 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     const long tiles = (long)nxw * strips;
     const unsigned grid = (unsigned)((tiles + tpb - 1) / tpb);
     const bool dpp = tuning("sw_dpp", 1);
+#define DLESM_SW3(RR, DD, NN)                                                                                  \
+    hipLaunchKernelGGL((shallow_tile<RR, DD, NN>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, \
+                       nxw, u, v, p, uold, vold, pold, unew, vnew, pnew)
+#define DLESM_SW2(RR, DD)                                                                                      \
+    do {                                                                                                       \
+        switch (ntm) {                                                                                         \
+        case 1: DLESM_SW3(RR, DD, 1); break;                                                                   \
+        case 2: DLESM_SW3(RR, DD, 2); break;                                                                   \
+        case 3: DLESM_SW3(RR, DD, 3); break;                                                                   \
+        default: DLESM_SW3(RR, DD, 0); break;                                                                  \
+        }                                                                                                      \
+    } while (0)
 #define DLESM_SW(RR)                                                                                           \
     do {                                                                                                       \
-        if (dpp)                                                                                               \
-            hipLaunchKernelGGL((shallow_tile<RR, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, \
-                               cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew);                          \
-        else                                                                                                   \
-            hipLaunchKernelGGL((shallow_tile<RR, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, \
-                               cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew);                          \
+        if (dpp) DLESM_SW2(RR, true);                                                                          \
+        else DLESM_SW2(RR, false);                                                                             \
     } while (0)
     if (R == 1) DLESM_SW(1);
     else if (R == 3) DLESM_SW(3);
     else DLESM_SW(2);
+#undef DLESM_SW2
+#undef DLESM_SW3
 #undef DLESM_SW
 }
 
 } // namespace dlesm
+
+using namespace dlesm;
+
+extern "C" int dlesm_shallow_autotune_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop,
+                                          int ystart, int ystop, const double *u, const double *v,
+                                          const double *p, const double *uold, const double *vold,
+                                          const double *pold, double *unew, double *vnew, double *pnew,
+                                          void *stream)
+{
+    // the step itself validates the arguments, warms the clocks, and tells whether the tile kernel applies
+    if (int rc = dlesm_shallow_step_f64(q, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, unew,
+                                        vnew, pnew, stream))
+        return rc;
+    if (xstop < xstart || ystop < ystart || tuning("sw_kernel", 0) != 0) return DLESM_OK;
+    const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
+    const int nxw0 = (x1 / 2 - x0 / 2 + 62) / 62;
+    if (nxw0 < 16 || tuning("sw_tile_rows", 2) != 2) return DLESM_OK;      // thin boxes: nothing to choose
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<SwShape> cand;
+    auto add = [&](int tpb, int t, int ntm) {
+        for (const SwShape &c : cand)
+            if (c.tpb == tpb && c.nxw == t && c.ntm == ntm) return;
+        cand.push_back(SwShape{tpb, t, ntm});
+    };
+    int rn, rt;
+    sw_rule_shape(ld, x0, x1, &rn, &rt);
+    if (rt > 8) rt = 8;
+    const int nt0 = tuning("sw_nt", SW_NT_DEFAULT) & 3;
+    add(rt, rn, nt0);                                                      // the rule's own choice first
+    for (int tpb : {8, 4}) {
+        add(tpb, nxw0, nt0);
+        const int period = 8 * tpb, dmax = tpb == 8 ? 3 : 1;
+        for (int k = 0; k < 2; k++) {
+            const int base = (nxw0 / period + k) * period;
+            for (int d = 0; d <= dmax; d++) {
+                if (base - d >= nxw0) add(tpb, base - d, nt0);
+                if (base + d >= nxw0) add(tpb, base + d, nt0);
+            }
+        }
+    }
+    hipEvent_t e0, e1;
+    DLESM_HIP_TRY(hipEventCreate(&e0));
+    DLESM_HIP_TRY(hipEventCreate(&e1));
+    int rc = DLESM_OK;
+    auto measure = [&](std::vector<float> &best_of) {
+        // three interleaved passes (clock drift hits all candidates alike); a trial is 3 back-to-back
+        // launches between two events; the first trial of a pass is a warm-up
+        for (int pass = 0; pass < 3 && !rc; pass++)
+            for (size_t k = 0; k <= cand.size() && !rc; k++) {
+                const SwShape c = cand[k ? k - 1 : 0];
+                { std::lock_guard<std::mutex> lk(g_sw_mu); g_sw_override = c; }
+                (void)hipEventRecord(e0, s);
+                for (int rep = 0; rep < 3; rep++)
+                    launch_shallow_tile(*q, ld, x0, x1, y0, y1, u, v, p, uold, vold, pold, unew, vnew, pnew, s);
+                (void)hipEventRecord(e1, s);
+                { std::lock_guard<std::mutex> lk(g_sw_mu); g_sw_override = SwShape{0, 0, 0}; }
+                if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess)
+                    rc = fail(DLESM_EHIP, "shallow autotune: launch or synchronisation failed");
+                float ms = 0.f;
+                if (!rc && k > 0 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_of[k - 1]) best_of[k - 1] = ms;
+            }
+    };
+    std::vector<float> t1(cand.size(), 1e30f);
+    measure(t1);
+    SwShape best = cand[0];
+    float best_ms = t1[0] * 0.995f;                       // the rule's choice stays unless beaten by 0.5 %
+    if (!rc) {
+        for (size_t k = 1; k < cand.size(); k++)
+            if (t1[k] < best_ms) { best_ms = t1[k]; best = cand[k]; }
+        // second round: the cache policies on the chosen shape
+        cand.clear();
+        for (int ntm : {best.ntm, 0, 2, 3, 1}) add(best.tpb, best.nxw, ntm);
+        std::vector<float> t2(cand.size(), 1e30f);
+        measure(t2);
+        if (!rc) {
+            best_ms = t2[0] * 0.995f;
+            for (size_t k = 1; k < cand.size(); k++)
+                if (t2[k] < best_ms) { best_ms = t2[k]; best = cand[k]; }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_sw_mu);
+    g_sw_cache[SwKey{ld, x0, x1, y0, y1}] = best;
+    return DLESM_OK;
+}

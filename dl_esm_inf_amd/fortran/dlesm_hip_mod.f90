@@ -167,6 +167,14 @@ module dlesm_hip_mod
        type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
        integer(c_int) :: rc
      end function
+     function dlesm_shallow_autotune_f64(params, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
+          uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_autotune_f64") result(rc)
+       import :: c_int, c_ptr, c_sw_params
+       type(c_sw_params), intent(in) :: params
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
+       integer(c_int) :: rc
+     end function
      function dlesm_copy_patch_f64(src, dst, ld, ny_arr, sx0, sy0, dx0, dy0, nx, ny, stream) &
           bind(C, name="dlesm_copy_patch_f64") result(rc)
        import :: c_int, c_ptr

@@ -48,7 +48,7 @@ module dlesm_psy_mod
   private
 
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
-  public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5
+  public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5, plan_shallow_step
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
 
 contains
@@ -170,6 +170,26 @@ contains
                                 c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_shallow_step: ' // dlesm_error_text())
   end subroutine invoke_shallow_step
+
+  !> Optional planning call for invoke_shallow_step (like plan_jacobi5): the library times its
+  !! launch shapes and cache policies on these fields once -- every trial is the same valid step
+  !! into unew, vnew, pnew -- and keeps the fastest for this field geometry.
+  subroutine plan_shallow_step(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)
+    type(c_sw_params), intent(in) :: prm
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    rc = dlesm_shallow_autotune_f64(prm, int(p%grid%nx, c_int), int(p%grid%ny, c_int), &
+                                    int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                                    int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                                    field_device_data(u), field_device_data(v), field_device_data(p), &
+                                    field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                    field_device_data(unew), field_device_data(vnew), field_device_data(pnew), &
+                                    c_null_ptr)
+    if (rc /= 0) call gocean_stop('plan_shallow_step: ' // dlesm_error_text())
+  end subroutine plan_shallow_step
 
   !> Distributed shallow-water step: u, v, p must have valid halos; unew, vnew, pnew leave with
   !! theirs, exchanged in ONE grouped RCCL launch that runs behind the interior sweep.

@@ -79,6 +79,17 @@ def invoke_shallow_step(params, u, v, p, uold, vold, pold, unew, vnew, pnew, str
                                              pnew.device_ptr, _stream_ptr(stream)))
 
 
+def autotune_shallow(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
+    """optional planning call for invoke_shallow_step: time the launch shapes / cache policies once
+    for this field geometry (each trial is the same valid step) and keep the fastest"""
+    g, it = p.grid, p.internal
+    check(_cabi.lib().dlesm_shallow_autotune_f64(C.byref(params), g.nx, g.ny, it.xstart, it.xstop,
+                                                 it.ystart, it.ystop, u.device_ptr, v.device_ptr,
+                                                 p.device_ptr, uold.device_ptr, vold.device_ptr,
+                                                 pold.device_ptr, unew.device_ptr, vnew.device_ptr,
+                                                 pnew.device_ptr, _stream_ptr(stream)))
+
+
 def invoke_shallow_step_dm(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
     """distributed form: frame of the new fields, one grouped exchange of all three behind the
     interior; unew, vnew, pnew leave with valid halos"""

@@ -233,6 +233,16 @@ int dlesm_shallow_step_f64(const dlesm_sw_params *params, int ld, int ny,
                            const double *uold, const double *vold, const double *pold,
                            double *unew, double *vnew, double *pnew, void *stream);
 
+/* Optional planning call for dlesm_shallow_step_f64, like dlesm_stencil5_autotune_f64: times a
+ * dozen launch shapes and the cache policies of the once-read / once-written arrays on the caller's
+ * own arrays (each trial is the same valid step) and remembers the fastest for this (ld, box).
+ * Synchronises `stream`. */
+int dlesm_shallow_autotune_f64(const dlesm_sw_params *params, int ld, int ny,
+                               int xstart, int xstop, int ystart, int ystop,
+                               const double *u, const double *v, const double *p,
+                               const double *uold, const double *vold, const double *pold,
+                               double *unew, double *vnew, double *pnew, void *stream);
+
 /* field_copy_code over a box (infrastructure_mod.f90:32-41) and the patch copy
  * used for periodic boundaries (copy_2dfield_patch, field_mod.f90:1179-1187):
  * dst(dx0.., dy0..) = src(sx0.., sy0..) for an nx x ny patch. */

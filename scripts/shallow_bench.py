@@ -50,10 +50,18 @@ def main():
     cells = args.tile * args.tile
     res = {}
     with torch.cuda.stream(s):
-        for label, kern, rows in (("tile R=2", 0, 2), ("tile R=1", 0, 1), ("tile R=3", 0, 3), ("direct", 1, 2),
-                                  ("tile R=2 again", 0, 2)):
+        for label, kern, rows, nt in (("tile R=2", 0, 2, 0), ("tile R=2 nt old loads", 0, 2, 1), ("tile R=2 nt stores", 0, 2, 2),
+                                      ("tile R=2 nt both", 0, 2, 3), ("tile R=3 nt both", 0, 3, 3), ("tile R=1", 0, 1, 0),
+                                      ("tile R=3", 0, 3, 0), ("direct", 1, 2, 0), ("tile R=2 again", 0, 2, 0),
+                                      ("tile R=2 nt both again", 0, 2, 3), ("tile R=2 default + planning call", 0, 2, -1),
+                                      ("tile R=2 default, rule", 0, 2, -2)):
             L.dlesm_set_tuning(b"sw_kernel", kern)
             L.dlesm_set_tuning(b"sw_tile_rows", rows)
+            L.dlesm_set_tuning(b"sw_nt", nt if nt >= 0 else 2)
+            L.dlesm_set_tuning(b"j5_use_tuned", 0 if nt == -2 else 1)
+            if nt == -1:
+                D.psy.autotune_shallow(prm, F["u"], F["v"], F["p"], F["uold"], F["vold"], F["pold"], F["unew"], F["vnew"],
+                                       F["pnew"], stream=s)
             cur = [F["u"], F["v"], F["p"]]
             old = [F["uold"], F["vold"], F["pold"]]
             new = [F["unew"], F["vnew"], F["pnew"]]

@@ -518,6 +518,40 @@ def test_shallow_step_matches_oracle(D, nx, ny, alignment, sw_kernel, sw_rows, s
     _set_tuning(D, sw_kernel=0, sw_tile_rows=2, sw_dpp=1)
 
 
+@pytest.mark.parametrize("nx,ny,alignment", [(300, 70, 64), (2100, 33, 64), (4000, 9, 2)])
+def test_shallow_cache_policies_and_planned_shapes_change_no_bit(D, nx, ny, alignment):
+    """non-temporal loads of the old level / stores of the new level (sw_nt 0..3) and the launch shape
+    the planning call picks (dlesm_shallow_autotune_f64) are performance choices only"""
+    import torch
+    g = _grid(D, nx, ny, alignment)
+    names, F = _sw_fields(D, g)
+    for k, n in enumerate(names[:6]):
+        D.psy.hash_init(F[n], SEED + 20 + k)
+        F[n].data.add_(1.0 if n[0] == "p" else -0.5)
+    prm = D.psy.shallow_params(1.0e5, 0.8e5, 90.0)
+    H = {n: F[n].get_data() for n in names[:6]}
+    want = [np.full_like(H["u"], 9.0) for _ in range(3)]
+    O.sw_step(prm, g.nx, F["p"].internal.box(), *[H[n] for n in names[:6]], *want)
+
+    def check(tag):
+        for n in names[6:]:
+            D.set_field(F[n], 9.0)
+        D.psy.invoke_shallow_step(prm, *[F[n] for n in names])
+        torch.cuda.synchronize()
+        for n, w in zip(names[6:], want):
+            assert np.array_equal(F[n].get_data(), w), (tag, n)
+
+    for nt in (0, 1, 2, 3):
+        _set_tuning(D, sw_nt=nt)
+        check(f"sw_nt={nt}")
+    _set_tuning(D, sw_nt=2)
+    D.psy.autotune_shallow(prm, *[F[n] for n in names])
+    check("planned")
+    _set_tuning(D, j5_use_tuned=0)
+    check("rule")
+    _set_tuning(D, j5_use_tuned=1)
+
+
 def _sw_fields(D, g):
     names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
     pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
