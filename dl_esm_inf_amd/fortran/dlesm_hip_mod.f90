@@ -159,6 +159,13 @@ module dlesm_hip_mod
        integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
        integer(c_int) :: rc
      end function
+     function dlesm_stencil5_masked_f64(in, out, tmask, ld, ny, xstart, xstop, ystart, ystop, stream) &
+          bind(C, name="dlesm_stencil5_masked_f64") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: in, out, tmask, stream
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       integer(c_int) :: rc
+     end function
      function dlesm_shallow_step_f64(params, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
           uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_step_f64") result(rc)
        import :: c_int, c_ptr, c_sw_params

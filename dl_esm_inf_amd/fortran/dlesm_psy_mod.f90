@@ -47,6 +47,7 @@ module dlesm_psy_mod
   implicit none
   private
 
+  public :: invoke_jacobi5_masked
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
   public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5, plan_shallow_step
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
@@ -74,6 +75,24 @@ contains
                             int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_jacobi5: ' // dlesm_error_text())
   end subroutine invoke_jacobi5
+
+  !> The PSy layer of a kernel whose metadata requests the T mask,
+  !!   go_arg(GO_WRITE, GO_CT, GO_POINTWISE), go_arg(GO_READ, GO_CT, GO_STENCIL(010,111,010)),
+  !!   go_arg(GO_READ, GO_GRID_MASK_T)                          (argument_mod.f90:75-112)
+  !! i.e. `call jacobi5_masked_code(ji, jj, out%data, in%data, out%grid%tmask)` over out%internal:
+  !! the kernel gets the grid's mask -- on the device its mirror grid%tmask_device, created on
+  !! first use.  Dry points carry their value over, dry neighbours are mirrored.
+  subroutine invoke_jacobi5_masked(out, in)
+    type(r2d_field), intent(inout), target :: out, in
+    integer(c_int) :: rc
+    call need_device(in);  call need_device(out)
+    if (.not. c_associated(out%grid%tmask_device)) call grid_to_device(out%grid)
+    rc = dlesm_stencil5_masked_f64(field_device_data(in), field_device_data(out), out%grid%tmask_device, &
+                                   int(out%grid%nx, c_int), int(out%grid%ny, c_int), &
+                                   int(out%internal%xstart, c_int), int(out%internal%xstop, c_int), &
+                                   int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_jacobi5_masked: ' // dlesm_error_text())
+  end subroutine invoke_jacobi5_masked
 
   !> Optional planning call (once per field geometry, outside the time loop): lets the library time
   !! its launch shapes for invoke_jacobi5 / invoke_jacobi5_dm on these fields and keep the fastest.

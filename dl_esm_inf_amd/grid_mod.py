@@ -34,6 +34,22 @@ class grid_type:
         self.comm_tables = None
         self._halo_plan = None
         self.halo_width = 1
+        self.tmask = None              # host copy, (ny, nx) int32 (grid_mod.f90:100)
+        self._tmask_device = None      # its HBM mirror (grid_mod.f90:104-106), made on first use
+
+    @property
+    def tmask_device(self):
+        """device mirror of the T mask, a (ny, nx) int32 tensor"""
+        if self._tmask_device is None:
+            import torch
+            if self.tmask is None:
+                raise _cabi.GoceanStop(_cabi.EABORT, "grid%tmask requested before grid_init")
+            self._tmask_device = torch.from_numpy(self.tmask).cuda()
+        return self._tmask_device
+
+    @property
+    def tmask_device_ptr(self):
+        return C.c_void_p(self.tmask_device.data_ptr())
 
     def decompose(self, domainx, domainy, ndomains=None, ndomainx=None, ndomainy=None, halo_width=1):
         """grid_mod.f90:183-211"""
@@ -60,6 +76,8 @@ def grid_init(grid, dxarg, dyarg, tmask=None):
         raise _cabi.GoceanStop(_cabi.EABORT, "grid_init: ERROR: Periodic boundary conditions are "
                                              "not yet supported.")
     grid.dx, grid.dy = float(dxarg), float(dyarg)
+    grid.tmask = _make_tmask(grid, tmask)
+    grid._tmask_device = None
     if nranks > 1:
         if periodic:                                       # grid_mod.f90:559-564
             raise _cabi.GoceanStop(_cabi.EABORT, "map_comms call needs to be implemented for "
@@ -71,6 +89,27 @@ def grid_init(grid, dxarg, dyarg, tmask=None):
         grid.comm_tables = parallel_mod.map_comms(grid.decomp, depth=None if hw == 1 else hw)
     else:
         grid.comm_tables = _cabi.CommTables()              # serial: no messages (pcomms:216)
+
+
+def _make_tmask(grid, tmask):
+    """grid_init's T mask (grid_mod.f90:394-455): the grid's own copy of the user's mask on the
+    subdomain plus its one-cell ring, rows and columns beyond the ring replicated from it; without a
+    user mask the same region is all wet (1).  Cells the reference leaves unset are 0 here.
+    Arrays are (ny, nx) row-major = the Fortran (nx, ny)."""
+    import numpy as np
+    it = grid.subdomain.internal
+    xs, xe, ys, ye = it.xstart, it.xstop, it.ystart, it.ystop
+    m = np.zeros((grid.ny, grid.nx), dtype=np.int32)
+    if tmask is None:
+        m[ys - 2:ye + 1, xs - 2:xe + 1] = 1
+        return m
+    t = np.asarray(tmask)
+    m[ys - 2:ye + 1, xs - 2:xe + 1] = t[ys - 2:ye + 1, xs - 2:xe + 1]
+    m[ye + 1:, :] = m[ye, :]                   # rows ystop+2 .. ny  <- row ystop+1   (:416-418)
+    m[:ys - 2, :] = m[ys - 2, :]               # rows 1 .. ystart-2  <- row ystart-1  (:420-422)
+    m[:, :xs - 2] = m[:, xs - 2:xs - 1]        # cols 1 .. xstart-2  <- col xstart-1  (:424-426)
+    m[:, xe + 1:] = m[:, xe:xe + 1]            # cols xstop+2 .. nx  <- col xstop+1   (:428-430)
+    return m
 
 
 def halo_plan(grid):

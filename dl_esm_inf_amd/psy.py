@@ -17,6 +17,15 @@ def invoke_jacobi5(out_fld, in_fld, stream=None):
                                          _stream_ptr(stream)))
 
 
+def invoke_jacobi5_masked(out_fld, in_fld, stream=None):
+    """the masked Jacobi kernel (metadata: GO_GRID_MASK_T): the PSy layer hands the kernel the
+    grid's T mask, here its device mirror"""
+    g, it = out_fld.grid, out_fld.internal
+    check(_cabi.lib().dlesm_stencil5_masked_f64(in_fld.device_ptr, out_fld.device_ptr, g.tmask_device_ptr, g.nx,
+                                                g.ny, it.xstart, it.xstop, it.ystart, it.ystop,
+                                                _stream_ptr(stream)))
+
+
 def autotune_jacobi5(out_fld, in_fld, stream=None):
     """optional planning call: measure the launch shapes of invoke_jacobi5 for this field geometry
     once (each trial is the same valid step in -> out) and keep the fastest"""

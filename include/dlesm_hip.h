@@ -221,6 +221,15 @@ int dlesm_stencil5_multi_f64(const double *in, double *out, int ld, int ny, int 
                              int exstart, int exstop, int eystart, int eystop,
                              int grow_w, int grow_e, int grow_s, int grow_n, void *stream);
 
+/* The same loop nest for a kernel that requests a GRID PROPERTY: the T-point land/sea mask
+ * (GO_GRID_MASK_T in the kernel metadata, argument_mod.f90:75-112; the PSy layer passes
+ * grid%tmask, here its device mirror grid%tmask_device, grid_mod.f90:104-106).  tmask is a
+ * default-integer array with the field layout, > 0 = wet.  Dry points carry their value over;
+ * a dry neighbour of a wet point is mirrored (no-flux coast):
+ *   out = tmask(ji,jj) > 0 ? 0.25*((w+e)+(s+n)) : in(ji,jj),  w = tmask(ji-1,jj) > 0 ? in(ji-1,jj) : in(ji,jj), ... */
+int dlesm_stencil5_masked_f64(const double *in, double *out, const int *tmask, int ld, int ny,
+                              int xstart, int xstop, int ystart, int ystop, void *stream);
+
 /* Shallow-water u/v/h update: reads u,v,p (3x3 footprint)
  * and uold,vold,pold, writes unew,vnew,pnew on the box. */
 typedef struct dlesm_sw_params {

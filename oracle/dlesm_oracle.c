@@ -555,6 +555,53 @@ void orc_jacobi5(const double *in, double *out, int ld,
         for (int ji = xstart; ji <= xstop; ji++) jacobi5_code(ji, jj, out, in, ld);
 }
 
+/* The same PSy loop nest for a kernel that requests the T mask (GO_GRID_MASK_T,
+ * argument_mod.f90:75-112): specification frozen in DESIGN.md section 5.7 -- dry points carry
+ * their value over, a dry neighbour is mirrored (no-flux coast).  tmask has the field layout. */
+static inline void jacobi5_masked_code(int ji, int jj, double *out, const double *in, const int *tmask, int ld)
+{
+    const double c = in[IDX(ld, ji, jj)];
+    if (tmask[IDX(ld, ji, jj)] <= 0) {
+        out[IDX(ld, ji, jj)] = c;
+        return;
+    }
+    const double w = tmask[IDX(ld, ji - 1, jj)] > 0 ? in[IDX(ld, ji - 1, jj)] : c;
+    const double e = tmask[IDX(ld, ji + 1, jj)] > 0 ? in[IDX(ld, ji + 1, jj)] : c;
+    const double s = tmask[IDX(ld, ji, jj - 1)] > 0 ? in[IDX(ld, ji, jj - 1)] : c;
+    const double n = tmask[IDX(ld, ji, jj + 1)] > 0 ? in[IDX(ld, ji, jj + 1)] : c;
+    out[IDX(ld, ji, jj)] = 0.25 * ((w + e) + (s + n));
+}
+
+void orc_jacobi5_masked(const double *in, double *out, const int *tmask, int ld,
+                        int xstart, int xstop, int ystart, int ystop)
+{
+    for (int jj = ystart; jj <= ystop; jj++)
+        for (int ji = xstart; ji <= xstop; ji++) jacobi5_masked_code(ji, jj, out, in, tmask, ld);
+}
+
+/* grid_init's T mask, grid_mod.f90:394-455: the grid's own (nx, ny) copy of the user's mask --
+ * copy-in of the subdomain plus its one-cell ring (:407-412), then the rows beyond the ring take
+ * the ring row (:416-422) and the columns beyond it the ring column (:424-430).  user == NULL:
+ * the all-wet mask on the same region (:447-453); cells the reference leaves unset are 0 here.
+ * `user` has leading dimension user_ld (the subdomain's whole width, as the callers allocate it). */
+void orc_tmask_fill(const int *user, int user_ld, int nx, int ny, int xstart, int xstop, int ystart,
+                    int ystop, int *tmask)
+{
+    for (long k = 0; k < (long)nx * ny; k++) tmask[k] = 0;
+    for (int jj = ystart - 1; jj <= ystop + 1; jj++)
+        for (int ji = xstart - 1; ji <= xstop + 1; ji++)
+            tmask[IDX(nx, ji, jj)] = user ? user[IDX(user_ld, ji, jj)] : 1;
+    if (!user) return;
+    for (int jj = ystop + 2; jj <= ny; jj++)                                  /* "North" :416-418 */
+        for (int ji = 1; ji <= nx; ji++) tmask[IDX(nx, ji, jj)] = tmask[IDX(nx, ji, ystop + 1)];
+    for (int jj = 1; jj <= ystart - 2; jj++)                                  /* "South" :420-422 */
+        for (int ji = 1; ji <= nx; ji++) tmask[IDX(nx, ji, jj)] = tmask[IDX(nx, ji, ystart - 1)];
+    for (int ji = 1; ji <= xstart - 2; ji++)                                  /* :424-426 */
+        for (int jj = 1; jj <= ny; jj++) tmask[IDX(nx, ji, jj)] = tmask[IDX(nx, xstart - 1, jj)];
+    for (int ji = xstop + 2; ji <= nx; ji++)                                  /* :428-430 */
+        for (int jj = 1; jj <= ny; jj++) tmask[IDX(nx, ji, jj)] = tmask[IDX(nx, xstop + 1, jj)];
+}
+
 void orc_jacobi5_omp(const double *in, double *out, int ld,
                      int xstart, int xstop, int ystart, int ystop, int nthreads)
 {

@@ -112,6 +112,11 @@ double orc_hash_u01(uint64_t seed, int64_t gi, int64_t gj);
 void orc_jacobi5(const double *in, double *out, int ld,
                  int xstart, int xstop, int ystart, int ystop);
 /* same loops with an OpenMP `parallel for` over jj (what PSyclone's OMP transformation emits) */
+/* masked 5-point Jacobi (kernel with a GO_GRID_MASK_T argument); grid_init's tmask fill */
+void orc_jacobi5_masked(const double *in, double *out, const int *tmask, int ld,
+                        int xstart, int xstop, int ystart, int ystop);
+void orc_tmask_fill(const int *user, int user_ld, int nx, int ny, int xstart, int xstop, int ystart,
+                    int ystop, int *tmask);
 void orc_jacobi5_omp(const double *in, double *out, int ld,
                      int xstart, int xstop, int ystart, int ystop, int nthreads);
 

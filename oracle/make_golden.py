@@ -143,6 +143,21 @@ def golden_model():
     return res
 
 
+def golden_tmask():
+    """grid%tmask after grid_init(tmask = a -1/0/1 pattern): copy-in + boundary fill"""
+    res = {"_provenance": "reference grid_init (grid_mod.f90:394-432) with tmask(i,j) = mod(7i+13j,3)-1 run via "
+                          "oracle/_ref/ref_dump.exe tmask; rows are grid%tmask(1:nx, j)", "cases": []}
+    for nx, ny, al in [(10, 4, None), (10, 4, 8), (7, 9, 64), (16, 5, 4), (4, 10, 1)]:
+        env = {"DL_ESM_ALIGNMENT": str(al)} if al else None
+        rc, so, se = run("ref_dump.exe", "tmask", nx, ny, env_extra=env)
+        assert rc == 0, se
+        g = g_lines(so)
+        rows = sorted((ints(r) for r in g["tmaskrow"]), key=lambda r: r[0])
+        res["cases"].append({"nx": nx, "ny": ny, "alignment": al, "grid": ints(g["grid"][0]),
+                             "tmask": [r[1:] for r in rows]})
+    return res
+
+
 def golden_device_io():
     res = {"_provenance": "reference tests/device_computation/test_device_io.f90 compiled "
                           "unmodified -> ref_device_io.exe; 'Resulting array' rows as printed",
@@ -164,7 +179,8 @@ def main():
         sys.exit("oracle/_ref not built: run `make -C oracle ref` in the build container")
     os.makedirs(OUT, exist_ok=True)
     for name, fn in [("ref_decomp", golden_decomp), ("ref_bounds", golden_bounds),
-                     ("ref_model", golden_model), ("ref_device_io", golden_device_io)]:
+                     ("ref_model", golden_model), ("ref_device_io", golden_device_io),
+                     ("ref_tmask", golden_tmask)]:
         data = fn()
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(data, f, indent=None, separators=(",", ":"))

@@ -42,6 +42,8 @@ program ref_dump
      call dump_model(nx, ny, fill)
   case ('gather')
      call dump_gather(nx, ny)
+  case ('tmask')
+     call dump_tmask(nx, ny)
   case default
      stop 'ref_dump: unknown command'
   end select
@@ -121,6 +123,29 @@ contains
     write(*, '("G: xt ",3(ES24.16E3,1x))') g%xt(1,1), g%xt(2,1), g%xt(g%nx,1)
     write(*, '("G: yt ",3(ES24.16E3,1x))') g%yt(1,1), g%yt(1,2), g%yt(1,g%ny)
   end subroutine dump_model
+
+  !> grid_init with a patterned T mask (values -1, 0, 1): the grid's tmask after the copy-in and
+  !! the boundary fill (grid_mod.f90:394-432), row by row.
+  subroutine dump_tmask(nx, ny)
+    integer, intent(in) :: nx, ny
+    type(grid_type), target :: g
+    integer, allocatable :: tmask(:,:)
+    integer :: i, j
+    g = grid_type(GO_ARAKAWA_C, (/GO_BC_EXTERNAL, GO_BC_EXTERNAL, GO_BC_NONE/), &
+                  GO_OFFSET_NE)
+    call g%decompose(nx, ny)
+    allocate(tmask(g%subdomain%global%nx, g%subdomain%global%ny))
+    do j = 1, size(tmask, 2)
+       do i = 1, size(tmask, 1)
+          tmask(i, j) = mod(7*i + 13*j, 3) - 1
+       end do
+    end do
+    call grid_init(g, 1.0_go_wp, 1.0_go_wp, tmask)
+    write(*, '("G: grid ",4(I0,1x))') g%nx, g%ny, g%global_nx, g%global_ny
+    do j = 1, g%ny
+       write(*, '("G: tmaskrow ",I0,*(1x,I0))') j, (g%tmask(i, j), i = 1, g%nx)
+    end do
+  end subroutine dump_tmask
 
   !> init_global_data scatter followed by gather_inner_data on one rank.
   subroutine dump_gather(nx, ny)

@@ -81,6 +81,13 @@ shallowpmc)
     python scripts/parse_rocprof.py pmc $OUT/swpmc_fetch $OUT/swpmc_write "shallow 8192x8192/A64" $OUT/traffic_shallow.json shallow_tile 2>&1 | tail -12
     step swP 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sw_prof -- python3 scripts/shallow_bench.py --steps 10 --no-cpu --out $OUT/sw_tmp.json > $OUT/sw_prof.log 2>&1
     python scripts/parse_rocprof.py stats $OUT/sw_prof $OUT/sw_prof_summary.md | cut -c1-170 | tail -8 ;;
+swcounters)   # occupancy / VALU / L2 counters of shallow_tile, one counter per pass (bench.py's shallow leg: 8192^2)
+    rm -rf $OUT/swcounters
+    for cnt in ${PMC_LIST:-VALUBusy MemUnitStalled MeanOccupancyPerActiveCU TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCP_TCC_READ_REQ_sum SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU FETCH_SIZE WRITE_SIZE}; do
+        step swc_$cnt 200 rocprofv3 --pmc $cnt --output-format csv -d $OUT/swcounters/$cnt -- python3 scripts/shallow_bench.py --steps 3 --no-cpu --only-default --out $OUT/sw_tmp.json > $OUT/swcounters_$cnt.log 2>&1
+    done
+    python scripts/pmc_table.py $OUT/swcounters shallow_tile > $OUT/swcounters_table.txt 2>&1
+    cat $OUT/swcounters_table.txt ;;
 dmprof)
     rm -rf $OUT/dm_prof
     step dmprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dm_prof -- python3 scripts/dm_overhead.py --tile ${DM_TILE:-16384} --steps 20 --out $OUT/dm_overhead_prof.json > $OUT/dm_prof.log 2>&1

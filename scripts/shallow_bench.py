@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--out", default="gpurun_out/shallow_bench.json")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--only-default", action="store_true", help="time the default kernel only (profiling runs)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -55,6 +56,8 @@ def main():
                                       ("tile R=3", 0, 3, 0), ("direct", 1, 2, 0), ("tile R=2 again", 0, 2, 0),
                                       ("tile R=2 nt both again", 0, 2, 3), ("tile R=2 default + planning call", 0, 2, -1),
                                       ("tile R=2 default, rule", 0, 2, -2)):
+            if args.only_default and label != "tile R=2 default, rule":
+                continue
             L.dlesm_set_tuning(b"sw_kernel", kern)
             L.dlesm_set_tuning(b"sw_tile_rows", rows)
             L.dlesm_set_tuning(b"sw_nt", nt if nt >= 0 else 2)

@@ -76,6 +76,9 @@ program ftest_device
   ! ---- (2b) four fused steps against four single steps --------------------------
   call fused_check(model_grid)
 
+  ! ---- (2c) a kernel that takes the grid's T mask (GO_GRID_MASK_T) ---------------
+  call masked_model(nx, ny, nsteps)
+
   ! ---- (3) one shallow-water step through the PSy layer ------------------------
   call shallow_step(model_grid)
   call free_field(a);  call free_field(b);  call free_field(test_field)
@@ -118,6 +121,44 @@ contains
        call free_field(f(k))
     end do
   end subroutine shallow_step
+
+  !> a grid built WITH a T mask (-1/0/1 pattern, as ftest_dump's tmask mode): nsteps masked Jacobi
+  !! steps through the PSy layer, which hands the kernel grid%tmask_device
+  subroutine masked_model(nx, ny, nsteps)
+    integer, intent(in) :: nx, ny, nsteps
+    type(grid_type), target :: g
+    type(r2d_field), target :: x, y
+    integer, allocatable :: tmask(:,:)
+    real(go_wp), pointer :: d(:,:)
+    integer :: i, j
+    g = grid_type(GO_ARAKAWA_C, (/GO_BC_EXTERNAL, GO_BC_EXTERNAL, GO_BC_NONE/), GO_OFFSET_NE)
+    call g%decompose(nx, ny)
+    allocate(tmask(g%subdomain%global%nx, g%subdomain%global%ny))
+    do j = 1, size(tmask, 2)
+       do i = 1, size(tmask, 1)
+          tmask(i, j) = mod(7*i + 13*j, 3) - 1
+       end do
+    end do
+    call grid_init(g, 1.0_go_wp, 1.0_go_wp, tmask)
+    x = r2d_field(g, GO_T_POINTS);  y = r2d_field(g, GO_T_POINTS)
+    call invoke_hash_init(x, 777_c_int64_t)
+    call invoke_copy(y, x)
+    do i = 1, nsteps
+       if (mod(i, 2) == 1) then
+          call invoke_jacobi5_masked(y, x)
+       else
+          call invoke_jacobi5_masked(x, y)
+       end if
+    end do
+    if (mod(nsteps, 2) == 1) then
+       d => y%get_data()
+       write(*, '("G: masked ",4(ES24.16E3,1x))') field_checksum(y), d(2, 2), d(nx/2 + 1, ny/2 + 1), d(nx + 1, ny + 1)
+    else
+       d => x%get_data()
+       write(*, '("G: masked ",4(ES24.16E3,1x))') field_checksum(x), d(2, 2), d(nx/2 + 1, ny/2 + 1), d(nx + 1, ny + 1)
+    end if
+    call free_field(x);  call free_field(y)
+  end subroutine masked_model
 
   !> invoke_jacobi5_multi(.., 4) must reproduce four invoke_jacobi5 calls bit for bit
   subroutine fused_check(g)

@@ -39,6 +39,8 @@ program ftest_dump
      call dump_model(nx, ny, fill)
   case ('gather')
      call dump_gather(nx, ny)
+  case ('tmask')
+     call dump_tmask(nx, ny)
   case ('comms')
      ndom = 1                                   ! optional 4th argument: halo width of the decomposition
      if (command_argument_count() >= 4) then
@@ -118,6 +120,30 @@ contains
     write(*, '("G: xt ",3(ES24.16E3,1x))') g%xt(1,1), g%xt(2,1), g%xt(g%nx,1)
     write(*, '("G: yt ",3(ES24.16E3,1x))') g%yt(1,1), g%yt(1,2), g%yt(1,g%ny)
   end subroutine dump_model
+
+  !> grid_init with a patterned T mask (values -1, 0, 1): the grid's tmask after the copy-in and
+  !! the boundary fill, row by row -- same "G:" lines as oracle/ref_drivers/ref_dump.f90 prints
+  !! for the real reference.
+  subroutine dump_tmask(nx, ny)
+    integer, intent(in) :: nx, ny
+    type(grid_type), target :: g
+    integer, allocatable :: tmask(:,:)
+    integer :: i, j
+    g = grid_type(GO_ARAKAWA_C, (/GO_BC_EXTERNAL, GO_BC_EXTERNAL, GO_BC_NONE/), &
+                  GO_OFFSET_NE)
+    call g%decompose(nx, ny)
+    allocate(tmask(g%subdomain%global%nx, g%subdomain%global%ny))
+    do j = 1, size(tmask, 2)
+       do i = 1, size(tmask, 1)
+          tmask(i, j) = mod(7*i + 13*j, 3) - 1
+       end do
+    end do
+    call grid_init(g, 1.0_go_wp, 1.0_go_wp, tmask)
+    write(*, '("G: grid ",4(I0,1x))') g%nx, g%ny, g%global_nx, g%global_ny
+    do j = 1, g%ny
+       write(*, '("G: tmaskrow ",I0,*(1x,I0))') j, (g%tmask(i, j), i = 1, g%nx)
+    end do
+  end subroutine dump_tmask
 
   subroutine dump_gather(nx, ny)
     integer, intent(in) :: nx, ny

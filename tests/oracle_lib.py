@@ -93,6 +93,9 @@ def lib():
     L.orc_hash_u01.restype = C.c_double
     L.orc_jacobi5.argtypes = [_dp, _dp] + [C.c_int] * 5
     L.orc_jacobi5_omp.argtypes = [_dp, _dp] + [C.c_int] * 6
+    _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    L.orc_jacobi5_masked.argtypes = [_dp, _dp, _ip] + [C.c_int] * 5
+    L.orc_tmask_fill.argtypes = [C.c_void_p] + [C.c_int] * 7 + [_ip]
     L.orc_sw_step.argtypes = [C.POINTER(SwParams)] + [C.c_int] * 5 + [_dp] * 13
     L.orc_max_threads.restype = C.c_int
     L.orc_copy_rows_omp.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int]
@@ -227,3 +230,19 @@ def sw_step(prm, ld, box, u, v, p, uold, vold, pold, unew, vnew, pnew):
     op = SwParams(prm.fsdx, prm.fsdy, prm.tdts8, prm.tdtsdx, prm.tdtsdy)
     xs, xe, ys, ye = box
     lib().orc_sw_step(C.byref(op), ld, xs, xe, ys, ye, u, v, p, uold, vold, pold, *scratch, unew, vnew, pnew)
+
+
+def jacobi5_masked(inp, out, tmask, ld, xs, xe, ys, ye):
+    lib().orc_jacobi5_masked(inp, out, tmask, ld, xs, xe, ys, ye)
+
+
+def tmask_fill(user, nx, ny, internal):
+    """grid_init's tmask (grid_mod.f90:394-455); user: (rows, cols) int32 array or None; internal =
+    (xstart, xstop, ystart, ystop) of the subdomain"""
+    out = np.zeros((ny, nx), dtype=np.int32)
+    if user is None:
+        lib().orc_tmask_fill(None, 0, nx, ny, *internal, out)
+    else:
+        u = np.ascontiguousarray(user, dtype=np.int32)
+        lib().orc_tmask_fill(u.ctypes.data, u.shape[1], nx, ny, *internal, out)
+    return out

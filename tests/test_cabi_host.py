@@ -290,3 +290,21 @@ def test_rendezvous_roundtrip_and_stale_records(tmp_path):
     assert L.dlesm_rendezvous_fetch(path, got, b"4:run1", 50) == 0 and got.raw == ident[::-1]
     assert L.dlesm_rendezvous_publish(path, ident, ("x" * 112).encode()) == D._cabi.EINVAL   # token too long
     assert L.dlesm_rendezvous_remove(path) == 0 and not os.path.exists(path)
+
+
+def test_python_grid_tmask_matches_reference():
+    """grid_init(tmask=...) of the Python mirror builds the same grid%tmask as the real reference"""
+    for c in load_golden("ref_tmask")["cases"]:
+        if c["alignment"]:
+            os.environ["DL_ESM_ALIGNMENT"] = str(c["alignment"])
+        else:
+            os.environ.pop("DL_ESM_ALIGNMENT", None)
+        D.parallel_init(0, 1, use_rccl=False)
+        g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
+        g.decompose(c["nx"], c["ny"])
+        user = np.fromfunction(lambda j, i: (7 * (i + 1) + 13 * (j + 1)) % 3 - 1, (c["ny"] + 2, c["nx"] + 2),
+                               dtype=np.int64)
+        D.grid_init(g, 1.0, 1.0, tmask=user)
+        assert [g.nx, g.ny] == c["grid"][:2]
+        assert g.tmask.tolist() == c["tmask"]
+    os.environ.pop("DL_ESM_ALIGNMENT", None)

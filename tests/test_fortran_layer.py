@@ -135,6 +135,17 @@ def test_fortran_deep_halo_tables_match_the_c_abi(exe, nx, ny, nranks, hw):
         assert any(s["nx"] == hw or s["ny"] == hw for s in c.sends())
 
 
+def test_fortran_tmask_matches_reference(exe):
+    """grid_init(tmask=pattern) through the Fortran layer: grid%tmask equals the real reference's
+    (tests/golden/ref_tmask.json, oracle/_ref/ref_dump.exe tmask) entry for entry"""
+    for c in load_golden("ref_tmask")["cases"]:
+        env = {"DL_ESM_ALIGNMENT": str(c["alignment"])} if c["alignment"] else None
+        _, g, _ = exe("ftest_dump.exe", "tmask", c["nx"], c["ny"], env=env)
+        assert ints(g["grid"][0]) == c["grid"]
+        rows = sorted((ints(r) for r in g["tmaskrow"]), key=lambda r: r[0])
+        assert [r[1:] for r in rows] == c["tmask"]
+
+
 def _plant_stale(path, token, age_s):
     """a rendezvous record as a dead job would have left it (format: dlesm_rendezvous.cpp)"""
     import struct
@@ -222,6 +233,18 @@ def test_fortran_device_io_and_jacobi_on_gpu(exe):
         a, b = b, a
     cs4 = O.lib().orc_checksum(a, ld, 2, nx + 1, 2, ny + 1)
     assert abs(float(g["fused4"][0][1]) - cs4) <= 1e-12 * cs4
+    # (2c) masked Jacobi through the PSy layer (kernel argument GO_GRID_MASK_T -> grid%tmask_device)
+    user = np.fromfunction(lambda j, i: (7 * (i + 1) + 13 * (j + 1)) % 3 - 1, (ny + 2, nx + 2), dtype=np.int64)
+    tm = O.tmask_fill(user.astype(np.int32), ld, nyy, (2, nx + 1, 2, ny + 1))
+    a = O.hash_field(777, nyy, ld, 0, 0, 1, nx + 2, 1, ny + 2)
+    b = a.copy()
+    for _ in range(nsteps):
+        O.jacobi5_masked(a, b, tm, ld, 2, nx + 1, 2, ny + 1)
+        a, b = b, a
+    csm = O.lib().orc_checksum(a, ld, 2, nx + 1, 2, ny + 1)
+    row = [float(x) for x in g["masked"][0]]
+    assert abs(row[0] - csm) <= 1e-12 * csm
+    assert row[1:] == [a[1, 1], a[ny // 2, nx // 2], a[ny, nx]]
     # (3) one fused shallow-water step launched from Fortran == oracle
     import ctypes as C
     H = []

@@ -479,6 +479,55 @@ def test_distributed_step_variants(D, corners, frame_pack):
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
+# --------------------------------------------------------------------------- grid properties (f.4)
+@pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (64, 48, 8), (300, 70, 64), (257, 129, None), (1, 1, 2),
+                                             (129, 3, 2), (1000, 37, 64), (4100, 9, 64)])
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_masked_jacobi_matches_oracle(D, nx, ny, alignment, kernel):
+    """a kernel that consumes a grid property: the PSy layer passes grid%tmask_device (GO_GRID_MASK_T).
+    grid_init gets a -1/0/1 pattern; three ping-pong steps, bit for bit against the oracle's
+    jacobi5_masked_code loops on the oracle's own tmask fill"""
+    import torch
+    _set_tuning(D, j5m_kernel=kernel)
+    if alignment is None:
+        os.environ.pop("DL_ESM_ALIGNMENT", None)
+    else:
+        os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    g.decompose(nx, ny)
+    rng = np.random.default_rng(nx * 7 + ny)
+    user = rng.integers(-1, 2, (ny + 2, nx + 2)).astype(np.int32)
+    D.grid_init(g, 1.0, 1.0, tmask=user)
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = a.internal
+    tm = O.tmask_fill(user, g.nx, g.ny, it.box())
+    assert np.array_equal(g.tmask, tm) and np.array_equal(g.tmask_device.cpu().numpy(), tm)
+    D.psy.hash_init(a, SEED + 31)
+    D.set_field(b, -3.0)
+    ha = a.get_data()
+    hb = b.get_data()
+    for _ in range(3):
+        D.psy.invoke_jacobi5_masked(b, a)
+        O.jacobi5_masked(ha, hb, tm, g.nx, *it.box())
+        torch.cuda.synchronize()
+        assert np.array_equal(b.get_data(), hb)
+        a, b, ha, hb = b, a, hb, ha
+    _set_tuning(D, j5m_kernel=0)
+
+
+def test_masked_jacobi_all_wet_is_the_plain_step_at_full_size(D):
+    """8192^2, no mask supplied (all wet): the masked kernel equals invoke_jacobi5 exactly"""
+    import torch
+    g = _grid(D, 8192, 8192, 64)
+    a, b, c = (D.r2d_field(g, D.GO_T_POINTS) for _ in range(3))
+    D.psy.hash_init(a, SEED)
+    D.psy.invoke_jacobi5(b, a)
+    D.psy.invoke_jacobi5_masked(c, a)
+    torch.cuda.synchronize()
+    assert bool(torch.equal(b.data, c.data))
+
+
 # --------------------------------------------------------------------------- shallow water
 @pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (5, 4, 2), (64, 48, 8), (300, 70, 64), (257, 129, None),
                                              (1, 1, 2), (123, 3, 2), (124, 5, 2), (125, 2, 2), (1000, 37, 64),

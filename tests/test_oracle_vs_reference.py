@@ -294,3 +294,46 @@ def test_sw_oracle_reproduces_numpy_golden():
 
     N.leapfrog(step, 10, cur, old, new, on_step)
     assert seen == [1, 5, 10]
+
+
+# --------------------------------------------------------------------------- T mask (section 8 f.4)
+def test_tmask_fill_matches_reference():
+    """orc_tmask_fill against grid%tmask of the REAL reference (tests/golden/ref_tmask.json)"""
+    for c in load_golden("ref_tmask")["cases"]:
+        nx, ny = c["nx"], c["ny"]
+        gnx, gny = c["grid"][0], c["grid"][1]
+        assert (gnx, gny) == O.grid_extents(nx + 2, ny + 2, c["alignment"])
+        user = np.fromfunction(lambda j, i: (7 * (i + 1) + 13 * (j + 1)) % 3 - 1, (ny + 2, nx + 2), dtype=np.int64)
+        got = O.tmask_fill(user.astype(np.int32), gnx, gny, (2, nx + 1, 2, ny + 1))
+        assert got.tolist() == c["tmask"]
+    # no mask supplied: all wet on the subdomain and its ring (grid_mod.f90:447-453)
+    m = O.tmask_fill(None, 13, 7, (2, 11, 2, 5))
+    assert m[:6, :12].min() == 1 and m.sum() == 6 * 12
+
+
+def test_jacobi5_masked_against_numpy():
+    """PARITY UNPINNED by the reference (it has no stencil).  orc_jacobi5_masked (per-point GOcean
+    kernel form) against a whole-array numpy evaluation of DESIGN.md section 5.7, bit for bit"""
+    rng = np.random.default_rng(5)
+    for n, ld in [(37, 44), (64, 67), (5, 8)]:
+        a = rng.random((n + 3, ld))
+        tm = rng.integers(-1, 2, (n + 3, ld)).astype(np.int32)
+        out = np.full_like(a, -7.0)
+        O.jacobi5_masked(a, out, tm, ld, 2, n + 1, 2, n + 1)
+        c = a[1:n + 1, 1:n + 1]
+        wet = lambda m, v: np.where(m > 0, v, c)                               # noqa: E731
+        w = wet(tm[1:n + 1, 0:n], a[1:n + 1, 0:n])
+        e = wet(tm[1:n + 1, 2:n + 2], a[1:n + 1, 2:n + 2])
+        s_ = wet(tm[0:n, 1:n + 1], a[0:n, 1:n + 1])
+        n_ = wet(tm[2:n + 2, 1:n + 1], a[2:n + 2, 1:n + 1])
+        want = np.where(tm[1:n + 1, 1:n + 1] > 0, 0.25 * ((w + e) + (s_ + n_)), c)
+        assert np.array_equal(out[1:n + 1, 1:n + 1], want)
+        out[1:n + 1, 1:n + 1] = -7.0
+        assert np.all(out == -7.0)
+    # an all-wet mask reduces it to the plain Jacobi step
+    a = rng.random((20, 24))
+    one = np.ones((20, 24), dtype=np.int32)
+    o1, o2 = np.zeros_like(a), np.zeros_like(a)
+    O.jacobi5_masked(a, o1, one, 24, 2, 22, 2, 18)
+    O.jacobi5(a, o2, 24, 2, 22, 2, 18)
+    assert np.array_equal(o1, o2)
