@@ -114,6 +114,9 @@ PROTOTYPES = {
     "dlesm_stencil5_multi_f64": (_i, [_vp, _vp] + [_i] * 15 + [_vp]),
     "dlesm_shallow_step_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_shallow_autotune_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
+    "dlesm_periodic_halos": (_i, [C.POINTER(Region), _i, _i, C.POINTER(Region), C.POINTER(Region), C.POINTER(_i)]),
+    "dlesm_periodic_halos_apply_f64": (_i, [_vp, _i, _i, C.POINTER(Region), _i, _i, _vp]),
+    "dlesm_shallow_step_sw_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_copy_patch_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_fill_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, _d, _vp]),
     "dlesm_checksum_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_d), _vp]),
@@ -138,6 +141,10 @@ PROTOTYPES = {
     "dlesm_shallow_step_dm": (_i, [_vp, C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_global_sum_f64": (_i, [C.POINTER(_d)]),
     "dlesm_gather_f64": (_i, [_vp, _vp, _i]),
+    "dlesm_pack_inner_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, C.c_long, _vp]),
+    "dlesm_unpack_gathered_f64": (_i, [_vp, C.c_long, C.POINTER(Decomp), C.POINTER(Subdomain), _i, _vp, _vp]),
+    "dlesm_gather_inner_f64": (_i, [_vp, _i, _i, C.POINTER(Region), C.POINTER(Decomp), C.POINTER(Subdomain), _i, _vp]),
+    "dlesm_scatter_inner_f64": (_i, [_vp, _i, _i, C.POINTER(Subdomain), _vp, _i, _i]),
 }
 
 _lib = None

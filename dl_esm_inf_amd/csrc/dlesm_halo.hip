@@ -573,3 +573,147 @@ extern "C" int dlesm_gather_f64(const double *send, double *recv, int n)
     DLESM_HIP_TRY(hipStreamSynchronize(s));
     return DLESM_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Device-side gather / scatter of whole fields (field_mod.f90:1313-1390, 378-389)
+
+__global__ void pack_inner_k(const double *__restrict__ f, int ld, int x0, int y0, int nx, long n, long slot,
+                             double *__restrict__ send)
+{
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < slot; t += (long)gridDim.x * blockDim.x)
+        send[t] = t < n ? f[(size_t)(y0 + t / nx) * ld + x0 + t % nx] : 0.0;
+}
+
+struct GBox { int x0, y0, w, h; };            // 0-based origin in the global array, extent
+
+// grid.y = rank; j outer / i inner as field_mod.f90:1376-1386
+__global__ void unpack_gathered_k(const double *__restrict__ recv, long slot, const GBox *__restrict__ boxes,
+                                  int gnx, double *__restrict__ global)
+{
+    const GBox b = boxes[blockIdx.y];
+    const long n = (long)b.w * b.h;
+    const double *src = recv + (size_t)blockIdx.y * slot;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+        global[(size_t)(b.y0 + t / b.w) * gnx + b.x0 + t % b.w] = src[t];
+}
+
+extern "C" int dlesm_pack_inner_f64(const double *field, int ld, int ny, int xstart, int xstop, int ystart,
+                                    int ystop, double *send, long slot, void *stream)
+{
+    DLESM_REQUIRE(field != nullptr && send != nullptr, "null pointer");
+    if (int rc = ensure_device()) return rc;
+    if (int rc = check_box("dlesm_pack_inner_f64", ld, ny, xstart, xstop, ystart, ystop, 0)) return rc;
+    const int nx = xstop - xstart + 1, h = ystop - ystart + 1;
+    const long n = nx > 0 && h > 0 ? (long)nx * h : 0;
+    DLESM_REQUIRE(slot >= n, "slot of %ld doubles for a %dx%d region", slot, nx, h);
+    if (slot == 0) return DLESM_OK;
+    long blocks = (slot + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_inner_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, ld, xstart - 1,
+                       ystart - 1, nx > 0 ? nx : 1, n, slot, send);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_unpack_gathered_f64(const double *recv, long slot, const dlesm_decomp *d,
+                                         const dlesm_subdomain *subs, int nranks, double *global, void *stream)
+{
+    DLESM_REQUIRE(recv != nullptr && d != nullptr && subs != nullptr && global != nullptr, "null pointer");
+    DLESM_REQUIRE(nranks >= 1 && nranks <= d->ndomains, "%d ranks for %d subdomains", nranks, d->ndomains);
+    if (int rc = ensure_device()) return rc;
+    std::vector<GBox> boxes(nranks);
+    long widest = 0;
+    for (int r = 0; r < nranks; r++) {
+        const dlesm_region &g = subs[r].global;
+        const int w = g.xstop - g.xstart + 1, h = g.ystop - g.ystart + 1;
+        DLESM_REQUIRE(g.xstart >= 1 && g.ystart >= 1 && g.xstop <= d->global_nx && g.ystop <= d->global_ny && w >= 0 &&
+                          h >= 0 && (long)w * h <= slot,
+                      "subdomain %d box (%d:%d,%d:%d) does not fit (global %dx%d, slot %ld)", r + 1, g.xstart, g.xstop,
+                      g.ystart, g.ystop, d->global_nx, d->global_ny, slot);
+        boxes[r] = GBox{g.xstart - 1, g.ystart - 1, w, h};
+        if ((long)w * h > widest) widest = (long)w * h;
+    }
+    if (widest == 0) return DLESM_OK;
+    GBox *dboxes = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    DLESM_HIP_TRY(hipMalloc((void **)&dboxes, boxes.size() * sizeof(GBox)));
+    hipError_t e = hipMemcpyAsync(dboxes, boxes.data(), boxes.size() * sizeof(GBox), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        long gx = (widest + 255) / 256;
+        if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL(unpack_gathered_k, dim3((unsigned)gx, (unsigned)nranks), dim3(256), 0, s, recv, slot, dboxes,
+                           d->global_nx, global);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);      // the table is a stack-lifetime upload
+    (void)hipFree(dboxes);
+    if (e != hipSuccess) return fail(DLESM_EHIP, "unpack of the gathered slots failed: %s", hipGetErrorString(e));
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_gather_inner_f64(const double *field, int ld, int ny, const dlesm_region *it,
+                                      const dlesm_decomp *d, const dlesm_subdomain *subs, int nranks,
+                                      double *global_host)
+{
+    DLESM_REQUIRE(field != nullptr && it != nullptr && d != nullptr && subs != nullptr, "null pointer");
+    DLESM_REQUIRE(nranks >= 1, "nranks = %d", nranks);
+    if (int rc = ensure_device()) return rc;
+    hipStream_t s = side_stream();
+    DLESM_HIP_TRY(hipDeviceSynchronize());                 // the field's producers run on the caller's streams
+    const bool root = nranks == 1 || g_rank == 0;
+    DLESM_REQUIRE(!root || global_host != nullptr, "null result array on the gathering rank");
+    const size_t gbytes = (size_t)d->global_nx * d->global_ny * sizeof(double);
+    if (nranks == 1) {                                     // the copy-out of field_mod.f90:1332-1343
+        DLESM_REQUIRE(it->xstop - it->xstart + 1 == d->global_nx && it->ystop - it->ystart + 1 == d->global_ny,
+                      "one rank: internal region %dx%d is not the %dx%d domain", it->xstop - it->xstart + 1,
+                      it->ystop - it->ystart + 1, d->global_nx, d->global_ny);
+        DLESM_HIP_TRY(hipMemcpy2D(global_host, (size_t)d->global_nx * sizeof(double),
+                                  field + lin(ld, it->xstart, it->ystart), (size_t)ld * sizeof(double),
+                                  (size_t)d->global_nx * sizeof(double), (size_t)d->global_ny, hipMemcpyDeviceToHost));
+        return DLESM_OK;
+    }
+    DLESM_REQUIRE(g_comm != nullptr && g_size == nranks, "gather over %d ranks, communicator has %d", nranks, g_size);
+    const int halo_x = it->xstart - 1, halo_y = it->ystart - 1;                  // field_mod.f90:1348-1349
+    const long slot = (long)(d->max_width - 2 * halo_x) * (d->max_height - 2 * halo_y);
+    DLESM_REQUIRE(slot > 0, "empty gather slot (max tile %dx%d, halos %d,%d)", d->max_width, d->max_height, halo_x, halo_y);
+    double *send = nullptr, *recv = nullptr, *gdev = nullptr;
+    int rc = DLESM_OK;
+    auto cleanup = [&]() {
+        if (send) (void)hipFree(send);
+        if (recv) (void)hipFree(recv);
+        if (gdev) (void)hipFree(gdev);
+    };
+    if (hipMalloc((void **)&send, (size_t)slot * sizeof(double)) != hipSuccess ||
+        (root && (hipMalloc((void **)&recv, (size_t)slot * nranks * sizeof(double)) != hipSuccess ||
+                  hipMalloc((void **)&gdev, gbytes) != hipSuccess))) {
+        cleanup();
+        return fail(DLESM_EHIP, "gather_inner_data: device buffers");
+    }
+    rc = dlesm_pack_inner_f64(field, ld, ny, it->xstart, it->xstop, it->ystart, it->ystop, send, slot, s);
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(DLESM_EHIP, "gather_inner_data: pack failed");
+    if (!rc) rc = dlesm_gather_f64(send, recv, (int)slot);
+    if (!rc && root) {
+        rc = dlesm_unpack_gathered_f64(recv, slot, d, subs, nranks, gdev, s);
+        if (!rc && hipMemcpy(global_host, gdev, gbytes, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(DLESM_EHIP, "gather_inner_data: copy of the global array to the host failed");
+    }
+    cleanup();
+    return rc;
+}
+
+extern "C" int dlesm_scatter_inner_f64(const double *global_host, int gnx, int gny, const dlesm_subdomain *sub,
+                                       double *field, int ld, int ny)
+{
+    DLESM_REQUIRE(global_host != nullptr && sub != nullptr && field != nullptr, "null pointer");
+    if (int rc = ensure_device()) return rc;
+    const dlesm_region &g = sub->global, &it = sub->internal;
+    const int w = it.xstop - it.xstart + 1, h = it.ystop - it.ystart + 1;
+    if (w <= 0 || h <= 0) return DLESM_OK;
+    DLESM_REQUIRE(g.xstart >= 1 && g.ystart >= 1 && g.xstart + w - 1 <= gnx && g.ystart + h - 1 <= gny,
+                  "patch (%d,%d)+%dx%d outside the %dx%d global array", g.xstart, g.ystart, w, h, gnx, gny);
+    if (int rc = check_box("dlesm_scatter_inner_f64", ld, ny, it.xstart, it.xstop, it.ystart, it.ystop, 0)) return rc;
+    DLESM_HIP_TRY(hipMemcpy2D(field + lin(ld, it.xstart, it.ystart), (size_t)ld * sizeof(double),
+                              global_host + lin(gnx, g.xstart, g.ystart), (size_t)gnx * sizeof(double),
+                              (size_t)w * sizeof(double), (size_t)h, hipMemcpyHostToDevice));
+    return DLESM_OK;
+}

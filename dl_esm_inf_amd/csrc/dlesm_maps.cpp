@@ -121,6 +121,34 @@ extern "C" int dlesm_field_bounds(int grid_points, int offset, int bc_x, int bc_
     return DLESM_OK;
 }
 
+// init_periodic_bc_halos, field_mod.f90:1394-1464: for each periodic direction two copies,
+// (source, destination) regions, in the reference's order: x first -- east halo column <- west-most
+// internal column, west halo column <- east-most internal column, over the internal rows -- then y
+// -- north halo row <- south-most internal row, south halo row <- north-most internal row, over the
+// internal columns PLUS the two halo columns, so that the corners come out right when the copies
+// are applied in this order.
+extern "C" int dlesm_periodic_halos(const dlesm_region *it, int bc_x, int bc_y, dlesm_region *source,
+                                    dlesm_region *dest, int *num_halos)
+{
+    if (!it || !source || !dest || !num_halos) return fail(DLESM_EINVAL, "null pointer");
+    int n = 0;
+    auto add = [&](int sx0, int sx1, int sy0, int sy1, int dx0, int dx1, int dy0, int dy1) {
+        source[n] = dlesm_region{sx1 - sx0 + 1, sy1 - sy0 + 1, sx0, sx1, sy0, sy1};
+        dest[n] = dlesm_region{dx1 - dx0 + 1, dy1 - dy0 + 1, dx0, dx1, dy0, dy1};
+        n++;
+    };
+    if (bc_x == DLESM_BC_PERIODIC) {
+        add(it->xstart, it->xstart, it->ystart, it->ystop, it->xstop + 1, it->xstop + 1, it->ystart, it->ystop);
+        add(it->xstop, it->xstop, it->ystart, it->ystop, it->xstart - 1, it->xstart - 1, it->ystart, it->ystop);
+    }
+    if (bc_y == DLESM_BC_PERIODIC) {
+        add(it->xstart - 1, it->xstop + 1, it->ystart, it->ystart, it->xstart - 1, it->xstop + 1, it->ystop + 1, it->ystop + 1);
+        add(it->xstart - 1, it->xstop + 1, it->ystop, it->ystop, it->xstart - 1, it->xstop + 1, it->ystart - 1, it->ystart - 1);
+    }
+    *num_halos = n;
+    return DLESM_OK;
+}
+
 extern "C" int dlesm_decompose(int domainx, int domainy, int ndomains, int ntilex, int ntiley,
                                int halo_width, dlesm_decomp *d, dlesm_subdomain *subs)
 {

@@ -263,6 +263,82 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
 
 using namespace dlesm;
 
+// SW staggering, one cell per thread, neighbours through L1/L2: the
+// configuration is serial-only in the reference (periodic boundaries), small next to the NE step.
+// Expression trees exactly as specified (oracle: compute_*_sw_code).
+__global__ __launch_bounds__(256) void shallow_step_sw_direct(
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, const double *__restrict__ u,
+    const double *__restrict__ v, const double *__restrict__ p, const double *__restrict__ uold,
+    const double *__restrict__ vold, const double *__restrict__ pold, double *__restrict__ unew,
+    double *__restrict__ vnew, double *__restrict__ pnew)
+{
+    const int i = x0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > x1) return;
+    for (int j = y0 + blockIdx.y; j <= y1; j += gridDim.y) {
+        const size_t o = (size_t)j * ld + i;
+#define U_(di, dj) u[o + (di) + (long)(dj) * ld]
+#define V_(di, dj) v[o + (di) + (long)(dj) * ld]
+#define P_(di, dj) p[o + (di) + (long)(dj) * ld]
+#define CU(di, dj) (0.5 * (P_(di, dj) + P_((di)-1, dj)) * U_(di, dj))
+#define CV(di, dj) (0.5 * (P_(di, dj) + P_(di, (dj)-1)) * V_(di, dj))
+#define Z(di, dj)                                                                                   \
+    ((q.fsdx * (V_(di, dj) - V_((di)-1, dj)) - q.fsdy * (U_(di, dj) - U_(di, (dj)-1))) /             \
+     (P_((di)-1, (dj)-1) + P_(di, (dj)-1) + P_(di, dj) + P_((di)-1, dj)))
+#define H(di, dj)                                                                                   \
+    (P_(di, dj) + 0.25 * (U_((di) + 1, dj) * U_((di) + 1, dj) + U_(di, dj) * U_(di, dj) +            \
+                          V_(di, (dj) + 1) * V_(di, (dj) + 1) + V_(di, dj) * V_(di, dj)))
+        const double z00 = Z(0, 0), z0p = Z(0, 1), zp0 = Z(1, 0);
+        const double h00 = H(0, 0), hm0 = H(-1, 0), h0m = H(0, -1);
+        const double cu00 = CU(0, 0), cup0 = CU(1, 0), cu0m = CU(0, -1), cupm = CU(1, -1);
+        const double cv00 = CV(0, 0), cv0p = CV(0, 1), cvmp = CV(-1, 1), cvm0 = CV(-1, 0);
+        unew[o] = uold[o] + q.tdts8 * (z0p + z00) * (cv0p + cvmp + cvm0 + cv00) - q.tdtsdx * (h00 - hm0);
+        vnew[o] = vold[o] - q.tdts8 * (zp0 + z00) * (cup0 + cu00 + cu0m + cupm) - q.tdtsdy * (h00 - h0m);
+        pnew[o] = pold[o] - q.tdtsdx * (cup0 - cu00) - q.tdtsdy * (cv0p - cv00);
+#undef U_
+#undef V_
+#undef P_
+#undef CU
+#undef CV
+#undef Z
+#undef H
+    }
+}
+
+extern "C" int dlesm_shallow_step_sw_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop,
+                                         int ystart, int ystop, const double *u, const double *v,
+                                         const double *p, const double *uold, const double *vold,
+                                         const double *pold, double *unew, double *vnew, double *pnew,
+                                         void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(q && u && v && p && uold && vold && pold && unew && vnew && pnew, "null pointer");
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("dlesm_shallow_step_sw_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    DLESM_REQUIRE(unew != u && unew != v && unew != p && vnew != u && vnew != v && vnew != p &&
+                      pnew != u && pnew != v && pnew != p,
+                  "shallow step: outputs alias the 3x3-read inputs");
+    const int nx = xstop - xstart + 1, h = ystop - ystart + 1;
+    hipLaunchKernelGGL(shallow_step_sw_direct, dim3((nx + 255) / 256, h > 4096 ? 4096 : h), dim3(256), 0,
+                       (hipStream_t)stream, *q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold,
+                       pold, unew, vnew, pnew);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_periodic_halos_apply_f64(double *field, int ld, int ny, const dlesm_region *internal,
+                                              int bc_x, int bc_y, void *stream)
+{
+    DLESM_REQUIRE(field != nullptr && internal != nullptr, "null pointer");
+    dlesm_region src[4], dst[4];
+    int n = 0;
+    if (int rc = dlesm_periodic_halos(internal, bc_x, bc_y, src, dst, &n)) return rc;
+    for (int k = 0; k < n; k++)   // in order: the y copies carry the corners the x copies made
+        if (int rc = dlesm_copy_patch_f64(field, field, ld, ny, src[k].xstart, src[k].ystart, dst[k].xstart,
+                                          dst[k].ystart, src[k].nx, src[k].ny, stream))
+            return rc;
+    return DLESM_OK;
+}
+
 extern "C" int dlesm_shallow_autotune_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop,
                                           int ystart, int ystop, const double *u, const double *v,
                                           const double *p, const double *uold, const double *vold,

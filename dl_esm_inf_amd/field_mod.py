@@ -40,6 +40,23 @@ def field_bounds(grid, grid_points):
     return internal, whole
 
 
+def periodic_halos(grid, grid_points, internal):
+    """init_periodic_bc_halos (field_mod.f90:1394-1464): only SW-offset fields on a point type get
+    them (the c?_sw_init routines call it; the NE ones stop on periodic boundaries)"""
+    if grid_points == GO_ALL_POINTS or grid.offset != grid_mod.GO_OFFSET_SW:
+        return []
+    src, dst, n = (Region * 4)(), (Region * 4)(), C.c_int()
+    check(_cabi.lib().dlesm_periodic_halos(C.byref(internal), grid.boundary_conditions[0],
+                                           grid.boundary_conditions[1], src, dst, C.byref(n)))
+    out = []
+    for k in range(n.value):
+        s, d = Region(), Region()
+        C.memmove(C.byref(s), C.byref(src[k]), C.sizeof(Region))
+        C.memmove(C.byref(d), C.byref(dst[k]), C.sizeof(Region))
+        out.append((s, d))
+    return out
+
+
 class r2d_field:
     """r2d_field (field_mod.f90:139-166) with device-resident data"""
 
@@ -47,20 +64,21 @@ class r2d_field:
         self.grid = grid
         self.defined_on = grid_points
         self.internal, self.whole = field_bounds(grid, grid_points)
+        self.halo = periodic_halos(grid, grid_points, self.internal)   # [(source, dest)], field_mod.f90:1394-1464
         torch = _torch()
         # data(1:grid%nx, 1:grid%ny), zeroed (field_mod.f90:350,375); row-major (ny, nx) here
         self.data = torch.zeros((grid.ny, grid.nx), dtype=torch.float64, device="cuda")
         self.data_on_device = True
         self.ntiles = 0
         if init_global_data is not None:                   # field_mod.f90:378-389
-            g = np.asarray(init_global_data, dtype=np.float64)
-            s = grid.subdomain
-            dx = s.glob.xstart - self.internal.xstart
-            dy = s.glob.ystart - self.internal.ystart
-            si = s.internal
-            patch = g[si.ystart + dy - 1:si.ystop + dy, si.xstart + dx - 1:si.xstop + dx]
-            self.data[si.ystart - 1:si.ystop, si.xstart - 1:si.xstop] = torch.from_numpy(
-                np.ascontiguousarray(patch)).cuda()
+            # one strided host-to-device copy of this rank's patch of the global array
+            g = np.ascontiguousarray(init_global_data, dtype=np.float64)
+            if g.shape != (grid.global_ny, grid.global_nx):
+                raise _cabi.DlesmError(_cabi.EINVAL, f"init_global_data has shape {g.shape}, the domain is "
+                                                     f"{(grid.global_ny, grid.global_nx)}")
+            torch.cuda.current_stream().synchronize()      # the zero fill above
+            check(_cabi.lib().dlesm_scatter_inner_f64(g.ctypes.data_as(C.c_void_p), grid.global_nx, grid.global_ny,
+                                                      C.byref(grid.subdomain), self.device_ptr, grid.nx, grid.ny))
 
     # -- raw views ---------------------------------------------------------
     @property
@@ -86,31 +104,18 @@ class r2d_field:
         check(_cabi.lib().dlesm_halo_exchange_f64(plan, self.device_ptr, dirs, _stream_ptr(stream)))
 
     def gather_inner_data(self):
-        """gather_inner_data (field_mod.f90:1313-1390): global (ny, nx) array on rank 1, else None"""
+        """gather_inner_data (field_mod.f90:1313-1390): global (ny, nx) array on rank 1, else None.
+        Pack, gather (RCCL) and unpack all run on the device; one copy of the assembled global array
+        comes back to the host (dlesm_gather_inner_f64)."""
         from . import parallel_mod
-        torch = _torch()
+        _torch()
         g = self.grid
         nranks = parallel_mod.get_num_ranks()
-        it = self.internal
-        if nranks == 1:
-            return self.data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop].cpu().numpy().copy()
-        halo_x, halo_y = it.xstart - 1, it.ystart - 1      # field_mod.f90:1348-1351
-        n = (g.decomp.max_width - 2 * halo_x) * (g.decomp.max_height - 2 * halo_y)
-        send = torch.zeros(n, dtype=torch.float64, device="cuda")
-        inner = self.data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop].reshape(-1)
-        send[:inner.numel()] = inner
-        recv = torch.zeros(n * nranks, dtype=torch.float64, device="cuda") if parallel_mod.on_master() else None
-        torch.cuda.synchronize()
-        check(_cabi.lib().dlesm_gather_f64(C.c_void_p(send.data_ptr()),
-                                           C.c_void_p(recv.data_ptr()) if recv is not None else None, n))
-        if not parallel_mod.on_master():
-            return None
-        out = np.zeros((g.global_ny, g.global_nx))
-        host = recv.cpu().numpy()
-        for r in range(nranks):
-            s = g.decomp.subdomains[r].glob
-            w, h = s.xstop - s.xstart + 1, s.ystop - s.ystart + 1
-            out[s.ystart - 1:s.ystop, s.xstart - 1:s.xstop] = host[r * n:r * n + w * h].reshape(h, w)
+        root = parallel_mod.on_master()
+        out = np.zeros((g.global_ny, g.global_nx)) if root else None
+        check(_cabi.lib().dlesm_gather_inner_f64(self.device_ptr, g.nx, g.ny, C.byref(self.internal),
+                                                 C.byref(g.decomp._info), g.decomp.subdomains, nranks,
+                                                 out.ctypes.data_as(C.c_void_p) if root else None))
         return out
 
 

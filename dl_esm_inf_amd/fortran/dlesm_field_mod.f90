@@ -591,6 +591,12 @@ contains
     allocate(global_data(self%grid%global_nx, self%grid%global_ny), stat=ierr)
     if (ierr /= 0) call gocean_stop('gather_inner_data failed to allocate global result array')
     me => self
+    if (self%data_on_device .and. field_on_dlesm_device(me)) then
+       ! device-resident field: pack, gather (RCCL) and unpack on the device, one copy of the
+       ! assembled global array to the host -- no full-field download, no host loops
+       call gather_on_device(me, global_data)
+       return
+    end if
     d => me%get_data()          ! host copy up to date
     associate (it => self%internal)
       if (get_num_ranks() == 1) then
@@ -616,6 +622,25 @@ contains
        end do
     end if
   end subroutine gather_inner_data
+
+  subroutine gather_on_device(fld, global_data)
+    use parallel_utils_mod, only: get_num_ranks
+    use parallel_comms_mod, only: to_c_decomp
+    type(r2d_field), intent(in), target :: fld
+    real(go_wp), dimension(:,:), intent(inout), target, contiguous :: global_data
+    type(c_decomp) :: cd
+    type(c_subdomain), allocatable :: csubs(:)
+    type(c_region) :: cint
+    integer(c_int) :: rc
+    call to_c_decomp(fld%grid%decomp, cd, csubs)
+    associate (it => fld%internal)
+      cint = c_region(it%nx, it%ny, it%xstart, it%xstop, it%ystart, it%ystop)
+    end associate
+    rc = dlesm_gather_inner_f64(field_device_data(fld), int(size(fld%data, 1), c_int), &
+                                int(size(fld%data, 2), c_int), cint, cd, csubs, &
+                                int(get_num_ranks(), c_int), c_loc(global_data))
+    if (rc /= 0) call gocean_stop('gather_inner_data: ' // dlesm_error_text())
+  end subroutine gather_on_device
 
   !> GOCEAN_OMP_GRID="NxM": dimensions of the OpenMP tiling grid (field_mod.f90:1473-1503)
   function get_grid_dims(nx, ny) result(success)

@@ -332,6 +332,16 @@ module dlesm_hip_mod
        real(c_double), intent(inout) :: val
        integer(c_int) :: rc
      end function
+     function dlesm_gather_inner_f64(field, ld, ny, internal, decomp, subdomains, nranks, global_host) &
+          bind(C, name="dlesm_gather_inner_f64") result(rc)
+       import :: c_int, c_ptr, c_region, c_decomp, c_subdomain
+       type(c_ptr), value :: field, global_host
+       integer(c_int), value :: ld, ny, nranks
+       type(c_region), intent(in) :: internal
+       type(c_decomp), intent(in) :: decomp
+       type(c_subdomain), intent(in) :: subdomains(*)
+       integer(c_int) :: rc
+     end function
      function dlesm_gather_f64(send, recv, n) bind(C, name="dlesm_gather_f64") result(rc)
        import :: c_int, c_ptr
        type(c_ptr), value :: send, recv

@@ -343,7 +343,7 @@ module parallel_comms_mod
             IminusJplus, MaxCommDir
   public :: opp_dirn
   ! additions of this implementation
-  public :: halo_plan_for, exchange_device
+  public :: halo_plan_for, exchange_device, to_c_decomp
 
 contains
 

@@ -88,6 +88,25 @@ def invoke_shallow_step(params, u, v, p, uold, vold, pold, unew, vnew, pnew, str
                                              pnew.device_ptr, _stream_ptr(stream)))
 
 
+def invoke_shallow_step_sw(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
+    """the SW-offset form (the GOcean `shallow` staggering); periodic models follow it with
+    apply_periodic_halos on the three new fields"""
+    g, it = p.grid, p.internal
+    check(_cabi.lib().dlesm_shallow_step_sw_f64(C.byref(params), g.nx, g.ny, it.xstart, it.xstop,
+                                                it.ystart, it.ystop, u.device_ptr, v.device_ptr,
+                                                p.device_ptr, uold.device_ptr, vold.device_ptr,
+                                                pold.device_ptr, unew.device_ptr, vnew.device_ptr,
+                                                pnew.device_ptr, _stream_ptr(stream)))
+
+
+def apply_periodic_halos(fld, stream=None):
+    """the periodic-boundary copies of a field (field_mod.f90:1394-1464), on the device"""
+    g = fld.grid
+    check(_cabi.lib().dlesm_periodic_halos_apply_f64(fld.device_ptr, g.nx, g.ny, C.byref(fld.internal),
+                                                     g.boundary_conditions[0], g.boundary_conditions[1],
+                                                     _stream_ptr(stream)))
+
+
 def autotune_shallow(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
     """optional planning call for invoke_shallow_step: time the launch shapes / cache policies once
     for this field geometry (each trial is the same valid step) and keep the fastest"""

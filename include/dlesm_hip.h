@@ -110,6 +110,13 @@ int dlesm_field_bounds(int grid_points, int offset, int bc_x, int bc_y,
                        const dlesm_region *subdomain_internal, int grid_nx, int grid_ny,
                        dlesm_region *internal, dlesm_region *whole);
 
+/* init_periodic_bc_halos, field_mod.f90:1394-1464: the (source, destination) regions of the
+ * periodic-boundary copies of a field with the given internal region, in the reference's order
+ * (x pair first, then the y pair over the widened columns).  source/dest hold 4 entries;
+ * *num_halos = 0, 2 or 4.  The region's nx, ny members are filled with the extents. */
+int dlesm_periodic_halos(const dlesm_region *internal, int bc_x, int bc_y, dlesm_region *source,
+                         dlesm_region *dest, int *num_halos);
+
 /* go_decompose, parallel_mod.f90:70-332.  ntilex,ntiley <= 0 selects the
  * reference's automatic tiling.  subdomains must hold ndomains entries. */
 int dlesm_decompose(int domainx, int domainy, int ndomains, int ntilex, int ntiley,
@@ -252,6 +259,23 @@ int dlesm_shallow_autotune_f64(const dlesm_sw_params *params, int ld, int ny,
                                const double *uold, const double *vold, const double *pold,
                                double *unew, double *vnew, double *pnew, void *stream);
 
+/* The SW-offset form of the same step -- the staggering of the GOcean `shallow` benchmark
+ * (DESIGN.md section 6.2): u(i,j) on the WEST face of T(i,j), v on the south face, z on the SW
+ * corner.  The only staggering the reference supports with periodic boundaries, and only serially
+ * (field_mod.f90:675-751, grid_mod.f90:437-442); u, v, p must hold valid periodic halos
+ * (dlesm_periodic_halos_apply_f64), the new fields get theirs from the caller the same way. */
+int dlesm_shallow_step_sw_f64(const dlesm_sw_params *params, int ld, int ny,
+                              int xstart, int xstop, int ystart, int ystop,
+                              const double *u, const double *v, const double *p,
+                              const double *uold, const double *vold, const double *pold,
+                              double *unew, double *vnew, double *pnew, void *stream);
+
+/* All periodic-boundary copies of one field (dlesm_periodic_halos' regions, applied in order with
+ * the patch copy below), enqueued on `stream`: what the PSy layer of a periodic model does after
+ * every kernel that writes the field. */
+int dlesm_periodic_halos_apply_f64(double *field, int ld, int ny, const dlesm_region *internal,
+                                   int bc_x, int bc_y, void *stream);
+
 /* field_copy_code over a box (infrastructure_mod.f90:32-41) and the patch copy
  * used for periodic boundaries (copy_2dfield_patch, field_mod.f90:1179-1187):
  * dst(dx0.., dy0..) = src(sx0.., sy0..) for an nx x ny patch. */
@@ -366,6 +390,40 @@ int dlesm_global_sum_f64(double *value);
 /* gather, parallel_utils_mod.f90:242-255: n doubles per rank (device memory)
  * -> n*nranks doubles on rank 0 (device memory). Synchronous. */
 int dlesm_gather_f64(const double *send, double *recv, int n);
+
+/* ------------------------------------------------------------------------
+ * 6. Device-side gather / scatter of whole fields
+ *    (gather_inner_data, field_mod.f90:1313-1390; the init_global_data scatter of the
+ *     constructor, field_mod.f90:378-389)
+ * ---------------------------------------------------------------------- */
+
+/* Pack loop of gather_inner_data (field_mod.f90:1360-1368): the box of a device field, j outer /
+ * i inner, into send[0 .. nx*ny); the rest of the slot (tiles are uneven, every rank sends the
+ * size of the largest one, field_mod.f90:1348-1351) is zeroed.  slot >= nx*ny. */
+int dlesm_pack_inner_f64(const double *field, int ld, int ny, int xstart, int xstop, int ystart,
+                         int ystop, double *send, long slot, void *stream);
+
+/* Unpack loop of gather_inner_data on rank 0 (field_mod.f90:1372-1386): slot r of `recv` (slot
+ * doubles each) goes to rank r's box in the global array, `global` being a device array of
+ * global_nx x global_ny doubles (column-major, like the Fortran result).  One launch for all ranks. */
+int dlesm_unpack_gathered_f64(const double *recv, long slot, const dlesm_decomp *decomp,
+                              const dlesm_subdomain *subdomains, int nranks, double *global,
+                              void *stream);
+
+/* gather_inner_data for a device-resident field: pack on the device, ncclSend/ncclRecv to rank 0
+ * (MPI_Gather of parallel_utils_mod.f90:242-255), unpack on the device, ONE device-to-host copy of
+ * the global array into global_host (global_nx x global_ny doubles; only read on rank 0, may be
+ * NULL elsewhere).  internal: this rank's internal region (halo_x = xstart-1, halo_y = ystart-1,
+ * field_mod.f90:1348-1349).  Synchronous.  With one rank: the copy-out of field_mod.f90:1332-1343. */
+int dlesm_gather_inner_f64(const double *field, int ld, int ny, const dlesm_region *internal,
+                           const dlesm_decomp *decomp, const dlesm_subdomain *subdomains,
+                           int nranks, double *global_host);
+
+/* The constructor's scatter (field_mod.f90:378-389): this rank's internal region of the device
+ * field <- the matching patch of a HOST global array (global_nx x global_ny), one strided
+ * host-to-device copy.  sub: this rank's subdomain (its global box gives the patch). Synchronous. */
+int dlesm_scatter_inner_f64(const double *global_host, int global_nx, int global_ny,
+                            const dlesm_subdomain *sub, double *field, int ld, int ny);
 
 #ifdef __cplusplus
 }

@@ -702,3 +702,125 @@ void orc_sw_step(const orc_sw_params *q, int ld, int xs, int xe, int ys, int ye,
     for (j = ys; j <= ye; j++)
         for (i = xs; i <= xe; i++) compute_pnew_code(i, j, pnew, pold, cu, cv, q->tdtsdx, q->tdtsdy, ld);
 }
+
+/* ------------------------------------------------------------------------ */
+/* Shallow-water kernels, SW offset -- the staggering of the GOcean `shallow` benchmark the SURVEY
+ * (section 8 f.2) names [external; not in /root/reference]: u(i,j) is the WEST face of T(i,j),
+ * v(i,j) the south face, z(i,j) the SW corner.  Formulas frozen in DESIGN.md section 6.2. */
+static inline void compute_cu_sw_code(int i, int j, double *cu, const double *p, const double *u, int ld)
+{
+    A(cu, i, j) = 0.5 * (A(p, i, j) + A(p, i - 1, j)) * A(u, i, j);
+}
+static inline void compute_cv_sw_code(int i, int j, double *cv, const double *p, const double *v, int ld)
+{
+    A(cv, i, j) = 0.5 * (A(p, i, j) + A(p, i, j - 1)) * A(v, i, j);
+}
+static inline void compute_z_sw_code(int i, int j, double *z, const double *p, const double *u,
+                                     const double *v, double fsdx, double fsdy, int ld)
+{
+    A(z, i, j) = (fsdx * (A(v, i, j) - A(v, i - 1, j)) - fsdy * (A(u, i, j) - A(u, i, j - 1))) /
+                 (A(p, i - 1, j - 1) + A(p, i, j - 1) + A(p, i, j) + A(p, i - 1, j));
+}
+static inline void compute_h_sw_code(int i, int j, double *h, const double *p, const double *u,
+                                     const double *v, int ld)
+{
+    A(h, i, j) = A(p, i, j) + 0.25 * (A(u, i + 1, j) * A(u, i + 1, j) + A(u, i, j) * A(u, i, j) +
+                                      A(v, i, j + 1) * A(v, i, j + 1) + A(v, i, j) * A(v, i, j));
+}
+static inline void compute_unew_sw_code(int i, int j, double *unew, const double *uold, const double *z,
+                                        const double *cv, const double *h, double tdts8, double tdtsdx, int ld)
+{
+    A(unew, i, j) = A(uold, i, j) +
+                    tdts8 * (A(z, i, j + 1) + A(z, i, j)) *
+                        (A(cv, i, j + 1) + A(cv, i - 1, j + 1) + A(cv, i - 1, j) + A(cv, i, j)) -
+                    tdtsdx * (A(h, i, j) - A(h, i - 1, j));
+}
+static inline void compute_vnew_sw_code(int i, int j, double *vnew, const double *vold, const double *z,
+                                        const double *cu, const double *h, double tdts8, double tdtsdy, int ld)
+{
+    A(vnew, i, j) = A(vold, i, j) -
+                    tdts8 * (A(z, i + 1, j) + A(z, i, j)) *
+                        (A(cu, i + 1, j) + A(cu, i, j) + A(cu, i, j - 1) + A(cu, i + 1, j - 1)) -
+                    tdtsdy * (A(h, i, j) - A(h, i, j - 1));
+}
+static inline void compute_pnew_sw_code(int i, int j, double *pnew, const double *pold, const double *cu,
+                                        const double *cv, double tdtsdx, double tdtsdy, int ld)
+{
+    A(pnew, i, j) = A(pold, i, j) - tdtsdx * (A(cu, i + 1, j) - A(cu, i, j)) -
+                    tdtsdy * (A(cv, i, j + 1) - A(cv, i, j));
+}
+
+void orc_sw_step_sw(const orc_sw_params *q, int ld, int xs, int xe, int ys, int ye,
+                    const double *u, const double *v, const double *p,
+                    const double *uold, const double *vold, const double *pold,
+                    double *cu, double *cv, double *z, double *h,
+                    double *unew, double *vnew, double *pnew)
+{
+    int i, j;
+    /* intermediates on the box grown towards their consumers */
+    for (j = ys - 1; j <= ye; j++)
+        for (i = xs; i <= xe + 1; i++) compute_cu_sw_code(i, j, cu, p, u, ld);
+    for (j = ys; j <= ye + 1; j++)
+        for (i = xs - 1; i <= xe; i++) compute_cv_sw_code(i, j, cv, p, v, ld);
+    for (j = ys; j <= ye + 1; j++)
+        for (i = xs; i <= xe + 1; i++) compute_z_sw_code(i, j, z, p, u, v, q->fsdx, q->fsdy, ld);
+    for (j = ys - 1; j <= ye; j++)
+        for (i = xs - 1; i <= xe; i++) compute_h_sw_code(i, j, h, p, u, v, ld);
+    for (j = ys; j <= ye; j++)
+        for (i = xs; i <= xe; i++) compute_unew_sw_code(i, j, unew, uold, z, cv, h, q->tdts8, q->tdtsdx, ld);
+    for (j = ys; j <= ye; j++)
+        for (i = xs; i <= xe; i++) compute_vnew_sw_code(i, j, vnew, vold, z, cu, h, q->tdts8, q->tdtsdy, ld);
+    for (j = ys; j <= ye; j++)
+        for (i = xs; i <= xe; i++) compute_pnew_sw_code(i, j, pnew, pold, cu, cv, q->tdtsdx, q->tdtsdy, ld);
+}
+
+/* init_periodic_bc_halos, field_mod.f90:1394-1464: source/dest hold up to 4 regions each, in the
+ * reference's order; returns their number.  bc: 0 = GO_BC_PERIODIC (grid_mod.f90:64-69). */
+int orc_periodic_halos(const orc_region *it, int bc_x, int bc_y, orc_region *source, orc_region *dest)
+{
+    int n = 0;
+    if (bc_x == 0) {
+        /* E-most column set to W-most internal column (:1413-1423) */
+        dest[n].xstart = it->xstop + 1;  dest[n].xstop = it->xstop + 1;
+        dest[n].ystart = it->ystart;     dest[n].ystop = it->ystop;
+        source[n].xstart = it->xstart;   source[n].xstop = it->xstart;
+        source[n].ystart = it->ystart;   source[n].ystop = it->ystop;
+        n++;
+        /* W-most column set to E-most internal column (:1425-1435) */
+        dest[n].xstart = it->xstart - 1; dest[n].xstop = it->xstart - 1;
+        dest[n].ystart = it->ystart;     dest[n].ystop = it->ystop;
+        source[n].xstart = it->xstop;    source[n].xstop = it->xstop;
+        source[n].ystart = it->ystart;   source[n].ystop = it->ystop;
+        n++;
+    }
+    if (bc_y == 0) {
+        /* N-most row set to S-most internal row (:1439-1449) */
+        dest[n].xstart = it->xstart - 1; dest[n].xstop = it->xstop + 1;
+        dest[n].ystart = it->ystop + 1;  dest[n].ystop = it->ystop + 1;
+        source[n].xstart = it->xstart - 1; source[n].xstop = it->xstop + 1;
+        source[n].ystart = it->ystart;   source[n].ystop = it->ystart;
+        n++;
+        /* S-most row set to N-most internal row (:1451-1461) */
+        dest[n].xstart = it->xstart - 1; dest[n].xstop = it->xstop + 1;
+        dest[n].ystart = it->ystart - 1; dest[n].ystop = it->ystart - 1;
+        source[n].xstart = it->xstart - 1; source[n].xstop = it->xstop + 1;
+        source[n].ystart = it->ystop;    source[n].ystop = it->ystop;
+        n++;
+    }
+    for (int k = 0; k < n; k++) {
+        source[k].nx = source[k].xstop - source[k].xstart + 1;  source[k].ny = source[k].ystop - source[k].ystart + 1;
+        dest[k].nx = dest[k].xstop - dest[k].xstart + 1;        dest[k].ny = dest[k].ystop - dest[k].ystart + 1;
+    }
+    return n;
+}
+
+/* the copies themselves, copy_2dfield_patch (field_mod.f90:1179-1187), in the list's order */
+void orc_apply_periodic_halos(double *f, int ld, const orc_region *it, int bc_x, int bc_y)
+{
+    orc_region src[4], dst[4];
+    const int n = orc_periodic_halos(it, bc_x, bc_y, src, dst);
+    for (int k = 0; k < n; k++)
+        for (int j = 0; j < src[k].ny; j++)
+            for (int i = 0; i < src[k].nx; i++)
+                f[IDX(ld, dst[k].xstart + i, dst[k].ystart + j)] = f[IDX(ld, src[k].xstart + i, src[k].ystart + j)];
+}

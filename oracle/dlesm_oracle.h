@@ -142,4 +142,14 @@ int orc_max_threads(void);
 #ifdef __cplusplus
 }
 #endif
+/* SW-offset shallow-water step and the periodic-boundary halo copies
+ * (field_mod.f90:1394-1464, 1179-1187) */
+void orc_sw_step_sw(const orc_sw_params *q, int ld, int xs, int xe, int ys, int ye,
+                    const double *u, const double *v, const double *p,
+                    const double *uold, const double *vold, const double *pold,
+                    double *cu, double *cv, double *z, double *h,
+                    double *unew, double *vnew, double *pnew);
+int orc_periodic_halos(const orc_region *it, int bc_x, int bc_y, orc_region *source, orc_region *dest);
+void orc_apply_periodic_halos(double *f, int ld, const orc_region *it, int bc_x, int bc_y);
+
 #endif

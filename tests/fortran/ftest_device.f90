@@ -71,6 +71,16 @@ program ftest_device
      h => a%get_data()
   end if
   write(*, '("G: cs ",ES24.16E3)') cs
+  ! gather_inner_data of the device-resident field (device pack/unpack, one copy to the host)
+  block
+    real(go_wp), allocatable :: glob(:,:)
+    if (mod(nsteps, 2) == 1) then
+       call b%gather_inner_data(glob)
+    else
+       call a%gather_inner_data(glob)
+    end if
+    write(*, '("G: gather ",3(I0,1x))') size(glob, 1), size(glob, 2), count(glob /= h(2:nx + 1, 2:ny + 1))
+  end block
   write(*, '("G: sample ",3(ES24.16E3,1x))') h(2, 2), h(nx/2 + 1, ny/2 + 1), h(nx + 1, ny + 1)
 
   ! ---- (2b) four fused steps against four single steps --------------------------

@@ -97,6 +97,10 @@ def lib():
     L.orc_jacobi5_masked.argtypes = [_dp, _dp, _ip] + [C.c_int] * 5
     L.orc_tmask_fill.argtypes = [C.c_void_p] + [C.c_int] * 7 + [_ip]
     L.orc_sw_step.argtypes = [C.POINTER(SwParams)] + [C.c_int] * 5 + [_dp] * 13
+    L.orc_sw_step_sw.argtypes = [C.POINTER(SwParams)] + [C.c_int] * 5 + [_dp] * 13
+    L.orc_periodic_halos.argtypes = [C.POINTER(Region), C.c_int, C.c_int, C.POINTER(Region), C.POINTER(Region)]
+    L.orc_periodic_halos.restype = C.c_int
+    L.orc_apply_periodic_halos.argtypes = [_dp, C.c_int, C.POINTER(Region), C.c_int, C.c_int]
     L.orc_max_threads.restype = C.c_int
     L.orc_copy_rows_omp.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int]
     _lib = L
@@ -246,3 +250,24 @@ def tmask_fill(user, nx, ny, internal):
         u = np.ascontiguousarray(user, dtype=np.int32)
         lib().orc_tmask_fill(u.ctypes.data, u.shape[1], nx, ny, *internal, out)
     return out
+
+
+def sw_step_sw(prm, ld, box, u, v, p, uold, vold, pold, unew, vnew, pnew):
+    """orc_sw_step_sw (SW-offset staggering) on the 1-based inclusive box"""
+    scratch = [np.zeros_like(p) for _ in range(4)]
+    op = SwParams(prm.fsdx, prm.fsdy, prm.tdts8, prm.tdtsdx, prm.tdtsdy)
+    xs, xe, ys, ye = box
+    lib().orc_sw_step_sw(C.byref(op), ld, xs, xe, ys, ye, u, v, p, uold, vold, pold, *scratch, unew, vnew, pnew)
+
+
+def periodic_halos(internal, bcx, bcy):
+    """[(source as6, dest as6)] of init_periodic_bc_halos; internal = (xstart, xstop, ystart, ystop)"""
+    it = Region(0, 0, *internal)
+    src, dst = (Region * 4)(), (Region * 4)()
+    n = lib().orc_periodic_halos(C.byref(it), bcx, bcy, src, dst)
+    return [(src[k].as6()[:4], dst[k].as6()[:4]) for k in range(n)]
+
+
+def apply_periodic_halos(f, ld, internal, bcx, bcy):
+    it = Region(0, 0, *internal)
+    lib().orc_apply_periodic_halos(f, ld, C.byref(it), bcx, bcy)

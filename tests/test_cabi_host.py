@@ -308,3 +308,22 @@ def test_python_grid_tmask_matches_reference():
         assert [g.nx, g.ny] == c["grid"][:2]
         assert g.tmask.tolist() == c["tmask"]
     os.environ.pop("DL_ESM_ALIGNMENT", None)
+
+
+def test_periodic_halo_regions_match_reference_and_python_fields_carry_them():
+    """dlesm_periodic_halos == the real reference's field%halo lists (ref_bounds.json)"""
+    import ctypes as C
+    Reg = _cabi.Region
+    n_checked = 0
+    for c in load_golden("ref_bounds")["cases"]:
+        if c["abort"] or c["offset"] != 0 or not c["halos"]:
+            continue
+        it = Reg(0, 0, *c["internal"][:4])
+        src, dst, n = (Reg * 4)(), (Reg * 4)(), C.c_int()
+        assert L.dlesm_periodic_halos(C.byref(it), c["bcx"], c["bcy"], src, dst, C.byref(n)) == 0
+        got = [[src[k].xstart, src[k].xstop, src[k].ystart, src[k].ystop, dst[k].xstart, dst[k].xstop,
+                dst[k].ystart, dst[k].ystop] for k in range(n.value)]
+        assert got == c["halos"], c
+        assert all(src[k].nx == dst[k].nx and src[k].ny == dst[k].ny for k in range(n.value))
+        n_checked += 1
+    assert n_checked >= 100

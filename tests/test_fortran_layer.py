@@ -224,6 +224,7 @@ def test_fortran_device_io_and_jacobi_on_gpu(exe):
     assert abs(float(g["cs"][0][0]) - cs) <= 1e-12 * cs
     got = [float(x) for x in g["sample"][0]]
     assert got == [a[1, 1], a[ny // 2, nx // 2], a[ny, nx]]
+    assert ints(g["gather"][0]) == [nx, ny, 0]        # device-side gather_inner_data == the field's interior
     # (2b) invoke_jacobi5_multi(.., 4) == four invoke_jacobi5 calls, and == four oracle steps
     assert int(g["fused4"][0][0]) == 0
     a = O.hash_field(4242, nyy, ld, 0, 0, 1, nx + 2, 1, ny + 2)

@@ -299,6 +299,43 @@ def test_scatter_gather_matches_reference_golden(D):
         assert list(back.shape[::-1]) == m["gather_shape"] and np.array_equal(back, glob)
 
 
+@pytest.mark.parametrize("nx,ny,nranks", [(10, 10, 4), (10, 10, 6), (37, 29, 6), (64, 48, 8), (13, 13, 9)])
+def test_device_gather_pack_and_unpack_for_uneven_tiles(D, nx, ny, nranks):
+    """gather_inner_data's device legs for 4-9 ranks on one GPU: every rank's internal region packed
+    into its fixed-size slot (dlesm_pack_inner_f64, the slot is the LARGEST tile: tiles are uneven,
+    field_mod.f90:1348-1351), all slots unpacked into the global array in one launch
+    (dlesm_unpack_gathered_f64) -- against the oracle's gather of the same per-rank fields"""
+    import torch
+    L = D._cabi.lib()
+    d, subs = O.decompose(nx, ny, nranks)
+    ext = [O.grid_extents(s.glob.nx, s.glob.ny, 2) for s in subs]
+    rng = np.random.default_rng(nranks)
+    fields = [rng.random((e[1], e[0])) for e in ext]
+    want = O.gather_all(fields, [e[0] for e in ext], d, subs)
+    pd = D.go_decompose(nx, ny, ndomains=nranks)
+    assert (pd.max_width, pd.max_height) == (d.max_width, d.max_height)
+    slot = (d.max_width - 2) * (d.max_height - 2)
+    recv = torch.full((nranks * slot,), -5.0, dtype=torch.float64, device="cuda")
+    for r, s in enumerate(subs):
+        f = torch.from_numpy(fields[r]).cuda()
+        it = s.internal
+        D._cabi.check(L.dlesm_pack_inner_f64(C.c_void_p(f.data_ptr()), ext[r][0], ext[r][1], it.xstart, it.xstop,
+                                             it.ystart, it.ystop, C.c_void_p(recv.data_ptr() + 8 * r * slot), slot, None))
+        torch.cuda.synchronize()
+        n = it.nx * it.ny
+        got = recv[r * slot:(r + 1) * slot].cpu().numpy()
+        assert np.array_equal(got[:n], fields[r][it.ystart - 1:it.ystop, it.xstart - 1:it.xstop].ravel())
+        assert np.all(got[n:] == 0.0)
+    glob = torch.full((ny, nx), -9.0, dtype=torch.float64, device="cuda")
+    D._cabi.check(L.dlesm_unpack_gathered_f64(C.c_void_p(recv.data_ptr()), slot, C.byref(pd._info), pd.subdomains,
+                                              nranks, C.c_void_p(glob.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(glob.cpu().numpy(), want)
+    # a slot that is too small is refused, not overrun
+    assert L.dlesm_unpack_gathered_f64(C.c_void_p(recv.data_ptr()), 1, C.byref(pd._info), pd.subdomains, nranks,
+                                       C.c_void_p(glob.data_ptr()), None) == D._cabi.EINVAL
+
+
 def test_copy_patch_periodic_halos(D):
     """the periodic-BC halo copies (field_mod.f90:1394-1464) done with the device patch copy,
     regions taken from the reference golden for SW-offset periodic T fields"""
@@ -599,6 +636,52 @@ def test_shallow_cache_policies_and_planned_shapes_change_no_bit(D, nx, ny, alig
     _set_tuning(D, j5_use_tuned=0)
     check("rule")
     _set_tuning(D, j5_use_tuned=1)
+
+
+@pytest.mark.parametrize("nx,ny,alignment,steps", [(10, 10, None, 5), (10, 10, 8, 5), (256, 256, None, 4), (256, 256, 64, 4),
+                                                   (37, 5, 2, 3)])
+def test_periodic_sw_offset_shallow_model(D, nx, ny, alignment, steps):
+    """the configuration section 8 f.2 was built for: SW offset, periodic in x and y (serial only in
+    the reference, field_mod.f90:675-751): dlesm_shallow_step_sw_f64 + the device periodic-halo
+    copies (the field's own halo list) + leapfrog rotation, `steps` times, every bit against the
+    oracle running the same model (orc_sw_step_sw pinned by tests/sw_numpy.py, halo regions by the
+    reference's)"""
+    import torch
+    g = _grid(D, nx, ny, alignment, offset=D.GO_OFFSET_SW, bc=(0, 0, 2))
+    names, F = _sw_fields(D, g)
+    it = F["p"].internal
+    assert all(F[n].internal.box() == it.box() for n in names)      # periodic SW: all point types share the internal region
+    assert len(F["u"].halo) == 4
+    prm = D.psy.shallow_params(1.0e5, 0.9e5, 90.0)
+    for k, n in enumerate("uvp"):
+        D.psy.hash_init(F[n], SEED + 40 + k, box=it)
+        F[n].data.add_(1.0 if n == "p" else -0.5)
+        D.psy.apply_periodic_halos(F[n])
+        D.copy_field(F[n], F[n + "old"])
+        D.copy_field(F[n], F[n + "new"])
+    torch.cuda.synchronize()
+    H = {n: F[n].get_data() for n in names}
+    # the device halo copies == the oracle's on the same interior
+    for n in "uvp":
+        ref = H[n].copy()
+        ref[0, :] = ref[:, 0] = -7.0                             # wreck the halos, let the oracle rebuild them
+        ref[it.ystop, :] = ref[:, it.xstop] = -7.0
+        O.apply_periodic_halos(ref, g.nx, it.box(), 0, 0)
+        assert np.array_equal(ref[:it.ystop + 1, :it.xstop + 1], H[n][:it.ystop + 1, :it.xstop + 1]), n
+    cur, old, new = [F[n] for n in "uvp"], [F[n + "old"] for n in "uvp"], [F[n + "new"] for n in "uvp"]
+    hc, ho, hn = [H[n] for n in "uvp"], [H[n + "old"] for n in "uvp"], [H[n + "new"] for n in "uvp"]
+    for _ in range(steps):
+        D.psy.invoke_shallow_step_sw(prm, *cur, *old, *new)
+        for f in new:
+            D.psy.apply_periodic_halos(f)
+        O.sw_step_sw(prm, g.nx, it.box(), *hc, *ho, *hn)
+        for f in hn:
+            O.apply_periodic_halos(f, g.nx, it.box(), 0, 0)
+        torch.cuda.synchronize()
+        for f, w in zip(new, hn):
+            assert np.array_equal(f.get_data(), w)
+        old, cur, new = cur, new, old
+        ho, hc, hn = hc, hn, ho
 
 
 def _sw_fields(D, g):

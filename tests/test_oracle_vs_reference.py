@@ -337,3 +337,85 @@ def test_jacobi5_masked_against_numpy():
     O.jacobi5_masked(a, o1, one, 24, 2, 22, 2, 18)
     O.jacobi5(a, o2, 24, 2, 22, 2, 18)
     assert np.array_equal(o1, o2)
+
+
+# --------------------------------------------------------------------------- SW offset + periodic boundaries
+def _periodic_cases():
+    return [c for c in load_golden("ref_bounds")["cases"] if not c["abort"] and c["offset"] == 0 and c["halos"]]
+
+
+def test_periodic_halo_regions_match_reference():
+    """orc_periodic_halos against the halo lists the REAL reference built (init_periodic_bc_halos,
+    field_mod.f90:1394-1464; tests/golden/ref_bounds.json): every SW-offset periodic case"""
+    cases = _periodic_cases()
+    assert len(cases) >= 100
+    for c in cases:
+        it = c["internal"][:4]
+        got = O.periodic_halos(it, c["bcx"], c["bcy"])
+        assert [s + d for (s, d) in got] == c["halos"], c
+        assert len(got) == c["num_halos"]
+
+
+@pytest.mark.parametrize("nx,ny,ld_extra", [(37, 23, 0), (10, 10, 1), (64, 48, 5), (1, 1, 0), (130, 7, 2)])
+def test_sw_offset_step_against_independent_numpy(nx, ny, ld_extra):
+    """PARITY UNPINNED by the reference (no stencil there; the SW-offset kernels are the public GOcean
+    `shallow` benchmark's).  orc_sw_step_sw against the whole-array numpy
+    evaluation sw_step_numpy_sw: bit for bit"""
+    import sw_numpy as N
+    ld, nyarr = nx + 3 + ld_extra, ny + 3
+    rng = np.random.default_rng(nx * 31 + ny)
+    prm = N.Params(1.0e5, 0.6e5, 90.0)
+    u, v, uold, vold = (rng.random((nyarr, ld)) - 0.5 for _ in range(4))
+    p, pold = (rng.random((nyarr, ld)) + 1.0 for _ in range(2))
+    boxes = [(2, nx + 1, 2, ny + 1)] + ([(3, nx, 4, ny - 1)] if nx > 8 and ny > 6 else [])
+    for box in boxes:
+        want = [np.full((nyarr, ld), 9.0) for _ in range(3)]
+        got = [np.full((nyarr, ld), 9.0) for _ in range(3)]
+        N.sw_step_numpy_sw(prm, box, u, v, p, uold, vold, pold, *want)
+        O.sw_step_sw(prm, ld, box, u, v, p, uold, vold, pold, *got)
+        for name, g, w in zip(("unew", "vnew", "pnew"), got, want):
+            assert np.array_equal(g, w), (name, box)
+        xs, xe, ys, ye = box
+        assert np.all(np.isfinite(got[0][ys - 1:ye, xs - 1:xe]))
+
+
+def test_periodic_sw_model_conserves_mass_and_is_translation_invariant():
+    """properties of the periodic model (step + halo copies + rotation) that need no reference:
+    (i) pnew - pold is a discrete divergence, so SUM(p) over the periodic domain returns to SUM(pold)
+    up to rounding; (ii) shifting the initial state by (3, 5) cells around the torus shifts the result"""
+    import sw_numpy as N
+    n, ld = 24, 27
+    prm = N.Params(1.0e5, 1.0e5, 90.0)
+    it = (2, n + 1, 2, n + 1)
+    rng = np.random.default_rng(11)
+
+    def state(shift):
+        rng2 = np.random.default_rng(11)
+        out = []
+        for k in range(3):
+            core = rng2.random((n, n)) + (1.0 if k == 2 else -0.5)
+            core = np.roll(core, shift, axis=(0, 1))
+            f = np.zeros((n + 3, ld))
+            f[1:n + 1, 1:n + 1] = core
+            O.apply_periodic_halos(f, ld, it, 0, 0)
+            out.append(f)
+        return out
+
+    def run(shift, steps=3):
+        cur = state(shift)
+        old = [f.copy() for f in cur]
+        new = [f.copy() for f in cur]
+        for _ in range(steps):
+            O.sw_step_sw(prm, ld, it, *cur, *old, *new)
+            for f in new:
+                O.apply_periodic_halos(f, ld, it, 0, 0)
+            old, cur, new = cur, new, old
+        return cur, old
+
+    cur, old = run((0, 0), steps=1)
+    p0 = state((0, 0))[2]
+    assert abs(cur[2][1:n + 1, 1:n + 1].sum() - p0[1:n + 1, 1:n + 1].sum()) < 1e-9
+    a, _ = run((0, 0))
+    b, _ = run((5, 3))
+    for fa, fb in zip(a, b):
+        assert np.array_equal(np.roll(fa[1:n + 1, 1:n + 1], (5, 3), axis=(0, 1)), fb[1:n + 1, 1:n + 1])
