@@ -358,7 +358,9 @@ def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, step
     a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
     it = a.internal
     assert (it.nx, it.ny) == (tile, tile) and (g.decomp.nx, g.decomp.ny) == (P, Q)
-    step = D.psy.invoke_jacobi5_dm if world > 1 else D.psy.invoke_jacobi5
+    # N > 1: the time-loop form of the distributed step -- the exchange of step k is joined by step k+1's
+    # frame workgroups on the device, the caller's stream carries one launch per step; ONE join closes the loop
+    step = D.psy.invoke_jacobi5_dm_pipelined if world > 1 else D.psy.invoke_jacobi5
     L = D._cabi.lib()
     with torch.cuda.stream(stream):
         D.psy.hash_init(a, SEED, stream=stream)
@@ -380,7 +382,8 @@ def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, step
             D.copy_field(a, y, stream=stream)
             D.psy.invoke_jacobi5(y, x, stream=stream)
             y.halo_exchange(1, stream=stream, dirs=D._cabi.DIRS_EDGES_ONLY)
-            D.psy.invoke_jacobi5_dm(b, a, stream=stream)
+            D.psy.invoke_jacobi5_dm_pipelined(b, a, stream=stream)
+            D.psy.halo_join(g, stream=stream)
         stream.synchronize()
         ok = torch.tensor([1 if torch.equal(b.data, y.data) else 0], device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -399,12 +402,16 @@ def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, step
         for _ in range(warmup):
             step(b, a, stream=stream)
             a, b = b, a
+        if world > 1:
+            D.psy.halo_join(g, stream=stream)
     barrier()
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         for _ in range(steps):
             step(b, a, stream=stream)
             a, b = b, a
+        if world > 1:
+            D.psy.halo_join(g, stream=stream)                # the one join of the loop, inside the timed region
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
@@ -478,7 +485,9 @@ def main():
         a.halo_exchange(1, stream=stream)    # `in` starts with valid halos
     stream.synchronize()
 
-    step = D.psy.invoke_jacobi5_dm if world > 1 else D.psy.invoke_jacobi5
+    # N > 1: the time-loop form of the distributed step -- the exchange of step k is joined by step k+1's
+    # frame workgroups on the device, the caller's stream carries one launch per step; ONE join closes the loop
+    step = D.psy.invoke_jacobi5_dm_pipelined if world > 1 else D.psy.invoke_jacobi5
     planned = False
     if not args.no_plan:
         # planning, outside the timed region (like an FFT plan): the library times its launch shapes for
@@ -512,8 +521,9 @@ def main():
         with torch.cuda.stream(stream):
             for f in (x1, y1, x2, y2):
                 D.copy_field(a, f, stream=stream)
-            for _ in range(3):
-                D.psy.invoke_jacobi5_dm(y1, x1, stream=stream)
+            for k in range(3):
+                # two steps in the time-loop form (device-side join), the last one in the joined form
+                (D.psy.invoke_jacobi5_dm_pipelined if k < 2 else D.psy.invoke_jacobi5_dm)(y1, x1, stream=stream)
                 x1, y1 = y1, x1
                 D.psy.invoke_jacobi5(y2, x2, stream=stream)
                 y2.halo_exchange(1, stream=stream, dirs=D._cabi.DIRS_EDGES_ONLY)   # what the 5-point step exchanges
@@ -537,6 +547,8 @@ def main():
         for _ in range(warm_launches):
             step(b, a, stream=stream)
             a, b = b, a
+        if world > 1:
+            D.psy.halo_join(grid, stream=stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
@@ -545,6 +557,8 @@ def main():
         for _ in range(launches):
             step(b, a, stream=stream)
             a, b = b, a
+        if world > 1:
+            D.psy.halo_join(grid, stream=stream)             # inside the timed region
         e1.record(stream)
     barrier()
     wall = time.perf_counter() - t0
@@ -570,7 +584,8 @@ def main():
                    "tile": args.tile, "decomposition": f"{P}x{Q}",
                    "global": [args.tile * P, args.tile * Q], "DL_ESM_ALIGNMENT": args.alignment,
                    "ld": grid.nx,
-                   "halo_exchange": "rccl send/recv of the four edges, overlapped" if world > 1 else "none (1 tile)",
+                   "halo_exchange": "rccl send/recv of the four edges, overlapped; time-loop form (device-side join)"
+                   if world > 1 else "none (1 tile)",
                    "launch_shape": "planned (dlesm_stencil5_autotune_f64, before the warm-up)" if planned else "rule"},
         "hbm_gbs_per_gpu": round(achieved, 1),
         "checksum": checksum, "dm_step_equals_stencil_plus_exchange": selfcheck,

@@ -100,6 +100,14 @@ struct dlesm_halo_plan {
     unsigned *frame_counter = nullptr;
     unsigned long long frame_seq = 0;
     int *frame_timed_out = nullptr;
+    // pipelined steps (dlesm_jacobi5_step_dm_pipelined): the exchange of the last step is still in
+    // flight on the side stream when the call returns; `halo_flag` (device word, set on the side
+    // stream after the unpack) is what the NEXT step's frame workgroups wait on, ev_comm what any
+    // other consumer is joined on (dlesm_halo_plan_join)
+    unsigned long long *halo_flag = nullptr;
+    bool pending = false;              // an exchange has been issued and not yet joined on pending_stream
+    unsigned long long pending_seq = 0;
+    hipStream_t pending_stream = nullptr;
 };
 
 // edge directions follow their bit; diagonals follow their two edges (parallel_comms_mod.f90:
@@ -264,8 +272,9 @@ extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny
             dlesm_halo_plan_destroy(p);
             return fail(DLESM_EHIP, "halo plan: cannot allocate the frame flag");
         }
-        p->frame_flag = (unsigned long long *)words;                 // two words, 128 bytes apart
-        p->frame_counter = (unsigned *)((char *)words + 128);
+        p->frame_flag = (unsigned long long *)words;                 // three words, 64 bytes apart
+        p->frame_counter = (unsigned *)((char *)words + 64);
+        p->halo_flag = (unsigned long long *)((char *)words + 128);
         *p->frame_timed_out = 0;
     }
     *out = p;
@@ -300,6 +309,24 @@ static int ensure_buffers(dlesm_halo_plan *p, int nfields)
     if (p->recvbuf_len) DLESM_HIP_TRY(hipMalloc((void **)&p->recvbuf, (size_t)nfields * p->recvbuf_len * sizeof(double)));
     p->buf_fields = nfields;
     return DLESM_OK;
+}
+
+// A pipelined step leaves its exchange in flight: whoever touches the plan or the halos next on
+// stream `s` is ordered behind it first.
+static int join_pending(dlesm_halo_plan *p, hipStream_t s)
+{
+    if (!p->pending) return DLESM_OK;
+    DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
+    p->pending = false;
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_halo_plan_join(dlesm_halo_plan *p, void *stream)
+{
+    DLESM_REQUIRE(p != nullptr, "null plan");
+    DLESM_REQUIRE(!p->frame_timed_out || *p->frame_timed_out == 0,
+                  "a distributed step gave up waiting for a flag (frame or halo wait timed out)");
+    return join_pending(p, (hipStream_t)stream);
 }
 
 // The exchange of `nf` fields of the plan's shape in ONE grouped launch.  Between a pair of
@@ -359,6 +386,7 @@ extern "C" int dlesm_halo_exchange_multi_f64(dlesm_halo_plan *p, double *const *
     DLESM_REQUIRE(p != nullptr && fields != nullptr && nfields >= 1 && nfields <= 16, "bad arguments");
     for (int k = 0; k < nfields; k++) DLESM_REQUIRE(fields[k] != nullptr, "null field %d", k);
     if (int rc = ensure_device()) return rc;
+    if (int rc = join_pending(p, (hipStream_t)stream)) return rc;
     return exchange_on(p, fields, nfields, dirs_mask & 0x1Fu, (hipStream_t)stream);
 }
 
@@ -366,19 +394,27 @@ extern "C" int dlesm_halo_exchange_f64(dlesm_halo_plan *p, double *field, unsign
 {
     DLESM_REQUIRE(p != nullptr && field != nullptr, "null pointer");
     if (int rc = ensure_device()) return rc;
+    if (int rc = join_pending(p, (hipStream_t)stream)) return rc;
     return exchange_on(p, field, dirs_mask & 0x1Fu, (hipStream_t)stream);
 }
 
-extern "C" int dlesm_jacobi5_step_dm(dlesm_halo_plan *p, const double *in, double *out, int ld, int ny,
-                                     int xstart, int xstop, int ystart, int ystop, void *stream)
+static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *out, int ld, int ny, int xstart,
+                                int xstop, int ystart, int ystop, hipStream_t s, bool pipelined)
 {
     DLESM_REQUIRE(p != nullptr && in != nullptr && out != nullptr, "null pointer");
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
     if (int rc = ensure_device()) return rc;
-    hipStream_t s = (hipStream_t)stream, side = side_stream();
+    hipStream_t side = side_stream();
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) // single tile: one launch over the whole box
         return launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s);
+    // The previous step of a pipelined sequence left its exchange in flight.  If this step can take
+    // the one-launch form on the same stream, its frame workgroups wait for that exchange on the
+    // device (halo_flag) and the caller's stream needs no event wait at all; otherwise join now.
+    const bool can_chain = pipelined && p->pending && p->pending_stream == s && p->frame_flag &&
+                           tuning("j5_dm_fused", 1) && tuning("j5_dm_chain", 1);
+    if (!can_chain)
+        if (int rc = join_pending(p, s)) return rc;
     // The 5-point stencil never reads a corner halo: exchange the four edge directions only
     // (what passing just the needed comm directions does in the reference, pcomms:1557-1571).
     // j5_dm_corners=1 keeps the diagonal messages (halos then equal a full halo_exchange).
@@ -413,12 +449,19 @@ extern "C" int dlesm_jacobi5_step_dm(dlesm_halo_plan *p, const double *in, doubl
         job.counter = p->frame_counter;
         job.flag = p->frame_flag;
         job.seq = p->frame_seq + 1;
+        job.halo_flag = p->halo_flag;
+        job.halo_seq = can_chain ? p->pending_seq : 0;
+        job.timed_out = p->frame_timed_out;
         if (int rc = launch_stencil5_framed(in, out, ld, ny, xstart, xstop, ystart, ystop, job, s, &fused)) return rc;
         if (fused) {
             p->frame_seq = job.seq;
+            p->pending = false;                          // the chained wait (if any) is inside the launch
             if (int rc = launch_frame_flag_wait(p->frame_flag, job.seq, p->frame_timed_out, side)) return rc;
             if (int rc = exchange_on(p, out, mask, side, prepacked)) return rc;
+            if (int rc = launch_flag_set(p->halo_flag, job.seq, side)) return rc;
             DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
+        } else if (can_chain) {                          // the arrays do not qualify: fall back to the event join
+            if (int rc = join_pending(p, s)) return rc;
         }
     }
     if (!fused) {
@@ -432,9 +475,28 @@ extern "C" int dlesm_jacobi5_step_dm(dlesm_halo_plan *p, const double *in, doubl
         // 3. ... while the interior streams through HBM on the caller's stream
         if (int rc = launch_stencil5(in, out, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, s)) return rc;
     }
-    // 4. join: the next step reads out's halos
+    // 4. join: the next step reads out's halos.  Pipelined one-launch form: left to the next step's
+    //    frame workgroups (device flag) or to dlesm_halo_plan_join, whichever comes first.
+    if (pipelined && fused) {
+        p->pending = true;
+        p->pending_seq = p->frame_seq;
+        p->pending_stream = s;
+        return DLESM_OK;
+    }
     DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
     return DLESM_OK;
+}
+
+extern "C" int dlesm_jacobi5_step_dm(dlesm_halo_plan *p, const double *in, double *out, int ld, int ny,
+                                     int xstart, int xstop, int ystart, int ystop, void *stream)
+{
+    return jacobi5_step_dm_impl(p, in, out, ld, ny, xstart, xstop, ystart, ystop, (hipStream_t)stream, false);
+}
+
+extern "C" int dlesm_jacobi5_step_dm_pipelined(dlesm_halo_plan *p, const double *in, double *out, int ld, int ny,
+                                               int xstart, int xstop, int ystart, int ystop, void *stream)
+{
+    return jacobi5_step_dm_impl(p, in, out, ld, ny, xstart, xstop, ystart, ystop, (hipStream_t)stream, true);
 }
 
 // Distributed form of the fused steps (temporal blocking across tiles): `in` holds valid
@@ -452,6 +514,7 @@ extern "C" int dlesm_jacobi5_multi_step_dm(dlesm_halo_plan *p, const double *in,
     DLESM_REQUIRE(nsteps >= 2 && nsteps <= 8, "fused distributed step: nsteps = %d (2..8 supported)", nsteps);
     if (int rc = ensure_device()) return rc;
     hipStream_t s = (hipStream_t)stream, side = side_stream();
+    if (int rc = join_pending(p, s)) return rc;
     const int T = nsteps;
     int hasW = 0, hasE = 0, hasS = 0, hasN = 0;
     for (const Msg &m : p->recvs) { // a receive filed under Iminus comes from the west neighbour, ...
@@ -510,6 +573,7 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
     if (int rc = ensure_device()) return rc;
     hipStream_t s = (hipStream_t)stream, side = side_stream();
+    if (int rc = join_pending(p, s)) return rc;
     auto box = [&](int xs, int xe, int ys, int ye) {
         return dlesm_shallow_step_f64(q, ld, ny, xs, xe, ys, ye, u, v, pf, uold, vold, pold, unew, vnew, pnew, s);
     };

@@ -88,6 +88,11 @@ struct FrameJob {
     unsigned *counter;            // device word, 0 between launches
     unsigned long long *flag;
     unsigned long long seq;
+    // pipelined steps: before touching anything, the frame workgroups wait (bounded) until
+    // *halo_flag >= halo_seq -- the previous step's exchange has landed in `in`'s halos
+    const unsigned long long *halo_flag;
+    unsigned long long halo_seq;  // 0: no wait
+    int *timed_out;               // pinned host word raised by a wait that gives up
 };
 // Frame of the box + interior sweep in ONE launch.  *fused = false (and nothing launched) when the
 // arrays do not qualify for the 16-byte-lane tile kernel: the caller then takes the two-launch path.
@@ -95,6 +100,8 @@ int launch_stencil5_framed(const double *in, double *out, int ld, int ny, int xs
                            int ystop, FrameJob job, hipStream_t s, bool *fused);
 // park stream `s` (one sleeping wave) until *flag >= seq; bounded, see frame_flag_wait
 int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s);
+// *flag = seq, stream ordered (one thread): publishes "the exchange before this point has landed"
+int launch_flag_set(unsigned long long *flag, unsigned long long seq, hipStream_t s);
 
 // nsteps fused Jacobi steps (dlesm_jacobi_x2.hip); 1-based inclusive output box, last stage box,
 // grow flags -- see dlesm_stencil5_multi_f64

@@ -314,7 +314,17 @@ __device__ __forceinline__ void frame_cell(long t, const double *__restrict__ in
         else { i = k < ncol ? x0 : x1; j = y0 + 1 + (int)(k % ncol); }
     }
     const size_t o = (size_t)j * ld + i;
-    const double r = 0.25 * ((in[o - 1] + in[o + 1]) + (in[o - ld] + in[o + ld]));
+    // WT (frame inside the interior launch): the operand OUTSIDE the box is a halo cell the exchange may
+    // have written after this kernel started -- read it at device scope, past this XCD's L2.  The
+    // operands inside the box were written by the previous launch: ordinary cached loads.
+    auto get = [](const double *p, bool outside) {
+        if constexpr (WT) {
+            if (outside) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return *p;
+    };
+    const double r = 0.25 * ((get(in + o - 1, i == x0) + get(in + o + 1, i == x1)) +
+                             (get(in + o - ld, j == y0) + get(in + o + ld, j == y1)));
     auto put = [](double *p, double v) {
         if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *p = v;
@@ -343,6 +353,22 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_framed(const double *__rest
         return;
     }
     const long total = frame_cells(fj.fx1 - fj.fx0 + 1, fj.fy1 - fj.fy0 + 1);
+    if (fj.halo_seq) {
+        // pipelined steps: `in`'s halos (and the send buffer) belong to the previous step's exchange
+        // until its completion flag is up.  In steady state it has been up for a long time -- the
+        // exchange ends well inside the previous interior sweep -- and this costs one load.  Bounded.
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(fj.halo_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fj.halo_seq) {
+                __builtin_amdgcn_s_sleep(32);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {   // ~20 s of the 100 MHz counter
+                    __hip_atomic_store(fj.timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
     // The frame cells are read by the exchange while this kernel is still running, possibly from
     // another XCD (whose L2 is not coherent with this one): they are stored write-through at device
     // scope.  A per-thread __threadfence() instead would be a whole-L2 write-back + invalidate per
@@ -672,7 +698,7 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
 
 // One wave parked on the frame flag: lane 0 sleeps until the flag reaches `seq`.  It holds one wave
 // slot and issues one load per sleep period; it never spins hot.  The wait is
-// bounded (about 2 s of the 100 MHz real-time counter): if the frame never reports -- which only a
+// bounded (about 20 s of the 100 MHz real-time counter): if the frame never reports -- which only a
 // failed launch could cause -- the kernel gives up, raises *timed_out (pinned host memory, checked
 // by the next step call) and lets the stream drain instead of hanging the device.
 __global__ void frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out)
@@ -681,11 +707,23 @@ __global__ void frame_flag_wait(const unsigned long long *flag, unsigned long lo
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
         __builtin_amdgcn_s_sleep(64);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {   // ~20 s of the 100 MHz counter
             __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
     }
+}
+
+__global__ void flag_set(unsigned long long *flag, unsigned long long seq)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int launch_flag_set(unsigned long long *flag, unsigned long long seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(flag_set, dim3(1), dim3(64), 0, s, flag, seq);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
 }
 
 int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s)

@@ -73,6 +73,20 @@ def invoke_jacobi5_dm(out_fld, in_fld, stream=None):
                                             _stream_ptr(stream)))
 
 
+def invoke_jacobi5_dm_pipelined(out_fld, in_fld, stream=None):
+    """the distributed step inside a time loop: returns with the exchange of `out` in flight; the
+    next such step waits for it on the device.  Call halo_join(grid) before anything else reads halos."""
+    g, it = out_fld.grid, out_fld.internal
+    check(_cabi.lib().dlesm_jacobi5_step_dm_pipelined(grid_mod.halo_plan(g), in_fld.device_ptr, out_fld.device_ptr,
+                                                      g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop,
+                                                      _stream_ptr(stream)))
+
+
+def halo_join(grid, stream=None):
+    """order `stream` behind the exchange a pipelined step left in flight"""
+    check(_cabi.lib().dlesm_halo_plan_join(grid_mod.halo_plan(grid), _stream_ptr(stream)))
+
+
 def shallow_params(dx, dy, dt):
     """constants of the shallow-water step: tdt = 2*dt (leapfrog)"""
     tdt = dt + dt

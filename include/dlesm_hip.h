@@ -366,6 +366,19 @@ int dlesm_jacobi5_step_dm(dlesm_halo_plan *plan, const double *in, double *out,
                           int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                           void *stream);
 
+/* The same step for a TIME LOOP of such steps: it returns with the exchange of `out` still in flight
+ * on the library's side stream -- the caller's stream carries one kernel launch per step and no
+ * event wait.  The next pipelined step on the same plan and stream waits for that exchange on the
+ * device (its frame workgroups, the only ones that read halos, sleep on a flag the side stream sets
+ * after the unpack; bounded); every other entry point that takes the plan joins it first.  Before
+ * anything ELSE reads the halo cells of `out` (a kernel of the host program, a copy on another
+ * stream), call dlesm_halo_plan_join.  Same results as dlesm_jacobi5_step_dm, bit for bit. */
+int dlesm_jacobi5_step_dm_pipelined(dlesm_halo_plan *plan, const double *in, double *out,
+                                    int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                                    void *stream);
+/* order `stream` behind the exchange a pipelined step left in flight (no-op when there is none) */
+int dlesm_halo_plan_join(dlesm_halo_plan *plan, void *stream);
+
 /* nsteps (2..8) distributed Jacobi time steps per call, ONE depth-nsteps exchange per call
  * (temporal blocking across tiles; dlesm_stencil5_multi_f64 with stage boxes grown towards
  * every neighbouring tile).  `plan` must come from dlesm_map_comms_depth(depth = nsteps) tables

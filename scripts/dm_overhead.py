@@ -99,13 +99,19 @@ def main():
         else:
             D._cabi.check(L.dlesm_jacobi5_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *box, sp))
 
+    def pipelined(a, b):    # the time-loop form: no join on the caller's stream between steps
+        D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *box, sp))
+
     res = {}
     finals = {}
     with torch.cuda.stream(s):
         # the first mode of a process runs on cold clocks (2-3 % slow): measure `plain` twice, keep the second;
         # then serial / overlapped twice interleaved, keep the faster of each
-        for name, fn in (("cold", plain), ("plain", plain), ("serial", serial), ("overlapped", overlapped),
-                         ("serial2", serial), ("overlapped2", overlapped), ("plain2", plain)):
+        modes = [("cold", plain), ("plain", plain), ("serial", serial), ("overlapped", overlapped),
+                 ("serial2", serial), ("overlapped2", overlapped), ("plain2", plain)]
+        if T == 1:
+            modes += [("pipelined", pipelined), ("pipelined2", pipelined), ("plain3", plain)]
+        for name, fn in modes:
             a, b = F[0], F[1]                         # the same two buffers for every mode
             init(a, b)
             for _ in range(5):
@@ -117,20 +123,28 @@ def main():
             for _ in range(args.steps):
                 fn(a, b)
                 a, b = b, a
+            if name.startswith("pipelined"):
+                D._cabi.check(L.dlesm_halo_plan_join(plan, sp))     # the one join of the loop, inside the timed region
             e1.record(s)
             s.synchronize()
             res[name] = e0.elapsed_time(e1) / args.steps
-            if name in ("serial", "overlapped"):
+            if name in ("serial", "overlapped", "pipelined"):
                 finals[name] = a.data.clone()
-    for k in ("plain", "serial", "overlapped"):
+    for k in ("plain", "serial", "overlapped") + (("pipelined",) if T == 1 else ()):
         res[k] = min(res[k], res.pop(k + "2"))
+    if T == 1:
+        res["plain"] = min(res["plain"], res.pop("plain3"))
     res.pop("cold")
     same = bool(torch.equal(finals["serial"], finals["overlapped"]))
+    if T == 1:
+        same = same and bool(torch.equal(finals["serial"], finals["pipelined"]))
     cells = args.tile * args.tile
     out = {"tile": args.tile, "tuning": args.tune, "launches": args.steps, "time_steps_per_launch": T, "ms_per_launch": res,
            "mcells_per_s": {k: cells * T / v / 1e3 for k, v in res.items()},
            "overlapped_equals_serial_bitwise": same,
            "overlap_efficiency_vs_plain": res["plain"] / res["overlapped"]}
+    if T == 1:
+        out["pipelined_efficiency_vs_plain"] = res["plain"] / res["pipelined"]
     print(json.dumps(out, indent=1))
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)

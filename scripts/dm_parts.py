@@ -60,10 +60,27 @@ def dm(x, y):
     D._cabi.check(L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, xs, xe, ys, ye, sp))
 
 
+def dm_pipelined(x, y):
+    D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, xs, xe, ys, ye, sp))
+
+
+def exch_alone(x, y):
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_EDGES_ONLY, sp))
+
+
+def rccl_beside_interior(x, y):
+    # the exchange of x's halos on the side stream while the INTERIOR box streams: no frame work at all
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_EDGES_ONLY, C.c_void_p(side.cuda_stream)))
+    interior(x, y)
+
+
 with torch.cuda.stream(s):
     for name, fn in (("full box", full), ("interior box", interior), ("y-shifted box", shifted_y),
                      ("x-shifted box", shifted_x), ("exchange on side stream || full box", exch_then_full),
-                     ("overlapped dm step", dm), ("full box again", full)):
+                     ("exchange on side stream || interior box", rccl_beside_interior),
+                     ("exchange alone", exch_alone),
+                     ("overlapped dm step", dm), ("pipelined dm step", dm_pipelined), ("full box again", full),
+                     ("interior box again", interior)):
         x, y = a, b
         for _ in range(5):
             fn(x, y)
@@ -74,6 +91,8 @@ with torch.cuda.stream(s):
         for _ in range(steps):
             fn(x, y)
             x, y = y, x
+        if fn is dm_pipelined:
+            D._cabi.check(L.dlesm_halo_plan_join(plan, sp))
         e1.record(s)
         torch.cuda.synchronize()
         print(f"{name:40s} {e0.elapsed_time(e1) / steps:.4f} ms/step", flush=True)

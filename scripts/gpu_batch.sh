@@ -29,14 +29,14 @@ tests)
     tail -15 $OUT/gpu_tests.log ;;
 prof)
     rm -rf $OUT/prof_stats
-    step prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/prof_stats.log 2>&1
+    step prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 bench.py --no-cpu-baseline > $OUT/prof_stats.log 2>&1
     tail -2 $OUT/prof_stats.log
     python scripts/parse_rocprof.py stats $OUT/prof_stats $OUT/prof_stats_summary.md > /dev/null 2>&1 || echo "parse failed" ;;
 pmc)
     rm -rf $OUT/pmc_fetch $OUT/pmc_write
     [ -f profiles/traffic.json ] && cp profiles/traffic.json $OUT/traffic.json   # records are merged by key
-    step pmcF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow > $OUT/pmc_fetch.log 2>&1
-    step pmcW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow > $OUT/pmc_write.log 2>&1
+    step pmcF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile > $OUT/pmc_fetch.log 2>&1
+    step pmcW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile > $OUT/pmc_write.log 2>&1
     python scripts/parse_rocprof.py pmc $OUT/pmc_fetch $OUT/pmc_write "16384x16384/A64" $OUT/traffic.json jacobi5_ 20 2>&1 | tail -12 ;;   # the 20 timed launches (planned shape)
 pmcx)    # HBM traffic of the fused kernel, FUSED steps per launch (default 8)
     F=${FUSED:-8}
@@ -88,6 +88,15 @@ swcounters)   # occupancy / VALU / L2 counters of shallow_tile, one counter per 
     done
     python scripts/pmc_table.py $OUT/swcounters shallow_tile > $OUT/swcounters_table.txt 2>&1
     cat $OUT/swcounters_table.txt ;;
+pmcconfigs)   # fabric traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the other BASELINE Jacobi configurations
+    [ -f profiles/traffic.json ] && cp profiles/traffic.json $OUT/traffic.json
+    for cfg in "8192 64" "4096 64" "16384 1"; do
+        set -- $cfg
+        rm -rf $OUT/pmcc_fetch $OUT/pmcc_write
+        step pmccF$1 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcc_fetch -- python3 bench.py --tile $1 --alignment $2 --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile > $OUT/pmcc_fetch.log 2>&1
+        step pmccW$1 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcc_write -- python3 bench.py --tile $1 --alignment $2 --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile > $OUT/pmcc_write.log 2>&1
+        python scripts/parse_rocprof.py pmc $OUT/pmcc_fetch $OUT/pmcc_write "$1x$1/A$2" $OUT/traffic.json jacobi5_ 20 2>&1 | tail -4
+    done ;;
 dmprof)
     rm -rf $OUT/dm_prof
     step dmprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dm_prof -- python3 scripts/dm_overhead.py --tile ${DM_TILE:-16384} --steps 20 --out $OUT/dm_overhead_prof.json > $OUT/dm_prof.log 2>&1

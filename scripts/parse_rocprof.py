@@ -41,15 +41,17 @@ def stats(d, out):
         for r in trace:
             name = r.get("Kernel_Name", "?")
             dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-            by.setdefault(name, []).append((dur, r))
-        lines += ["", "## per-kernel durations from the dispatch trace (ns)", "",
-                  "| kernel | launches | mean | median | min | max | VGPR | LDS | grid | workgroup |", "|---|---|---|---|---|---|---|---|---|---|"]
-        for name, v in sorted(by.items(), key=lambda kv: -sum(x[0] for x in kv[1]))[:15]:
+            # one row per (kernel, launch geometry): a bench run launches the same kernel on several tile sizes
+            key = (name, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")))
+            by.setdefault(key, []).append((dur, r))
+        lines += ["", "## per-kernel durations from the dispatch trace (ns), one row per launch geometry", "",
+                  "| kernel | launches | mean | median | min | max | VGPR | LDS | grid (threads) | workgroup |", "|---|---|---|---|---|---|---|---|---|---|"]
+        for (name, gx, wx), v in sorted(by.items(), key=lambda kv: -sum(x[0] for x in kv[1]))[:24]:
             ds = [x[0] for x in v]
             r = v[0][1]
             lines.append(f"| {name[:80]} | {len(ds)} | {statistics.mean(ds):.0f} | {statistics.median(ds):.0f} | "
                          f"{min(ds):.0f} | {max(ds):.0f} | {r.get('VGPR_Count', '')} | {r.get('LDS_Block_Size', '')} | "
-                         f"{r.get('Grid_Size', '')} | {r.get('Workgroup_Size', '')} |")
+                         f"{gx} | {wx} |")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 

@@ -2,8 +2,9 @@
 backend, no GPU).  It drives the PRODUCT's host logic for its own rank -- parallel_init,
 grid_type%decompose, grid_init (-> map_comms through the C ABI) -- and then plays the
 reference's dist_mem tests (test_halos / test_gsum / test_reduction) with numpy arrays as the
-fields and gloo send/recv as a TEST-ONLY transport that follows the product's message tables
-(ordering rule of the RCCL path: per peer, ascending direction code).  What this checks is
+fields and gloo send/recv as a TEST-ONLY transport that follows the product's message tables and,
+like RCCL, uses NO tags: messages between a pair of ranks match purely by issue order (field-major,
+then per peer ascending direction code), so the ordering rule of dlesm_halo.hip is what is tested.  What this checks is
 everything about the N>1 path that is not the GPU itself: tile ownership, message tables,
 peer/ordering logic, scatter/gather index maps.
 
@@ -24,24 +25,46 @@ import torch.distributed as dist  # noqa: E402
 import ref_cases as R  # noqa: E402
 
 
-def exchange(field, tables, rank):
-    """halo exchange of a (ny, ld) numpy field over gloo, message order as in dlesm_halo.hip"""
-    sends = sorted(tables.sends(), key=lambda m: (m["dest"], m["dir"]))
-    recvs = sorted(tables.recvs(), key=lambda m: (m["src"], m["dir"]))
+DIRS_ALL, DIRS_NO_DIAGONALS = 0xF, 0x10
+
+
+def dir_enabled(mask, d):
+    """dlesm_halo.hip dir_enabled: edges by their bit, diagonals when both their edges are (unless
+    DIRS_NO_DIAGONALS), parallel_comms_mod.f90:1557-1571"""
+    on = lambda k: (mask >> (k - 1)) & 1                       # noqa: E731
+    if 1 <= d <= 4:
+        return bool(on(d))
+    if mask & DIRS_NO_DIAGONALS:
+        return False
+    return bool({5: on(1) and on(3), 6: on(2) and on(4), 7: on(1) and on(4), 8: on(2) and on(3)}.get(d, 0))
+
+
+def exchange_multi(fields, tables, rank, mask=DIRS_ALL):
+    """halo exchange of several (ny, ld) numpy fields over gloo, issued EXACTLY as exchange_on() of
+    dlesm_halo.hip issues its ncclSend/ncclRecv: no tags (every message carries tag 0, as RCCL has
+    none), field-major, and per field the receives then the sends, each list sorted by (peer,
+    direction code).  Between a pair of ranks the k-th send therefore has to meet the k-th receive:
+    the ordering rule itself is what this transport tests."""
+    sends = sorted((m for m in tables.sends() if dir_enabled(mask, m["dir"])), key=lambda m: (m["dest"], m["dir"]))
+    recvs = sorted((m for m in tables.recvs() if dir_enabled(mask, m["dir"])), key=lambda m: (m["src"], m["dir"]))
     reqs, bufs = [], []
-    for m in recvs:
-        buf = torch.empty(m["nx"] * m["ny"], dtype=torch.float64)
-        reqs.append(dist.irecv(buf, src=m["src"], tag=m["dir"]))
-        bufs.append((m, buf))
-    for m in sends:
-        patch = field[m["jsrc"] - 1:m["jsrc"] - 1 + m["ny"], m["isrc"] - 1:m["isrc"] - 1 + m["nx"]]
-        reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(patch).reshape(-1)), dst=m["dest"],
-                               tag=m["dir"]))
+    for k, field in enumerate(fields):
+        for m in recvs:
+            buf = torch.empty(m["nx"] * m["ny"], dtype=torch.float64)
+            reqs.append(dist.irecv(buf, src=m["src"], tag=0))
+            bufs.append((k, m, buf))
+        for m in sends:
+            patch = field[m["jsrc"] - 1:m["jsrc"] - 1 + m["ny"], m["isrc"] - 1:m["isrc"] - 1 + m["nx"]]
+            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(patch).reshape(-1)), dst=m["dest"], tag=0))
     for q in reqs:
         q.wait()
-    for m, buf in bufs:
-        field[m["jdes"] - 1:m["jdes"] - 1 + m["ny"], m["ides"] - 1:m["ides"] - 1 + m["nx"]] = \
+    for k, m, buf in bufs:
+        fields[k][m["jdes"] - 1:m["jdes"] - 1 + m["ny"], m["ides"] - 1:m["ides"] - 1 + m["nx"]] = \
             buf.numpy().reshape(m["ny"], m["nx"])
+
+
+def exchange(field, tables, rank, mask=DIRS_ALL):
+    exchange_multi([field], tables, rank, mask)
 
 
 def deep_halo_suite(D, nx, ny, depth, rank, world):
@@ -142,6 +165,36 @@ def main():
         if not np.array_equal(f[ys - 1:ye, xs - 1:xe], before[ys - 1:ye, xs - 1:xe]):
             print(f"rank {rank}: ERROR internal cells modified", flush=True)
             errors += 1
+    # ---- three fields in ONE grouped exchange (what dlesm_shallow_step_dm issues), tag-free ------------
+    fields, befores = [], []
+    for k, ptype in enumerate((R.GO_U, R.GO_V, R.GO_T)):
+        internal, _ = D.field_mod.field_bounds(g, ptype)
+        f = R.init_field_hill(ptype, g.nx, g.ny, internal.box(), sub.glob.xstart, sub.glob.ystart)
+        f *= (k + 1)                                           # a mixed-up field order would show
+        fields.append(f)
+    exchange_multi(fields, t, rank)
+    for k, ptype in enumerate((R.GO_U, R.GO_V, R.GO_T)):
+        internal, _ = D.field_mod.field_bounds(g, ptype)
+        bad = R.check_hill_halos(fields[k] / (k + 1), ptype, internal.box(), sub.glob.box(), nx, ny, corners=True)
+        if bad:
+            print(f"rank {rank}: ERROR grouped exchange, field {k}: {bad[:3]}", flush=True)
+            errors += 1
+    # ---- edges only (what dlesm_jacobi5_step_dm exchanges): corner halos stay untouched ----------------
+    internal, _ = D.field_mod.field_bounds(g, R.GO_T)
+    it = internal.box()
+    f = R.init_field_hill(R.GO_T, g.nx, g.ny, it, sub.glob.xstart, sub.glob.ystart)
+    xs, xe, ys, ye = it
+    corners = [(ys - 2, xs - 2), (ys - 2, xe), (ye, xs - 2), (ye, xe)]
+    for (j, i) in corners:
+        f[j, i] = -123.0
+    exchange(f, t, rank, DIRS_ALL | DIRS_NO_DIAGONALS)
+    if any(f[j, i] != -123.0 for (j, i) in corners):
+        print(f"rank {rank}: ERROR edges-only exchange touched a corner halo", flush=True)
+        errors += 1
+    bad = R.check_hill_halos(f, R.GO_T, it, sub.glob.box(), nx, ny, corners=False)
+    if bad:
+        print(f"rank {rank}: ERROR edges-only exchange: {bad[:3]}", flush=True)
+        errors += 1
     # ---- test_gsum: checksum of ones == jpiglo*jpjglo --------------------------------
     internal, _ = D.field_mod.field_bounds(g, R.GO_T)
     f = R.gsum_field(g.nx, g.ny, internal.box())

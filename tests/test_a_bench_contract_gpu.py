@@ -39,8 +39,16 @@ def test_bench_line_and_secondary_legs():
     assert d["cpu_baseline"]["fortran_psy_loops_value"] > 0, d["cpu_baseline"]
     sw = d["shallow_water"]
     assert "error" not in sw and sw["value"] > 0 and sw["roofline"]["algorithmic_bytes_per_cell"] == 72, sw
+    assert sw["cpu_baseline"]["gpu_first_step_equals_oracle_on_slab"] is True and sw["cpu_baseline"]["cores"] == 1, sw
     tb = d["temporal_blocking"]
     assert tb["fused_steps"] == 8 and tb["bit_identical_to_single_steps"] is True and tb["value"] > 0
+    assert tb["steps"] >= 24 * 8                       # secondary legs time >= 24 launches whatever --steps is
+    w = d["weak_scaling_tile"]
+    assert w["tile"] == 8192 and w["n_gpus"] == 1 and w["value"] > 0 and w["steps"] >= 24, w
+    cfgs = {(c["tile"], c["DL_ESM_ALIGNMENT"]): c for c in d["configs"]}
+    assert set(cfgs) == {(4096, 64), (16384, 1), (4096, 1)} and all("error" not in c for c in cfgs.values()), cfgs
+    assert "configs[1]" in cfgs[(4096, 64)]["workload"] and "configs[2]" in cfgs[(16384, 1)]["workload"]
+    assert "traffic_source" in d["roofline"] and "secondary_legs_error" not in d
     f = _bench("--fused", "4", "--no-cpu-baseline")
     assert f["config"]["fused_steps_per_launch"] == 4 and f["value"] > 0
 
@@ -50,3 +58,5 @@ def test_rehearsal_of_the_multi_gpu_secondary_leg():
     tb = d["temporal_blocking"]
     assert "error" not in tb, tb
     assert tb["halo_depth"] == 8 and tb["bit_identical_to_single_steps_plus_exchange"] is True
+    w = d["weak_scaling_tile"]                          # the 8192^2 object every N > 1 line carries
+    assert w["tile"] == 8192 and w["value"] > 0 and "secondary_legs_error" not in d, d

@@ -516,6 +516,56 @@ def test_distributed_step_variants(D, corners, frame_pack):
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
+@pytest.mark.parametrize("nx,ny,alignment,nsteps", [(300, 41, 64, 7), (64, 64, 2, 12), (1500, 700, 64, 9), (130, 5, 2, 4)])
+@pytest.mark.parametrize("chain", [1, 0])
+def test_pipelined_distributed_steps(D, nx, ny, alignment, nsteps, chain):
+    """dlesm_jacobi5_step_dm_pipelined: a time loop of steps that never joins the exchange on the
+    caller's stream -- each step's frame workgroups wait on the device for the previous exchange --
+    then ONE dlesm_halo_plan_join.  Every bit of the result (halos included) against the oracle's
+    nsteps x (stencil + edge exchange); j5_dm_chain=0 is the same API with the event join inside."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dm_overhead import loopback_tables
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    _set_tuning(D, j5_dm_chain=chain)
+    g = _grid(D, nx, ny, alignment)
+    x, y = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = x.internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    D.psy.hash_init(x, SEED + 13)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+    D.copy_field(x, y)
+    torch.cuda.synchronize()
+    hx, hy = x.get_data(), y.get_data()
+    s = torch.cuda.Stream()
+    sp = C.c_void_p(s.cuda_stream)
+    a, b = x, y
+    for _ in range(nsteps):
+        D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), sp))
+        a, b = b, a
+        O.jacobi5(hx, hy, g.nx, *it.box())
+        assert O.exchange_dirs([hy], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+        hx, hy = hy, hx
+    D._cabi.check(L.dlesm_halo_plan_join(plan, sp))
+    s.synchronize()
+    assert np.array_equal(a.get_data(), hx)
+    # a plain exchange after a pipelined step joins by itself
+    D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), sp))
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, b.device_ptr, D._cabi.DIRS_ALL, sp))
+    s.synchronize()
+    O.jacobi5(hx, hy, g.nx, *it.box())
+    assert O.exchange_all([hy], [g.nx], [oc]) == 0
+    assert np.array_equal(b.get_data(), hy)
+    _set_tuning(D, j5_dm_chain=1)
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
 # --------------------------------------------------------------------------- grid properties (f.4)
 @pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (64, 48, 8), (300, 70, 64), (257, 129, None), (1, 1, 2),
                                              (129, 3, 2), (1000, 37, 64), (4100, 9, 64)])
