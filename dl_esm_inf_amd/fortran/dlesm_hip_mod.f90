@@ -303,6 +303,18 @@ module dlesm_hip_mod
        integer(c_int), value :: exstart, exstop, eystart, eystop, grow_w, grow_e, grow_s, grow_n
        integer(c_int) :: rc
      end function
+     function dlesm_jacobi5_step_dm_pipelined(plan, in, out, ld, ny, xstart, xstop, ystart, ystop, stream) &
+          bind(C, name="dlesm_jacobi5_step_dm_pipelined") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: plan, in, out, stream
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       integer(c_int) :: rc
+     end function
+     function dlesm_halo_plan_join(plan, stream) bind(C, name="dlesm_halo_plan_join") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: plan, stream
+       integer(c_int) :: rc
+     end function
      function dlesm_jacobi5_multi_step_dm(plan, in, out, ld, ny, nsteps, xstart, xstop, ystart, ystop, &
           stream) bind(C, name="dlesm_jacobi5_multi_step_dm") result(rc)
        import :: c_int, c_ptr

@@ -47,7 +47,7 @@ module dlesm_psy_mod
   implicit none
   private
 
-  public :: invoke_jacobi5_masked
+  public :: invoke_jacobi5_masked, invoke_jacobi5_dm_pipelined, halo_join
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
   public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5, plan_shallow_step
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
@@ -130,6 +130,37 @@ contains
                                int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_jacobi5_dm: ' // dlesm_error_text())
   end subroutine invoke_jacobi5_dm
+
+  !> The same step for a time loop of such steps: returns with the exchange of `out` in flight;
+  !! the next invoke_jacobi5_dm_pipelined on this grid waits for it on the device, any other library
+  !! call on the grid's plan joins it first, and halo_join(grid) orders everything else behind it.
+  subroutine invoke_jacobi5_dm_pipelined(out, in)
+    use parallel_comms_mod, only: halo_plan_for
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(r2d_field), intent(inout), target :: out, in
+    integer(c_int) :: rc
+    if (.not. DIST_MEM_ENABLED) then
+       call invoke_jacobi5(out, in)
+       return
+    end if
+    call need_device(in);  call need_device(out)
+    rc = dlesm_jacobi5_step_dm_pipelined(halo_plan_for(out%grid%nx, out%grid%ny), field_device_data(in), &
+                                         field_device_data(out), int(out%grid%nx, c_int), &
+                                         int(out%grid%ny, c_int), int(out%internal%xstart, c_int), &
+                                         int(out%internal%xstop, c_int), int(out%internal%ystart, c_int), &
+                                         int(out%internal%ystop, c_int), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_jacobi5_dm_pipelined: ' // dlesm_error_text())
+  end subroutine invoke_jacobi5_dm_pipelined
+
+  subroutine halo_join(grid)
+    use parallel_comms_mod, only: halo_plan_for
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(grid_type), intent(in) :: grid
+    integer(c_int) :: rc
+    if (.not. DIST_MEM_ENABLED) return
+    rc = dlesm_halo_plan_join(halo_plan_for(grid%nx, grid%ny), c_null_ptr)
+    if (rc /= 0) call gocean_stop('halo_join: ' // dlesm_error_text())
+  end subroutine halo_join
 
   !> nsteps (2..8) Jacobi time steps in one sweep (temporal blocking).  Serial / one tile: the
   !! boundary ring of `in` stays fixed through all steps.  Distributed (grid decomposed with
