@@ -174,6 +174,22 @@ module dlesm_hip_mod
        type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
        integer(c_int) :: rc
      end function
+     function dlesm_shallow_step_sw_f64(params, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
+          uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_step_sw_f64") result(rc)
+       import :: c_int, c_ptr, c_sw_params
+       type(c_sw_params), intent(in) :: params
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_periodic_halos_apply_f64(field, ld, ny, internal, bc_x, bc_y, stream) &
+          bind(C, name="dlesm_periodic_halos_apply_f64") result(rc)
+       import :: c_int, c_ptr, c_region
+       type(c_ptr), value :: field, stream
+       integer(c_int), value :: ld, ny, bc_x, bc_y
+       type(c_region), intent(in) :: internal
+       integer(c_int) :: rc
+     end function
      function dlesm_shallow_autotune_f64(params, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
           uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_autotune_f64") result(rc)
        import :: c_int, c_ptr, c_sw_params

@@ -48,6 +48,7 @@ module dlesm_psy_mod
   private
 
   public :: invoke_jacobi5_masked, invoke_jacobi5_dm_pipelined, halo_join
+  public :: invoke_shallow_step_sw, invoke_periodic_halos
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
   public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5, plan_shallow_step
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
@@ -221,6 +222,43 @@ contains
     if (rc /= 0) call gocean_stop('invoke_shallow_step: ' // dlesm_error_text())
   end subroutine invoke_shallow_step
 
+  !> The SW-offset form (the staggering of the GOcean `shallow` benchmark; with periodic boundaries the
+  !! only configuration the reference supports for it, serially).  u, v, p must hold valid periodic
+  !! halos; follow it with invoke_periodic_halos on the three new fields.
+  subroutine invoke_shallow_step_sw(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)
+    type(c_sw_params), intent(in) :: prm
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    rc = dlesm_shallow_step_sw_f64(prm, int(p%grid%nx, c_int), int(p%grid%ny, c_int), &
+                                   int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                                   int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                                   field_device_data(u), field_device_data(v), field_device_data(p), &
+                                   field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                   field_device_data(unew), field_device_data(vnew), field_device_data(pnew), &
+                                   c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_sw: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_sw
+
+  !> The periodic-boundary copies of a field -- its halo(:) list (field_mod.f90:1394-1464), in order --
+  !! on the device: what a periodic model's PSy layer does after every kernel that writes the field.
+  subroutine invoke_periodic_halos(fld)
+    type(r2d_field), intent(inout), target :: fld
+    type(c_region) :: cint
+    integer(c_int) :: rc
+    if (fld%num_halos == 0) return
+    call need_device(fld)
+    associate (it => fld%internal)
+      cint = c_region(it%nx, it%ny, it%xstart, it%xstop, it%ystart, it%ystop)
+    end associate
+    rc = dlesm_periodic_halos_apply_f64(field_device_data(fld), int(fld%grid%nx, c_int), int(fld%grid%ny, c_int), &
+                                        cint, int(fld%grid%boundary_conditions(1), c_int), &
+                                        int(fld%grid%boundary_conditions(2), c_int), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_periodic_halos: ' // dlesm_error_text())
+  end subroutine invoke_periodic_halos
+
   !> Optional planning call for invoke_shallow_step (like plan_jacobi5): the library times its
   !! launch shapes and cache policies on these fields once -- every trial is the same valid step
   !! into unew, vnew, pnew -- and keeps the fastest for this field geometry.
@@ -326,17 +364,25 @@ contains
   end subroutine invoke_copy
 
   !> Synthetic initial condition: a hash of the GLOBAL cell index on the field's whole region
-  subroutine invoke_hash_init(fld, seed)
+  subroutine invoke_hash_init(fld, seed, internal_only)
     type(r2d_field), intent(inout), target :: fld
     integer(c_int64_t), intent(in) :: seed
+    logical, intent(in), optional :: internal_only    !< fill the internal region only (default: whole)
     integer(c_int) :: rc
+    integer :: bx0, bx1, by0, by1
     integer(c_int64_t) :: gx0, gy0
     call need_device(fld)
     gx0 = fld%grid%subdomain%global%xstart - fld%grid%subdomain%internal%xstart + 1
     gy0 = fld%grid%subdomain%global%ystart - fld%grid%subdomain%internal%ystart + 1
+    bx0 = fld%whole%xstart;  bx1 = fld%whole%xstop;  by0 = fld%whole%ystart;  by1 = fld%whole%ystop
+    if (present(internal_only)) then
+       if (internal_only) then
+          bx0 = fld%internal%xstart;  bx1 = fld%internal%xstop
+          by0 = fld%internal%ystart;  by1 = fld%internal%ystop
+       end if
+    end if
     rc = dlesm_hash_init_f64(field_device_data(fld), int(fld%grid%nx, c_int), int(fld%grid%ny, c_int), &
-                             int(fld%whole%xstart, c_int), int(fld%whole%xstop, c_int), &
-                             int(fld%whole%ystart, c_int), int(fld%whole%ystop, c_int), seed, gx0, gy0, &
+                             int(bx0, c_int), int(bx1, c_int), int(by0, c_int), int(by1, c_int), seed, gx0, gy0, &
                              c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_hash_init: ' // dlesm_error_text())
   end subroutine invoke_hash_init

@@ -1,0 +1,80 @@
+!> A GOcean-style shallow-water model on the dl_esm_inf API, in the configuration of the public
+!! GOcean `shallow` benchmark: Arakawa C grid, SW offset, periodic in x and y (the only periodic
+!! configuration the reference supports, serially: field_mod.f90:675-751, grid_mod.f90:437-442).
+!! Algorithm layer = the usual sequence -- build grid and fields, initialise, time loop of
+!! [u/v/h update; periodic boundary copies of the new fields; leapfrog rotation], checksums --
+!! PSy layer = the launch wrappers of dlesm_psy_mod (invoke_shallow_step_sw, invoke_periodic_halos)
+!! instead of loop nests over compute_*_code.
+!!     shallow_app.exe N NSTEPS
+program shallow_app
+  use iso_c_binding
+  use kind_params_mod
+  use parallel_mod
+  use grid_mod
+  use field_mod
+  use gocean_mod
+  use dlesm_psy_mod
+  implicit none
+  character(len=32) :: arg
+  integer :: n, nsteps, step, k, rate, t0, t1
+  type(grid_type), target :: model_grid
+  type(r2d_field), target :: f(9)          ! u v p | uold vold pold | unew vnew pnew
+  integer :: ptype(9), cur(3), old(3), new(3), tmp(3)
+  real(go_wp), pointer :: d(:,:)
+  real(go_wp) :: secs
+
+  n = 256;  nsteps = 10
+  if (command_argument_count() >= 1) then
+     call get_command_argument(1, arg); read(arg, *) n
+  end if
+  if (command_argument_count() >= 2) then
+     call get_command_argument(2, arg); read(arg, *) nsteps
+  end if
+  call gocean_initialise()
+  model_grid = grid_type(GO_ARAKAWA_C, (/GO_BC_PERIODIC, GO_BC_PERIODIC, GO_BC_NONE/), GO_OFFSET_SW)
+  call model_grid%decompose(n, n)
+  call grid_init(model_grid, 1.0e5_go_wp, 1.0e5_go_wp)
+  ptype = (/ GO_U_POINTS, GO_V_POINTS, GO_T_POINTS, GO_U_POINTS, GO_V_POINTS, GO_T_POINTS, &
+             GO_U_POINTS, GO_V_POINTS, GO_T_POINTS /)
+  do k = 1, 9
+     f(k) = r2d_field(model_grid, ptype(k))
+  end do
+  ! initial state: counter hash on the internal region (u, v in [-0.5,0.5), p in [1,2)), periodic halos,
+  ! old and new levels start as copies
+  do k = 1, 3
+     call invoke_hash_init(f(k), int(100 + k, c_int64_t), internal_only=.true.)
+     d => f(k)%get_data()
+     if (k == 3) then
+        d = d + 1.0_go_wp
+     else
+        d = d - 0.5_go_wp
+     end if
+     call f(k)%write_to_device()
+     call invoke_periodic_halos(f(k))
+     call invoke_copy(f(k + 3), f(k))
+     call invoke_copy(f(k + 6), f(k))
+  end do
+  cur = (/1, 2, 3/);  old = (/4, 5, 6/);  new = (/7, 8, 9/)
+  call device_sync()
+  call system_clock(t0, rate)
+  do step = 1, nsteps
+     call invoke_shallow_step_sw(shallow_params(1.0e5_go_wp, 1.0e5_go_wp, 90.0_go_wp), &
+                                 f(cur(1)), f(cur(2)), f(cur(3)), f(old(1)), f(old(2)), f(old(3)), &
+                                 f(new(1)), f(new(2)), f(new(3)))
+     do k = 1, 3
+        call invoke_periodic_halos(f(new(k)))
+     end do
+     tmp = old;  old = cur;  cur = new;  new = tmp        ! leapfrog rotation
+  end do
+  call device_sync()
+  call system_clock(t1)
+  secs = real(t1 - t0, go_wp) / real(rate, go_wp)
+  write(*, '("G: shape ",3(I0,1x))') model_grid%nx, model_grid%ny, nsteps
+  do k = 1, 3
+     d => f(cur(k))%get_data()
+     write(*, '("G: cs ",I0,1x,3(ES24.16E3,1x))') k, field_checksum(f(cur(k))), d(2, 2), d(n + 1, n + 1)
+  end do
+  write(*, '("shallow_app: ",I0,"^2, ",I0," steps, ",F10.1," Mcells/s")') n, nsteps, &
+       real(n, go_wp) * real(n, go_wp) * nsteps / secs / 1.0e6_go_wp
+  call gocean_finalise()
+end program shallow_app
