@@ -295,6 +295,63 @@ def shallow_water(D, torch, stream, alignment, tile=8192, steps=40, cpu_seconds=
                                "gpu_first_step_equals_oracle_on_slab": bool(same)}
     del F, cur, old, new
     torch.cuda.empty_cache()
+    try:
+        out["sw_offset_periodic"] = shallow_water_periodic(D, torch, stream, alignment, tile, steps)
+    except Exception as e:                                   # noqa: BLE001
+        out["sw_offset_periodic"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def shallow_water_periodic(D, torch, stream, alignment, tile, steps):
+    """The same update in the configuration of the GOcean `shallow` benchmark: SW offset, periodic in
+    x and y (serial only in the reference).  A step = dlesm_shallow_step_sw_f64 + the periodic copies
+    of the three new fields (two launches) + leapfrog rotation."""
+    os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_PERIODIC, D.GO_BC_PERIODIC, D.GO_BC_NONE), D.GO_OFFSET_SW)
+    g.decompose(tile, tile)
+    D.grid_init(g, 1.0, 1.0)
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    F = {}
+    with torch.cuda.stream(stream):
+        for k, name in enumerate(["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]):
+            F[name] = D.r2d_field(g, pts[name[0]])
+            D.psy.hash_init(F[name], SEED + k, box=F[name].internal, stream=stream)
+            F[name].data.add_(1.0 if name[0] == "p" else -0.5)
+            D.psy.apply_periodic_halos(F[name], stream=stream)
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
+    cur, old, new = [F["u"], F["v"], F["p"]], [F["uold"], F["vold"], F["pold"]], [F["unew"], F["vnew"], F["pnew"]]
+    # leapfrog: S(p) of the even and of the odd time levels are conserved separately
+    p0 = [float(F[n].data[1:tile + 1, 1:tile + 1].sum().item()) for n in ("p", "pold")]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def step():
+        nonlocal cur, old, new
+        D.psy.invoke_shallow_step_sw(prm, *cur, *old, *new, stream=stream)
+        D.psy.apply_periodic_halos_multi(new, stream=stream)
+        old, cur, new = cur, new, old
+
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            step()
+        e0.record(stream)
+        for _ in range(steps):
+            step()
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    cells, bpc = tile * tile, 72
+    gbs = bpc * cells / (ms * 1e-3) / 1e9
+    p1 = float(cur[2].data[1:tile + 1, 1:tile + 1].sum().item())
+    out = {"workload": f"shallow-water u/v/h step + periodic halo copies, {tile}x{tile} fp64, SW offset, periodic in x and y "
+                       "(the GOcean `shallow` configuration)", "steps": steps,
+           "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_cell": bpc,
+                        "kernel": "shallow_tile_sw<2,dpp,nt> + 2 x periodic_pair_k"},
+           # pnew - pold is a discrete divergence: on the torus SUM(p) is conserved up to rounding
+           "mass_drift_relative": abs(p1 - p0[(5 + steps) % 2]) / abs(p0[(5 + steps) % 2])}
+    del F, cur, old, new
+    torch.cuda.empty_cache()
     return out
 
 

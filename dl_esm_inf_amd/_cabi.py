@@ -116,6 +116,7 @@ PROTOTYPES = {
     "dlesm_shallow_autotune_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_periodic_halos": (_i, [C.POINTER(Region), _i, _i, C.POINTER(Region), C.POINTER(Region), C.POINTER(_i)]),
     "dlesm_periodic_halos_apply_f64": (_i, [_vp, _i, _i, C.POINTER(Region), _i, _i, _vp]),
+    "dlesm_periodic_halos_apply_multi_f64": (_i, [C.POINTER(_vp), _i, _i, _i, C.POINTER(Region), _i, _i, _vp]),
     "dlesm_shallow_step_sw_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_copy_patch_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_fill_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, _d, _vp]),

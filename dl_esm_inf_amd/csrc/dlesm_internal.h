@@ -116,7 +116,7 @@ int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart
 void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,
                          const double *u, const double *v, const double *p, const double *uold,
                          const double *vold, const double *pold, double *unew, double *vnew,
-                         double *pnew, hipStream_t s);
+                         double *pnew, hipStream_t s, bool sw_offset = false);
 
 } // namespace dlesm
 

@@ -169,6 +169,127 @@ __global__ __launch_bounds__(512) void shallow_tile(
     }
 }
 
+
+// The SW-offset step in the same wave-tile form: the mirror image of
+// shallow_tile -- cu, cv, z look WEST/SOUTH, h looks EAST/NORTH -- with its own expression trees
+// (the four-term sums associate differently from the mirrored NE ones, so this is not the NE
+// kernel run backwards).  Row index k = row jb-1+k, as above.
+template <int R, bool DPP, int NTM>
+__global__ __launch_bounds__(512) void shallow_tile_sw(
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
+    const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
+    const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
+    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew)
+{
+    auto east = [](const V2 &a) { return east_of<DPP>(a); };
+    auto west = [](const V2 &a) { return west_of<DPP>(a); };
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int xw = w % nxw, strip = w / nxw;
+    const int jb = y0 + strip * R;
+    if (jb > y1) return;
+    int je = jb + R - 1;
+    if (je > y1) je = y1;
+    const int c = cb + xw * 62 - 1 + lane;             // this lane's chunk (2 columns)
+    if (c - lane + 1 > x1 / 2) return;                 // idle padding tile
+    const int c_ld = ld / 2 - 1;
+    const int cl = c < 0 ? 0 : (c > c_ld ? c_ld : c);  // halo / trailing lanes: any valid chunk
+    const bool out_lane = lane >= 1 && lane <= 62 && c <= c_ld;
+    const bool m0 = out_lane && 2 * c >= x0 && 2 * c <= x1;
+    const bool m1 = out_lane && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
+
+    const size_t col = (size_t)cl * 2;
+    V2 U[R + 2], Vv[R + 2], P[R + 2], UO[R], VO[R], PO[R];
+#pragma unroll
+    for (int k = 0; k < R + 2; k++) {
+        int jj = jb - 1 + k;
+        if (jj > je + 1) jj = je + 1;
+        const size_t o = (size_t)jj * ld + col;
+        U[k] = ld2(u + o);
+        Vv[k] = ld2(v + o);
+        P[k] = ld2(p + o);
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        int jj = jb + k;
+        if (jj > je) jj = je;
+        const size_t o = (size_t)jj * ld + col;
+        UO[k] = ld2<(NTM & 1) != 0>(uold + o);
+        VO[k] = ld2<(NTM & 1) != 0>(vold + o);
+        PO[k] = ld2<(NTM & 1) != 0>(pold + o);
+    }
+
+    // raw neighbours
+    V2 Pw[R + 2], Vw[R + 2], Ue[R + 1];
+#pragma unroll
+    for (int k = 0; k < R + 2; k++) Pw[k] = west(P[k]);
+#pragma unroll
+    for (int k = 1; k < R + 2; k++) Vw[k] = west(Vv[k]);
+#pragma unroll
+    for (int k = 0; k < R + 1; k++) Ue[k] = east(U[k]);
+
+    // intermediates at the lane's own columns
+    V2 CU[R + 1], H[R + 1], CV[R + 2], Z[R + 2];
+#pragma unroll
+    for (int k = 0; k < R + 1; k++) {   // rows jb-1 .. je: cu(i,j) = 0.5*(p(i,j)+p(i-1,j))*u(i,j); h looks east/north
+        CU[k] = EW(0.5 * (P[k].x + Pw[k].x) * U[k].x, 0.5 * (P[k].y + Pw[k].y) * U[k].y);
+        H[k] = EW(P[k].x + 0.25 * (Ue[k].x * Ue[k].x + U[k].x * U[k].x + Vv[k + 1].x * Vv[k + 1].x +
+                                   Vv[k].x * Vv[k].x),
+                  P[k].y + 0.25 * (Ue[k].y * Ue[k].y + U[k].y * U[k].y + Vv[k + 1].y * Vv[k + 1].y +
+                                   Vv[k].y * Vv[k].y));
+    }
+#pragma unroll
+    for (int k = 1; k < R + 2; k++) {   // rows jb .. je+1: cv and z look south
+        CV[k] = EW(0.5 * (P[k].x + P[k - 1].x) * Vv[k].x, 0.5 * (P[k].y + P[k - 1].y) * Vv[k].y);
+        Z[k] = EW((q.fsdx * (Vv[k].x - Vw[k].x) - q.fsdy * (U[k].x - U[k - 1].x)) /
+                      (Pw[k - 1].x + P[k - 1].x + P[k].x + Pw[k].x),
+                  (q.fsdx * (Vv[k].y - Vw[k].y) - q.fsdy * (U[k].y - U[k - 1].y)) /
+                      (Pw[k - 1].y + P[k - 1].y + P[k].y + Pw[k].y));
+    }
+    // derived neighbours
+    V2 CUe[R + 1], Ze[R + 1], CVw[R + 2], Hw[R + 1];
+#pragma unroll
+    for (int k = 0; k < R + 1; k++) CUe[k] = east(CU[k]);
+#pragma unroll
+    for (int k = 1; k < R + 1; k++) Ze[k] = east(Z[k]);
+#pragma unroll
+    for (int k = 1; k < R + 2; k++) CVw[k] = west(CV[k]);
+#pragma unroll
+    for (int k = 1; k < R + 1; k++) Hw[k] = west(H[k]);
+
+#pragma unroll
+    for (int k = 1; k <= R; k++) {
+        const int jj = jb - 1 + k;
+        if (jj > je) break;
+        // unew = uold + tdts8*(z(i,j+1)+z(i,j))*(cv(i,j+1)+cv(i-1,j+1)+cv(i-1,j)+cv(i,j)) - tdtsdx*(h(i,j)-h(i-1,j))
+        const V2 un = EW(UO[k - 1].x + q.tdts8 * (Z[k + 1].x + Z[k].x) *
+                                           (CV[k + 1].x + CVw[k + 1].x + CVw[k].x + CV[k].x) -
+                             q.tdtsdx * (H[k].x - Hw[k].x),
+                         UO[k - 1].y + q.tdts8 * (Z[k + 1].y + Z[k].y) *
+                                           (CV[k + 1].y + CVw[k + 1].y + CVw[k].y + CV[k].y) -
+                             q.tdtsdx * (H[k].y - Hw[k].y));
+        // vnew = vold - tdts8*(z(i+1,j)+z(i,j))*(cu(i+1,j)+cu(i,j)+cu(i,j-1)+cu(i+1,j-1)) - tdtsdy*(h(i,j)-h(i,j-1))
+        const V2 vn = EW(VO[k - 1].x - q.tdts8 * (Ze[k].x + Z[k].x) *
+                                           (CUe[k].x + CU[k].x + CU[k - 1].x + CUe[k - 1].x) -
+                             q.tdtsdy * (H[k].x - H[k - 1].x),
+                         VO[k - 1].y - q.tdts8 * (Ze[k].y + Z[k].y) *
+                                           (CUe[k].y + CU[k].y + CU[k - 1].y + CUe[k - 1].y) -
+                             q.tdtsdy * (H[k].y - H[k - 1].y));
+        // pnew = pold - tdtsdx*(cu(i+1,j)-cu(i,j)) - tdtsdy*(cv(i,j+1)-cv(i,j))
+        const V2 pn = EW(PO[k - 1].x - q.tdtsdx * (CUe[k].x - CU[k].x) - q.tdtsdy * (CV[k + 1].x - CV[k].x),
+                         PO[k - 1].y - q.tdtsdx * (CUe[k].y - CU[k].y) - q.tdtsdy * (CV[k + 1].y - CV[k].y));
+        const size_t o = (size_t)jj * ld + (size_t)c * 2;
+        if (m0 && m1) {
+            st2<(NTM & 2) != 0>(unew + o, un);
+            st2<(NTM & 2) != 0>(vnew + o, vn);
+            st2<(NTM & 2) != 0>(pnew + o, pn);
+        } else {
+            if (m0) { unew[o] = un.x; vnew[o] = vn.x; pnew[o] = pn.x; }
+            if (m1) { unew[o + 1] = un.y; vnew[o + 1] = vn.y; pnew[o + 1] = pn.y; }
+        }
+    }
+}
+
 } // namespace
 
 // Measured launch shapes (dlesm_shallow_autotune_f64), as for the Jacobi sweep: every shape and
@@ -216,7 +337,7 @@ static void sw_rule_shape(int ld, int x0, int x1, int *nxw_out, int *tpb_out)
 void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,
                          const double *u, const double *v, const double *p, const double *uold,
                          const double *vold, const double *pold, double *unew, double *vnew,
-                         double *pnew, hipStream_t s)
+                         double *pnew, hipStream_t s, bool sw_offset)
 {
     const int cb = x0 / 2;                               // first chunk holding an output column
     int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & 3;
@@ -235,8 +356,14 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     const unsigned grid = (unsigned)((tiles + tpb - 1) / tpb);
     const bool dpp = tuning("sw_dpp", 1);
 #define DLESM_SW3(RR, DD, NN)                                                                                  \
-    hipLaunchKernelGGL((shallow_tile<RR, DD, NN>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, \
-                       nxw, u, v, p, uold, vold, pold, unew, vnew, pnew)
+    do {                                                                                                       \
+        if (sw_offset)                                                                                         \
+            hipLaunchKernelGGL((shallow_tile_sw<RR, DD, NN>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
+                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew);                      \
+        else                                                                                                   \
+            hipLaunchKernelGGL((shallow_tile<RR, DD, NN>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
+                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew);                      \
+    } while (0)
 #define DLESM_SW2(RR, DD)                                                                                      \
     do {                                                                                                       \
         switch (ntm) {                                                                                         \
@@ -318,6 +445,17 @@ extern "C" int dlesm_shallow_step_sw_f64(const dlesm_sw_params *q, int ld, int n
                       pnew != u && pnew != v && pnew != p,
                   "shallow step: outputs alias the 3x3-read inputs");
     const int nx = xstop - xstart + 1, h = ystop - ystart + 1;
+    // 16-byte lanes under the same conditions as the NE step (dlesm_shallow_step_f64)
+    bool aligned = ld % 2 == 0 || (xstop - 1) + 1 <= 2 * (ld / 2) - 1;
+    for (const double *f : {u, v, p, uold, vold, pold, (const double *)unew, (const double *)vnew,
+                            (const double *)pnew})
+        aligned = aligned && ((uintptr_t)f % 16 == 0);
+    if (aligned && tuning("sw_kernel", 0) == 0) {
+        launch_shallow_tile(*q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold, unew,
+                            vnew, pnew, (hipStream_t)stream, true);
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
     hipLaunchKernelGGL(shallow_step_sw_direct, dim3((nx + 255) / 256, h > 4096 ? 4096 : h), dim3(256), 0,
                        (hipStream_t)stream, *q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold,
                        pold, unew, vnew, pnew);
@@ -325,18 +463,65 @@ extern "C" int dlesm_shallow_step_sw_f64(const dlesm_sw_params *q, int ld, int n
     return DLESM_OK;
 }
 
-extern "C" int dlesm_periodic_halos_apply_f64(double *field, int ld, int ny, const dlesm_region *internal,
-                                              int bc_x, int bc_y, void *stream)
+// Up to 16 fields x 2 independent patch copies in one launch: grid.y = field * 2 + copy.
+struct HaloPair { int sx[2], sy[2], dx[2], dy[2], nx[2], ny[2]; };
+struct FieldList { double *f[16]; };
+__global__ void periodic_pair_k(FieldList fl, int ld, HaloPair h)
 {
-    DLESM_REQUIRE(field != nullptr && internal != nullptr, "null pointer");
+    double *f = fl.f[blockIdx.y >> 1];
+    const int c = blockIdx.y & 1;
+    const long n = (long)h.nx[c] * h.ny[c];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(t / h.nx[c]), i = (int)(t % h.nx[c]);
+        f[(size_t)(h.dy[c] + j) * ld + h.dx[c] + i] = f[(size_t)(h.sy[c] + j) * ld + h.sx[c] + i];
+    }
+}
+
+// The periodic copies of `nfields` fields of one shape: the x pair of every field in one launch, then
+// the y pair of every field in a second one (the y copies carry the corners the x copies made, so
+// the two phases stay ordered; the two copies of a phase never overlap).
+extern "C" int dlesm_periodic_halos_apply_multi_f64(double *const *fields, int nfields, int ld, int ny,
+                                                    const dlesm_region *internal, int bc_x, int bc_y, void *stream)
+{
+    DLESM_REQUIRE(fields != nullptr && internal != nullptr && nfields >= 1 && nfields <= 16, "bad arguments");
+    if (int rc = ensure_device()) return rc;
+    FieldList fl{};
+    for (int k = 0; k < nfields; k++) {
+        DLESM_REQUIRE(fields[k] != nullptr, "null field %d", k);
+        fl.f[k] = fields[k];
+    }
     dlesm_region src[4], dst[4];
     int n = 0;
     if (int rc = dlesm_periodic_halos(internal, bc_x, bc_y, src, dst, &n)) return rc;
-    for (int k = 0; k < n; k++)   // in order: the y copies carry the corners the x copies made
-        if (int rc = dlesm_copy_patch_f64(field, field, ld, ny, src[k].xstart, src[k].ystart, dst[k].xstart,
-                                          dst[k].ystart, src[k].nx, src[k].ny, stream))
-            return rc;
+    for (int k = 0; k < n; k++)
+        DLESM_REQUIRE(src[k].xstart >= 1 && src[k].ystart >= 1 && dst[k].xstart >= 1 && dst[k].ystart >= 1 &&
+                          src[k].xstop <= ld && dst[k].xstop <= ld && src[k].ystop <= ny && dst[k].ystop <= ny,
+                      "periodic halo %d lies outside the %dx%d field", k, ld, ny);
+    for (int k0 = 0; k0 < n; k0 += 2) {
+        HaloPair h{};
+        long widest = 0;
+        for (int c = 0; c < 2; c++) {
+            h.sx[c] = src[k0 + c].xstart - 1; h.sy[c] = src[k0 + c].ystart - 1;
+            h.dx[c] = dst[k0 + c].xstart - 1; h.dy[c] = dst[k0 + c].ystart - 1;
+            h.nx[c] = src[k0 + c].nx;         h.ny[c] = src[k0 + c].ny;
+            if ((long)h.nx[c] * h.ny[c] > widest) widest = (long)h.nx[c] * h.ny[c];
+        }
+        if (widest <= 0) continue;
+        long gx = (widest + 255) / 256;
+        if (gx > 256) gx = 256;
+        hipLaunchKernelGGL(periodic_pair_k, dim3((unsigned)gx, (unsigned)(2 * nfields)), dim3(256), 0,
+                           (hipStream_t)stream, fl, ld, h);
+    }
+    DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
+}
+
+extern "C" int dlesm_periodic_halos_apply_f64(double *field, int ld, int ny, const dlesm_region *internal,
+                                              int bc_x, int bc_y, void *stream)
+{
+    DLESM_REQUIRE(field != nullptr, "null pointer");
+    double *one[1] = {field};
+    return dlesm_periodic_halos_apply_multi_f64(one, 1, ld, ny, internal, bc_x, bc_y, stream);
 }
 
 extern "C" int dlesm_shallow_autotune_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop,
@@ -389,7 +574,7 @@ extern "C" int dlesm_shallow_autotune_f64(const dlesm_sw_params *q, int ld, int 
                 { std::lock_guard<std::mutex> lk(g_sw_mu); g_sw_override = c; }
                 (void)hipEventRecord(e0, s);
                 for (int rep = 0; rep < 3; rep++)
-                    launch_shallow_tile(*q, ld, x0, x1, y0, y1, u, v, p, uold, vold, pold, unew, vnew, pnew, s);
+                    launch_shallow_tile(*q, ld, x0, x1, y0, y1, u, v, p, uold, vold, pold, unew, vnew, pnew, s, false);
                 (void)hipEventRecord(e1, s);
                 { std::lock_guard<std::mutex> lk(g_sw_mu); g_sw_override = SwShape{0, 0, 0}; }
                 if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess)

@@ -121,6 +121,15 @@ def apply_periodic_halos(fld, stream=None):
                                                      _stream_ptr(stream)))
 
 
+def apply_periodic_halos_multi(fields, stream=None):
+    """the periodic copies of several fields of one grid and internal region in two launches"""
+    g = fields[0].grid
+    arr = (C.c_void_p * len(fields))(*[f.device_ptr.value for f in fields])
+    check(_cabi.lib().dlesm_periodic_halos_apply_multi_f64(arr, len(fields), g.nx, g.ny, C.byref(fields[0].internal),
+                                                           g.boundary_conditions[0], g.boundary_conditions[1],
+                                                           _stream_ptr(stream)))
+
+
 def autotune_shallow(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
     """optional planning call for invoke_shallow_step: time the launch shapes / cache policies once
     for this field geometry (each trial is the same valid step) and keep the fastest"""

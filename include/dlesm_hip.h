@@ -275,6 +275,10 @@ int dlesm_shallow_step_sw_f64(const dlesm_sw_params *params, int ld, int ny,
  * every kernel that writes the field. */
 int dlesm_periodic_halos_apply_f64(double *field, int ld, int ny, const dlesm_region *internal,
                                    int bc_x, int bc_y, void *stream);
+/* the same for up to 16 fields of one shape and internal region in two launches (all x copies, then
+ * all y copies): what follows a step that writes unew, vnew and pnew */
+int dlesm_periodic_halos_apply_multi_f64(double *const *fields, int nfields, int ld, int ny,
+                                         const dlesm_region *internal, int bc_x, int bc_y, void *stream);
 
 /* field_copy_code over a box (infrastructure_mod.f90:32-41) and the patch copy
  * used for periodic boundaries (copy_2dfield_patch, field_mod.f90:1179-1187):

@@ -84,6 +84,43 @@ def main():
                           "frac_of_8TBs": 72.0 * cells / ms / 1e6 / 8000.0}
             print(f"{label:16s} {ms:.4f} ms/step  {cells / ms / 1e3:9.0f} Mcells/s  {72.0 * cells / ms / 1e6:6.0f} GB/s "
                   f"({72.0 * cells / ms / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+    # the SW-offset, doubly periodic form (the GOcean `shallow` benchmark's configuration): step + the
+    # periodic copies of the three new fields (two launches) + rotation
+    if not args.only_default:
+        L.dlesm_set_tuning(b"sw_tile_rows", 2)
+        L.dlesm_set_tuning(b"sw_nt", 2)
+        gs = D.grid_type(D.GO_ARAKAWA_C, (0, 0, 2), D.GO_OFFSET_SW)
+        gs.decompose(args.tile, args.tile)
+        D.grid_init(gs, 1.0, 1.0)
+        with torch.cuda.stream(s):
+            G = {}
+            for k, name in enumerate(["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]):
+                f = D.r2d_field(gs, pts[name[0]])
+                D.psy.hash_init(f, 20261004 + k, box=f.internal, stream=s)
+                f.data.add_(1.0 if name[0] == "p" else -0.5)
+                D.psy.apply_periodic_halos(f, stream=s)
+                G[name] = f
+            for label, kern in (("SW periodic, tile kernel", 0), ("SW periodic, direct kernel", 1)):
+                L.dlesm_set_tuning(b"sw_kernel", kern)
+                cur, old, new = [G["u"], G["v"], G["p"]], [G["uold"], G["vold"], G["pold"]], [G["unew"], G["vnew"], G["pnew"]]
+                ts = []
+                for rnd in range(4):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(s)
+                    for _ in range(args.steps):
+                        D.psy.invoke_shallow_step_sw(prm, *cur, *old, *new, stream=s)
+                        D.psy.apply_periodic_halos_multi(new, stream=s)
+                        old, cur, new = cur, new, old
+                    e1.record(s)
+                    s.synchronize()
+                    if rnd:
+                        ts.append(e0.elapsed_time(e1) / args.steps)
+                ms = min(ts)
+                res[label] = {"ms_per_step": ms, "mcells_per_s": cells / ms / 1e3, "gbs_72B": 72.0 * cells / ms / 1e6,
+                              "frac_of_8TBs": 72.0 * cells / ms / 1e6 / 8000.0}
+                print(f"{label:32s} {ms:.4f} ms/step  {cells / ms / 1e3:9.0f} Mcells/s  {72.0 * cells / ms / 1e6:6.0f} GB/s "
+                      f"({72.0 * cells / ms / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+            L.dlesm_set_tuning(b"sw_kernel", 0)
     out = {"tile": args.tile, "ld": g.nx, "steps": args.steps, "algorithmic_bytes_per_cell": 72, "gpu": res}
     if not args.no_cpu:
         import oracle_lib as O

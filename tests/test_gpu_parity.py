@@ -689,14 +689,16 @@ def test_shallow_cache_policies_and_planned_shapes_change_no_bit(D, nx, ny, alig
 
 
 @pytest.mark.parametrize("nx,ny,alignment,steps", [(10, 10, None, 5), (10, 10, 8, 5), (256, 256, None, 4), (256, 256, 64, 4),
-                                                   (37, 5, 2, 3)])
-def test_periodic_sw_offset_shallow_model(D, nx, ny, alignment, steps):
+                                                   (37, 5, 2, 3), (1000, 130, 64, 3), (2100, 7, 2, 2)])
+@pytest.mark.parametrize("sw_kernel,sw_rows", [(0, 2), (0, 3), (1, 2)])
+def test_periodic_sw_offset_shallow_model(D, nx, ny, alignment, steps, sw_kernel, sw_rows):
     """the configuration section 8 f.2 was built for: SW offset, periodic in x and y (serial only in
     the reference, field_mod.f90:675-751): dlesm_shallow_step_sw_f64 + the device periodic-halo
     copies (the field's own halo list) + leapfrog rotation, `steps` times, every bit against the
     oracle running the same model (orc_sw_step_sw pinned by tests/sw_numpy.py, halo regions by the
     reference's)"""
     import torch
+    _set_tuning(D, sw_kernel=sw_kernel, sw_tile_rows=sw_rows)        # wave-tile kernel (R rows) / one cell per thread
     g = _grid(D, nx, ny, alignment, offset=D.GO_OFFSET_SW, bc=(0, 0, 2))
     names, F = _sw_fields(D, g)
     it = F["p"].internal
@@ -722,8 +724,7 @@ def test_periodic_sw_offset_shallow_model(D, nx, ny, alignment, steps):
     hc, ho, hn = [H[n] for n in "uvp"], [H[n + "old"] for n in "uvp"], [H[n + "new"] for n in "uvp"]
     for _ in range(steps):
         D.psy.invoke_shallow_step_sw(prm, *cur, *old, *new)
-        for f in new:
-            D.psy.apply_periodic_halos(f)
+        D.psy.apply_periodic_halos_multi(new)                    # all three new fields: two launches
         O.sw_step_sw(prm, g.nx, it.box(), *hc, *ho, *hn)
         for f in hn:
             O.apply_periodic_halos(f, g.nx, it.box(), 0, 0)
@@ -732,6 +733,7 @@ def test_periodic_sw_offset_shallow_model(D, nx, ny, alignment, steps):
             assert np.array_equal(f.get_data(), w)
         old, cur, new = cur, new, old
         ho, hc, hn = hc, hn, ho
+    _set_tuning(D, sw_kernel=0, sw_tile_rows=2)
 
 
 def _sw_fields(D, g):
