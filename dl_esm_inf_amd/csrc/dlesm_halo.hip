@@ -324,7 +324,7 @@ static int join_pending(dlesm_halo_plan *p, hipStream_t s)
 extern "C" int dlesm_halo_plan_join(dlesm_halo_plan *p, void *stream)
 {
     DLESM_REQUIRE(p != nullptr, "null plan");
-    DLESM_REQUIRE(!p->frame_timed_out || *p->frame_timed_out == 0,
+    DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
                   "a distributed step gave up waiting for a flag (frame or halo wait timed out)");
     return join_pending(p, (hipStream_t)stream);
 }
@@ -441,8 +441,8 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
     // through a flag the side stream is parked on -- no frame launch and no event record on the
     // caller's stream (each costs it microseconds of a ~180 us step, scripts/syncbench.hip).
     bool fused = false;
-    DLESM_REQUIRE(!p->frame_timed_out || *p->frame_timed_out == 0,
-                  "an earlier distributed step never reported its frame (frame flag wait timed out)");
+    DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
+                  "an earlier distributed step gave up waiting for a flag (frame or halo wait timed out)");
     if (p->frame_flag && tuning("j5_dm_fused", 1)) {
         FrameJob job{};
         job.pk = fp;
@@ -641,11 +641,18 @@ extern "C" int dlesm_gather_f64(const double *send, double *recv, int n)
 // ---------------------------------------------------------------------------
 // Device-side gather / scatter of whole fields (field_mod.f90:1313-1390, 378-389)
 
-__global__ void pack_inner_k(const double *__restrict__ f, int ld, int x0, int y0, int nx, long n, long slot,
+// rows dealt round-robin to the workgroups, lanes along the row: no per-element division
+__global__ void pack_inner_k(const double *__restrict__ f, int ld, int x0, int y0, int nx, int h, long slot,
                              double *__restrict__ send)
 {
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < slot; t += (long)gridDim.x * blockDim.x)
-        send[t] = t < n ? f[(size_t)(y0 + t / nx) * ld + x0 + t % nx] : 0.0;
+    for (int j = blockIdx.x; j < h; j += gridDim.x) {
+        const double *src = f + (size_t)(y0 + j) * ld + x0;
+        double *dst = send + (size_t)j * nx;
+        for (int i = threadIdx.x; i < nx; i += blockDim.x) dst[i] = src[i];
+    }
+    // the rest of the slot (tiles are uneven): zeroed
+    for (long t = (long)nx * h + (long)blockIdx.x * blockDim.x + threadIdx.x; t < slot; t += (long)gridDim.x * blockDim.x)
+        send[t] = 0.0;
 }
 
 struct GBox { int x0, y0, w, h; };            // 0-based origin in the global array, extent
@@ -655,10 +662,12 @@ __global__ void unpack_gathered_k(const double *__restrict__ recv, long slot, co
                                   int gnx, double *__restrict__ global)
 {
     const GBox b = boxes[blockIdx.y];
-    const long n = (long)b.w * b.h;
     const double *src = recv + (size_t)blockIdx.y * slot;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
-        global[(size_t)(b.y0 + t / b.w) * gnx + b.x0 + t % b.w] = src[t];
+    for (int j = blockIdx.x; j < b.h; j += gridDim.x) {
+        double *dst = global + (size_t)(b.y0 + j) * gnx + b.x0;
+        const double *row = src + (size_t)j * b.w;
+        for (int i = threadIdx.x; i < b.w; i += blockDim.x) dst[i] = row[i];
+    }
 }
 
 extern "C" int dlesm_pack_inner_f64(const double *field, int ld, int ny, int xstart, int xstop, int ystart,
@@ -671,10 +680,11 @@ extern "C" int dlesm_pack_inner_f64(const double *field, int ld, int ny, int xst
     const long n = nx > 0 && h > 0 ? (long)nx * h : 0;
     DLESM_REQUIRE(slot >= n, "slot of %ld doubles for a %dx%d region", slot, nx, h);
     if (slot == 0) return DLESM_OK;
-    long blocks = (slot + 255) / 256;
+    long blocks = n > 0 ? h : (slot + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(pack_inner_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, ld, xstart - 1,
-                       ystart - 1, nx > 0 ? nx : 1, n, slot, send);
+                       ystart - 1, n > 0 ? nx : 0, n > 0 ? h : 0, slot, send);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -687,6 +697,7 @@ extern "C" int dlesm_unpack_gathered_f64(const double *recv, long slot, const dl
     if (int rc = ensure_device()) return rc;
     std::vector<GBox> boxes(nranks);
     long widest = 0;
+    int tallest = 0;
     for (int r = 0; r < nranks; r++) {
         const dlesm_region &g = subs[r].global;
         const int w = g.xstop - g.xstart + 1, h = g.ystop - g.ystart + 1;
@@ -696,6 +707,7 @@ extern "C" int dlesm_unpack_gathered_f64(const double *recv, long slot, const dl
                       g.ystart, g.ystop, d->global_nx, d->global_ny, slot);
         boxes[r] = GBox{g.xstart - 1, g.ystart - 1, w, h};
         if ((long)w * h > widest) widest = (long)w * h;
+        if (h > tallest) tallest = h;
     }
     if (widest == 0) return DLESM_OK;
     GBox *dboxes = nullptr;
@@ -703,8 +715,8 @@ extern "C" int dlesm_unpack_gathered_f64(const double *recv, long slot, const dl
     DLESM_HIP_TRY(hipMalloc((void **)&dboxes, boxes.size() * sizeof(GBox)));
     hipError_t e = hipMemcpyAsync(dboxes, boxes.data(), boxes.size() * sizeof(GBox), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-        long gx = (widest + 255) / 256;
-        if (gx > 1024) gx = 1024;
+        long gx = tallest;
+        if (gx > 2048) gx = 2048;
         hipLaunchKernelGGL(unpack_gathered_k, dim3((unsigned)gx, (unsigned)nranks), dim3(256), 0, s, recv, slot, dboxes,
                            d->global_nx, global);
         e = hipGetLastError();

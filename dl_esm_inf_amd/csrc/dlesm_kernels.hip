@@ -868,15 +868,42 @@ __device__ __forceinline__ double block_sum_256(double v)
     return r;
 }
 
+// SUM(ABS(f(box))) partials, one per workgroup: rows dealt round-robin to the workgroups, 16-byte
+// lanes on the even-aligned part of each row (the element before and after it by lane 0), two
+// independent accumulators per lane.  The order of the additions is fixed by the launch shape, so
+// the result is deterministic run to run.
 __global__ __launch_bounds__(256) void abs_sum_rows(const double *__restrict__ f, int ld, int x0, int y0,
                                                     int nx, int ny, double *__restrict__ partial)
 {
-    double acc = 0.0;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double acc0 = 0.0, acc1 = 0.0;
+    const bool base_ok = ((uintptr_t)f & 15) == 0;
     for (int j = blockIdx.x; j < ny; j += gridDim.x) {
-        const double *r = f + (size_t)(y0 + j) * ld + x0;
-        for (int i = threadIdx.x; i < nx; i += 256) acc += fabs(r[i]);
+        const size_t off = (size_t)(y0 + j) * ld + x0;
+        const double *r = f + off;
+        if (base_ok) {
+            const int head = (int)(off & 1);                  // one element before the 16-byte aligned part
+            const int nvec = (nx - head) / 2, tail = (nx - head) & 1;
+            const d2 *rv = (const d2 *)(r + head);
+            if (threadIdx.x == 0) {
+                if (head && nx > 0) acc0 += fabs(r[0]);
+                if (tail) acc1 += fabs(r[nx - 1]);
+            }
+            int i = threadIdx.x;
+            for (; i + 256 < nvec; i += 512) {                // two 16-byte loads in flight per lane
+                const d2 a = rv[i], b = rv[i + 256];
+                acc0 += fabs(a.x) + fabs(a.y);
+                acc1 += fabs(b.x) + fabs(b.y);
+            }
+            if (i < nvec) {
+                const d2 a = rv[i];
+                acc0 += fabs(a.x) + fabs(a.y);
+            }
+        } else {
+            for (int i = threadIdx.x; i < nx; i += 256) acc0 += fabs(r[i]);
+        }
     }
-    acc = block_sum_256(acc);
+    const double acc = block_sum_256(acc0 + acc1);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 

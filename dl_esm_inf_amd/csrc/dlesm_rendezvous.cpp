@@ -56,10 +56,14 @@ long long process_start()
         size_t n = fread(buf, 1, sizeof buf - 1, f);
         fclose(f);
         buf[n] = 0;
-        if (char *p = strrchr(buf, ')')) { // the command name may contain spaces
-            int field = 2;
-            for (char *tok = strtok(p + 1, " "); tok; tok = strtok(nullptr, " "))
-                if (++field == 22) { ticks = atoll(tok); break; }
+        if (const char *p = strrchr(buf, ')')) { // the command name may contain spaces: fields restart after it
+            int field = 2;                       // p points at the end of field 2 (comm)
+            for (const char *c = p + 1; *c; ) {
+                while (*c == ' ') c++;
+                if (!*c) break;
+                if (++field == 22) { ticks = atoll(c); break; }
+                while (*c && *c != ' ') c++;
+            }
         }
     }
     const long hz = sysconf(_SC_CLK_TCK);
