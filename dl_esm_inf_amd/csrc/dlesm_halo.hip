@@ -108,6 +108,10 @@ struct dlesm_halo_plan {
     bool pending = false;              // an exchange has been issued and not yet joined on pending_stream
     unsigned long long pending_seq = 0;
     hipStream_t pending_stream = nullptr;
+    // ... and its west/east strips have not been unpacked: they sit in recvbuf, where the next
+    // pipelined step's frame workgroups read them; whoever joins instead unpacks them into this field
+    double *pending_field = nullptr;
+    unsigned pending_mask = 0;
 };
 
 // edge directions follow their bit; diagonals follow their two edges (parallel_comms_mod.f90:
@@ -318,6 +322,14 @@ static int join_pending(dlesm_halo_plan *p, hipStream_t s)
     if (!p->pending) return DLESM_OK;
     DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
     p->pending = false;
+    if (p->pending_field && p->n_rpack) {      // the unpack the pipelined step left out
+        int gx = (p->max_strip + 255) / 256;
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(unpack_strips, dim3(gx, p->n_rpack), dim3(256), 0, s, p->pending_field, p->ld, p->d_rpack,
+                           p->recvbuf, p->pending_mask);
+        DLESM_HIP_TRY(hipGetLastError());
+    }
+    p->pending_field = nullptr;
     return DLESM_OK;
 }
 
@@ -334,7 +346,7 @@ extern "C" int dlesm_halo_plan_join(dlesm_halo_plan *p, void *stream)
 // `prepacked`: the caller's kernel has already written the enabled strided strips of every field
 // into the send buffer (dlesm_jacobi5_step_dm's frame kernel does), so no pack launch is needed.
 static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsigned mask, hipStream_t s,
-                       bool prepacked = false)
+                       bool prepacked = false, bool skip_unpack = false)
 {
     bool any = false, any_spack = false, any_rpack = false;
     for (const Msg &m : p->sends)
@@ -366,7 +378,7 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
         }
     }
     if (int rc = group_end(err, "halo exchange (ncclSend/ncclRecv)")) return rc;
-    if (any_rpack)
+    if (any_rpack && !skip_unpack)
         for (int k = 0; k < nf; k++)
             hipLaunchKernelGGL(unpack_strips, dim3(gx, p->n_rpack), dim3(256), 0, s, fields[k], p->ld, p->d_rpack,
                                p->recvbuf + (size_t)k * p->recvbuf_len, mask);
@@ -374,10 +386,11 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
     return DLESM_OK;
 }
 
-static int exchange_on(dlesm_halo_plan *p, double *f, unsigned mask, hipStream_t s, bool prepacked = false)
+static int exchange_on(dlesm_halo_plan *p, double *f, unsigned mask, hipStream_t s, bool prepacked = false,
+                       bool skip_unpack = false)
 {
     double *one[1] = {f};
-    return exchange_on(p, one, 1, mask, s, prepacked);
+    return exchange_on(p, one, 1, mask, s, prepacked, skip_unpack);
 }
 
 extern "C" int dlesm_halo_exchange_multi_f64(dlesm_halo_plan *p, double *const *fields, int nfields,
@@ -452,13 +465,36 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
         job.halo_flag = p->halo_flag;
         job.halo_seq = can_chain ? p->pending_seq : 0;
         job.timed_out = p->frame_timed_out;
+        // chained step: the previous exchange was not unpacked -- `in`'s west/east halo columns are the
+        // received strips themselves, read from the receive buffer (the same mask was exchanged)
+        const bool virt = can_chain && p->pending_field == in && tuning("j5_dm_lazy_unpack", 1);
+        if (virt) {
+            bool ok = true;
+            for (const Msg &m : p->recvs) {
+                if (m.off < 0 || !dir_enabled(p->pending_mask, m.dir)) continue;
+                if (m.nx != 1 || job.nh == FramePack::MAXS) { ok = false; break; }
+                job.hs[job.nh++] = FrameJob::HaloCol{m.i0, m.j0, m.ny, m.off};
+            }
+            if (ok) job.halo_buf = p->recvbuf;
+            else job.nh = 0;
+        }
+        if (can_chain && p->pending_field && !job.halo_buf) {       // cannot read them in place: unpack first
+            if (int rc = join_pending(p, s)) return rc;
+            job.halo_seq = 0;
+        }
         if (int rc = launch_stencil5_framed(in, out, ld, ny, xstart, xstop, ystart, ystop, job, s, &fused)) return rc;
         if (fused) {
             p->frame_seq = job.seq;
             p->pending = false;                          // the chained wait (if any) is inside the launch
+            p->pending_field = nullptr;
+            // pipelined: the received west/east strips stay in the receive buffer (no strided unpack kernel
+            // beside the sweep -- measured: two column-copy kernels cost the sweep 3 us, RCCL itself nothing);
+            // the next step reads them there, a join unpacks them
+            const bool lazy = pipelined && tuning("j5_dm_lazy_unpack", 1);
             if (int rc = launch_frame_flag_wait(p->frame_flag, job.seq, p->frame_timed_out, side)) return rc;
-            if (int rc = exchange_on(p, out, mask, side, prepacked)) return rc;
+            if (int rc = exchange_on(p, out, mask, side, prepacked, lazy)) return rc;
             if (int rc = launch_flag_set(p->halo_flag, job.seq, side)) return rc;
+            if (lazy) { p->pending_field = out; p->pending_mask = mask; }
             DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
         } else if (can_chain) {                          // the arrays do not qualify: fall back to the event join
             if (int rc = join_pending(p, s)) return rc;

@@ -93,6 +93,11 @@ struct FrameJob {
     const unsigned long long *halo_flag;
     unsigned long long halo_seq;  // 0: no wait
     int *timed_out;               // pinned host word raised by a wait that gives up
+    // pipelined steps: the west/east halo columns of `in` have NOT been unpacked into the field; they
+    // are read from the receive buffer of the previous exchange (contiguous), strip by strip
+    struct HaloCol { int i, j0, nj; long off; } hs[FramePack::MAXS]; // 0-based halo column, first row, rows, slot
+    int nh;
+    const double *halo_buf;       // nullptr: halos are in the field
 };
 // Frame of the box + interior sweep in ONE launch.  *fused = false (and nothing launched) when the
 // arrays do not qualify for the 16-byte-lane tile kernel: the caller then takes the two-launch path.

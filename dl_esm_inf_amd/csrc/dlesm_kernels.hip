@@ -300,7 +300,8 @@ __device__ __forceinline__ long frame_cells(int w, int h)
 // another kernel reads while this one is still running.
 template <bool WT>
 __device__ __forceinline__ void frame_cell(long t, const double *__restrict__ in, double *__restrict__ out,
-                                           int ld, int x0, int x1, int y0, int y1, const FramePack &pk)
+                                           int ld, int x0, int x1, int y0, int y1, const FramePack &pk,
+                                           const FrameJob *fj = nullptr)
 {
     const int w = x1 - x0 + 1, h = y1 - y0 + 1;
     const int ncol = h > 2 ? h - 2 : 0, nrows = h > 1 ? 2 : 1;
@@ -323,7 +324,18 @@ __device__ __forceinline__ void frame_cell(long t, const double *__restrict__ in
         }
         return *p;
     };
-    const double r = 0.25 * ((get(in + o - 1, i == x0) + get(in + o + 1, i == x1)) +
+    // a west/east halo operand that still sits in the receive buffer (pipelined steps: no unpack)
+    auto get_col = [&](int hi, const double *p, bool outside) {
+        if constexpr (WT) {
+            if (outside && fj && fj->halo_buf)
+                for (int k = 0; k < fj->nh; k++)
+                    if (hi == fj->hs[k].i && j >= fj->hs[k].j0 && j < fj->hs[k].j0 + fj->hs[k].nj)
+                        return __hip_atomic_load(fj->halo_buf + fj->hs[k].off + (j - fj->hs[k].j0), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return get(p, outside);
+    };
+    const double r = 0.25 * ((get_col(i - 1, in + o - 1, i == x0) + get_col(i + 1, in + o + 1, i == x1)) +
                              (get(in + o - ld, j == y0) + get(in + o + ld, j == y1)));
     auto put = [](double *p, double v) {
         if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_framed(const double *__rest
     // scope.  A per-thread __threadfence() instead would be a whole-L2 write-back + invalidate per
     // wave, in the middle of the interior sweep -- measured: +35 us on a 180 us step.
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)fj.nblocks * blockDim.x)
-        frame_cell<true>(t, in, out, ld, fj.fx0, fj.fx1, fj.fy0, fj.fy1, fj.pk);
+        frame_cell<true>(t, in, out, ld, fj.fx0, fj.fx1, fj.fy0, fj.fy1, fj.pk, &fj);
     __builtin_amdgcn_s_waitcnt(0);        // this wave's stores have been acknowledged ...
     __syncthreads();                      // ... and those of every wave of the group ...
     if (threadIdx.x == 0) {               // ... before the group is counted as done

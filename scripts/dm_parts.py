@@ -74,10 +74,30 @@ def rccl_beside_interior(x, y):
     interior(x, y)
 
 
+def ns_only_beside_interior(x, y):     # two in-place row messages: RCCL alone, no pack / unpack kernels
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, 0xC | D._cabi.DIRS_NO_DIAGONALS, C.c_void_p(side.cuda_stream)))
+    interior(x, y)
+
+
+def ew_only_beside_interior(x, y):     # two column messages: pack + RCCL + unpack
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, 0x3 | D._cabi.DIRS_NO_DIAGONALS, C.c_void_p(side.cuda_stream)))
+    interior(x, y)
+
+
+def tiny_kernels_beside_interior(x, y):   # the side stream runs two small copy kernels only (no RCCL)
+    with torch.cuda.stream(side):
+        D.copy_field(x, src=D._cabi.Region(1, 8192, xs, xs, ys, ye), dest=D._cabi.Region(1, 8192, xs - 1, xs - 1, ys, ye), stream=side)
+        D.copy_field(x, src=D._cabi.Region(1, 8192, xe, xe, ys, ye), dest=D._cabi.Region(1, 8192, xe + 1, xe + 1, ys, ye), stream=side)
+    interior(x, y)
+
+
 with torch.cuda.stream(s):
     for name, fn in (("full box", full), ("interior box", interior), ("y-shifted box", shifted_y),
                      ("x-shifted box", shifted_x), ("exchange on side stream || full box", exch_then_full),
                      ("exchange on side stream || interior box", rccl_beside_interior),
+                     ("N/S messages only on side stream || interior box", ns_only_beside_interior),
+                     ("E/W messages only on side stream || interior box", ew_only_beside_interior),
+                     ("two column-copy kernels on side stream || interior", tiny_kernels_beside_interior),
                      ("exchange alone", exch_alone),
                      ("overlapped dm step", dm), ("pipelined dm step", dm_pipelined), ("full box again", full),
                      ("interior box again", interior)):

@@ -517,19 +517,21 @@ def test_distributed_step_variants(D, corners, frame_pack):
 
 
 @pytest.mark.parametrize("nx,ny,alignment,nsteps", [(300, 41, 64, 7), (64, 64, 2, 12), (1500, 700, 64, 9), (130, 5, 2, 4)])
-@pytest.mark.parametrize("chain", [1, 0])
-def test_pipelined_distributed_steps(D, nx, ny, alignment, nsteps, chain):
+@pytest.mark.parametrize("chain,lazy", [(1, 1), (1, 0), (0, 1)])
+def test_pipelined_distributed_steps(D, nx, ny, alignment, nsteps, chain, lazy):
     """dlesm_jacobi5_step_dm_pipelined: a time loop of steps that never joins the exchange on the
     caller's stream -- each step's frame workgroups wait on the device for the previous exchange --
     then ONE dlesm_halo_plan_join.  Every bit of the result (halos included) against the oracle's
-    nsteps x (stencil + edge exchange); j5_dm_chain=0 is the same API with the event join inside."""
+    nsteps x (stencil + edge exchange); j5_dm_chain=0 is the same API with the event join inside;
+    j5_dm_lazy_unpack: the received west/east strips stay in the receive buffer between steps (the
+    next step's frame reads them there) and are unpacked by whoever joins."""
     import sys
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     from dm_overhead import loopback_tables
     D.parallel_init(0, 1, use_rccl=True)
     L = D._cabi.lib()
-    _set_tuning(D, j5_dm_chain=chain)
+    _set_tuning(D, j5_dm_chain=chain, j5_dm_lazy_unpack=lazy)
     g = _grid(D, nx, ny, alignment)
     x, y = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
     it = x.internal
@@ -562,7 +564,16 @@ def test_pipelined_distributed_steps(D, nx, ny, alignment, nsteps, chain):
     O.jacobi5(hx, hy, g.nx, *it.box())
     assert O.exchange_all([hy], [g.nx], [oc]) == 0
     assert np.array_equal(b.get_data(), hy)
-    _set_tuning(D, j5_dm_chain=1)
+    # ... and so does a joined step that follows pipelined ones (its `in` carries un-unpacked halos)
+    D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, b.device_ptr, a.device_ptr, g.nx, g.ny, *it.box(), sp))
+    D._cabi.check(L.dlesm_jacobi5_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), sp))
+    s.synchronize()
+    for _ in range(2):
+        O.jacobi5(hy, hx, g.nx, *it.box())
+        assert O.exchange_dirs([hx], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+        hx, hy = hy, hx
+    assert np.array_equal(b.get_data(), hy)
+    _set_tuning(D, j5_dm_chain=1, j5_dm_lazy_unpack=1)
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
@@ -777,20 +788,24 @@ def test_shallow_ten_steps_numpy_golden(D, sw_kernel, sw_rows):
     _set_tuning(D, sw_kernel=0, sw_tile_rows=2)
 
 
-@pytest.mark.parametrize("n,alignment", [(8192, 64), (4096, None)])
-def test_shallow_full_size_properties(D, n, alignment):
-    """BASELINE configs[3] size: (i) a constant state is a fixed point, exactly; (ii) sampled rows and
-    the edge rows agree bit for bit with the oracle run on 3-row slabs; (iii) nothing outside the
-    box is written"""
+@pytest.mark.parametrize("n,alignment,sw_offset", [(8192, 64, False), (4096, None, False), (8192, 64, True)])
+def test_shallow_full_size_properties(D, n, alignment, sw_offset):
+    """BASELINE configs[3] size, NE offset and the SW-offset periodic form: (i) a constant state is a
+    fixed point, exactly; (ii) sampled rows and the edge rows agree bit for bit with the oracle run on
+    3-row slabs; (iii) nothing outside the box is written"""
     import torch
-    import sw_numpy as N
-    g = _grid(D, n, n, alignment)
+    if sw_offset:
+        g = _grid(D, n, n, alignment, offset=D.GO_OFFSET_SW, bc=(0, 0, 2))
+        invoke, oracle_step = D.psy.invoke_shallow_step_sw, O.sw_step_sw
+    else:
+        g = _grid(D, n, n, alignment)
+        invoke, oracle_step = D.psy.invoke_shallow_step, O.sw_step
     names, F = _sw_fields(D, g)
     it = F["p"].internal
     prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
     for nm in names:
         D.set_field(F[nm], {"u": 0.25, "v": -0.125, "p": 1.5}[nm[0]] if not nm.endswith("new") else 9.0)
-    D.psy.invoke_shallow_step(prm, *[F[nm] for nm in names])
+    invoke(prm, *[F[nm] for nm in names])
     for nm, c in (("unew", 0.25), ("vnew", -0.125), ("pnew", 1.5)):
         inner = F[nm].data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop]
         assert bool((inner == c).all()), nm
@@ -798,7 +813,7 @@ def test_shallow_full_size_properties(D, n, alignment):
     for k, nm in enumerate(names[:6]):
         D.psy.hash_init(F[nm], SEED + k)
         F[nm].data.add_(1.0 if nm[0] == "p" else -0.5)
-    D.psy.invoke_shallow_step(prm, *[F[nm] for nm in names])
+    invoke(prm, *[F[nm] for nm in names])
     torch.cuda.synchronize()
     rng = np.random.default_rng(n)
     rows = sorted(set([it.ystart, it.ystart + 1, it.ystop - 1, it.ystop] +
@@ -806,7 +821,7 @@ def test_shallow_full_size_properties(D, n, alignment):
     for jj in rows:
         slab = {nm: F[nm].data[jj - 2:jj + 1, :].cpu().numpy() for nm in names[:6]}      # rows jj-1, jj, jj+1
         want = [np.full_like(slab["u"], 9.0) for _ in range(3)]
-        O.sw_step(prm, g.nx, (it.xstart, it.xstop, 2, 2), *[slab[nm] for nm in names[:6]], *want)
+        oracle_step(prm, g.nx, (it.xstart, it.xstop, 2, 2), *[slab[nm] for nm in names[:6]], *want)
         for nm, w in zip(names[6:], want):
             got = F[nm].data[jj - 1, :].cpu().numpy()
             assert np.array_equal(got, w[1]), (nm, jj)
@@ -814,6 +829,15 @@ def test_shallow_full_size_properties(D, n, alignment):
         d = F[nm].data
         assert bool((d[0, :] == 9.0).all()) and bool((d[it.ystop:, :] == 9.0).all()), nm
         assert bool((d[:, 0] == 9.0).all()) and bool((d[:, it.xstop:] == 9.0).all()), nm
+    if sw_offset:      # the periodic copies at full size: halo rows/columns equal the opposite internal ones
+        f = F["pnew"]
+        D.psy.apply_periodic_halos(f)
+        torch.cuda.synchronize()
+        d = f.data
+        assert bool(torch.equal(d[it.ystart - 1:it.ystop, it.xstop], d[it.ystart - 1:it.ystop, it.xstart - 1]))
+        assert bool(torch.equal(d[it.ystart - 1:it.ystop, it.xstart - 2], d[it.ystart - 1:it.ystop, it.xstop - 1]))
+        assert bool(torch.equal(d[it.ystop, it.xstart - 2:it.xstop + 1], d[it.ystart - 1, it.xstart - 2:it.xstop + 1]))
+        assert bool(torch.equal(d[it.ystart - 2, it.xstart - 2:it.xstop + 1], d[it.ystop - 1, it.xstart - 2:it.xstop + 1]))
 
 
 @pytest.mark.parametrize("nx,ny", [(1, 1), (2, 2), (1, 6), (6, 1), (3, 3), (130, 5), (5, 130), (257, 64)])
