@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <unistd.h>
 
 #include "dlesm_error.h"
 
@@ -172,6 +173,40 @@ int main()
             REQUIRE(dlesm_grid_extents(w, 5, al, &nx, &ny) == 0);
             REQUIRE(nx > w && nx % (al > 0 ? al : 1) == 0 && nx - w <= (al > 0 ? al : 1) && ny == 6);
         }
+    // periodic halo regions: sources inside the internal region (+ halo columns for the y pair),
+    // destinations on the ring, extents equal
+    for (int nx : {1, 2, 10, 257})
+        for (int ny : {1, 3, 64})
+            for (int bx : {0, 1})
+                for (int by : {0, 1}) {
+                    dlesm_region it{nx, ny, 2, nx + 1, 2, ny + 1}, src[4], dst[4];
+                    int n = -1;
+                    REQUIRE(dlesm_periodic_halos(&it, bx, by, src, dst, &n) == 0);
+                    REQUIRE(n == 2 * ((bx == 0) + (by == 0)));
+                    for (int k = 0; k < n; k++) {
+                        REQUIRE(src[k].nx == dst[k].nx && src[k].ny == dst[k].ny && src[k].nx >= 1 && src[k].ny >= 1);
+                        REQUIRE(dst[k].xstart >= 1 && dst[k].ystart >= 1 && dst[k].xstop <= nx + 2 && dst[k].ystop <= ny + 2);
+                    }
+                }
+    // the id rendezvous: publish / fetch / stale records / acknowledgements
+    {
+        char path[256], id[DLESM_UNIQUE_ID_BYTES], got[DLESM_UNIQUE_ID_BYTES];
+        snprintf(path, sizeof path, "/tmp/dlesm_sanitize_rv_%ld", (long)getpid());
+        for (int k = 0; k < DLESM_UNIQUE_ID_BYTES; k++) id[k] = (char)(3 * k + 1);
+        REQUIRE(dlesm_rendezvous_remove(path) == 0);
+        REQUIRE(dlesm_rendezvous_fetch(path, got, "2:x", 30) == DLESM_EINVAL);
+        REQUIRE(dlesm_rendezvous_publish(path, id, "2:x") == 0);
+        REQUIRE(dlesm_rendezvous_fetch(path, got, "2:x", 30) == 0 && memcmp(id, got, sizeof id) == 0);
+        REQUIRE(dlesm_rendezvous_fetch(path, got, "2:y", 30) == DLESM_EINVAL);
+        char longtok[200];
+        memset(longtok, 'a', sizeof longtok - 1);
+        longtok[sizeof longtok - 1] = 0;
+        REQUIRE(dlesm_rendezvous_publish(path, id, longtok) == DLESM_EINVAL);
+        REQUIRE(dlesm_rendezvous_ack(path, 1) == 0);
+        REQUIRE(dlesm_rendezvous_wait_acks(path, 2, 100) == 0);
+        REQUIRE(dlesm_rendezvous_wait_acks(path, 3, 30) == DLESM_EINVAL);
+        REQUIRE(dlesm_rendezvous_remove(path) == 0);
+    }
     printf("sanitize_maps: %ld checks passed\n", checks);
     return 0;
 }
