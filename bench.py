@@ -491,12 +491,37 @@ def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, step
     return out
 
 
+_STAGE = {"name": "start", "t0": time.time()}
+
+
+def stage(rank, world, name):
+    """N > 1 only: one stderr line per stage and rank, so that a failed or hung multi-GPU run (which
+    cannot be rehearsed on the one-GPU development box) says where it stopped"""
+    _STAGE["name"] = name
+    if world > 1:
+        print(f"[bench rank {rank}/{world} +{time.time() - _STAGE['t0']:6.1f}s] {name}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # a run that hangs before the headline exists must not sit there silently until the launcher's
+        # own limit: after 900 s every rank reports the stage it is stuck in and leaves non-zero
+        import threading
+
+        def stuck():
+            print(f"[bench rank {rank}/{world}] NO PROGRESS: still in stage '{_STAGE['name']}' after 900 s; giving up",
+                  file=sys.stderr, flush=True)
+            os._exit(6)
+
+        killer = threading.Timer(900.0, stuck)
+        killer.daemon = True
+        killer.start()
+    stage(rank, world, "process group init")
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -521,7 +546,9 @@ def main():
         L.dlesm_set_tuning(k.encode(), int(v))     # returns the previous value
     D._cabi.check(L.dlesm_init(local))             # after the knobs: the side stream's priority is one of them
     os.environ["DL_ESM_ALIGNMENT"] = str(args.alignment)
+    stage(rank, world, "RCCL communicator (dlesm_comm_init)")
     D.parallel_init(rank, world)
+    stage(rank, world, "grid + fields + first halo exchange")
 
     # global domain: what go_decompose will cut into `world` tiles of tile x tile
     small = int(math.isqrt(world))
@@ -545,6 +572,7 @@ def main():
     # N > 1: the time-loop form of the distributed step -- the exchange of step k is joined by step k+1's
     # frame workgroups on the device, the caller's stream carries one launch per step; ONE join closes the loop
     step = D.psy.invoke_jacobi5_dm_pipelined if world > 1 else D.psy.invoke_jacobi5
+    stage(rank, world, "planning call")
     planned = False
     if not args.no_plan:
         # planning, outside the timed region (like an FFT plan): the library times its launch shapes for
@@ -573,6 +601,7 @@ def main():
     # bit on every rank, three plain "stencil, then halo exchange" steps from the same state
     selfcheck = None
     if world > 1:
+        stage(rank, world, "self-check: distributed steps == stencil + exchange")
         x1, y1 = D.r2d_field(grid, D.GO_T_POINTS), D.r2d_field(grid, D.GO_T_POINTS)
         x2, y2 = D.r2d_field(grid, D.GO_T_POINTS), D.r2d_field(grid, D.GO_T_POINTS)
         with torch.cuda.stream(stream):
@@ -600,6 +629,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    stage(rank, world, "warm-up + timed steps")
     with torch.cuda.stream(stream):
         for _ in range(warm_launches):
             step(b, a, stream=stream)
@@ -625,7 +655,9 @@ def main():
         tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tt[0]), float(tt[1])
+    stage(rank, world, "global checksum (ncclAllReduce)")
     checksum = D.field_checksum(a)
+    stage(rank, world, "secondary legs")
 
     cells_step = args.tile * args.tile * world
     value = cells_step * args.steps / wall / 1e6
@@ -690,9 +722,11 @@ def main():
         dog.start()
         try:
             if not args.no_weak_tile and args.tile != WEAK_TILE:
+                stage(rank, world, "secondary leg: 8192^2 weak-scaling tile")
                 out["weak_scaling_tile"] = weak_scaling_tile(D, torch, dist, WEAK_TILE, args.alignment, world, P, Q,
                                                              stream, args.steps)
             if not args.no_temporal_blocking:
+                stage(rank, world, "secondary leg: fused 8-step distributed form")
                 out["temporal_blocking"] = temporal_blocking_dm(D, torch, dist, args.tile, P, Q, stream, args.steps)
         except Exception as e:                               # noqa: BLE001
             dog.cancel()
@@ -729,6 +763,9 @@ def main():
         out["secondary_legs_error"] = "failed: " + ", ".join(failed)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    stage(rank, world, "shutdown")
+    if world > 1:
+        killer.cancel()
     if world > 1 or args.force_dm_leg:
         dist.barrier()
         D.parallel_finalise()
