@@ -840,6 +840,15 @@ __global__ void copy_patch_k(const double *__restrict__ src, double *__restrict_
             dst[(size_t)(dy0 + j) * ld + dx0 + i] = src[(size_t)(sy0 + j) * ld + sx0 + i];
 }
 
+// whole rows of a field are one contiguous block: the linear copy that sets the measured ceiling
+// (scripts/membench.hip), one 16-byte element per thread, workgroups sweeping memory front to back
+__global__ __launch_bounds__(256) void copy_linear_k(const double *__restrict__ src, double *__restrict__ dst, size_t n2)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n2) ((d2 *)dst)[i] = ((const d2 *)src)[i];
+}
+
 __global__ void fill_k(double *__restrict__ f, int ld, int x0, int y0, int nx, int ny, double value)
 {
     for (int j = blockIdx.y; j < ny; j += gridDim.y)
@@ -1075,8 +1084,17 @@ extern "C" int dlesm_copy_patch_f64(const double *src, double *dst, int ld, int 
         const bool overlap = !(dx0 + nx <= sx0 || sx0 + nx <= dx0 || dy0 + ny <= sy0 || sy0 + ny <= dy0);
         DLESM_REQUIRE(!overlap, "copy_patch: overlapping source and destination patches");
     }
-    hipLaunchKernelGGL(copy_patch_k, grid2d(nx, ny), dim3(256), 0, (hipStream_t)stream, src, dst, ld,
-                       sx0 - 1, sy0 - 1, dx0 - 1, dy0 - 1, nx, ny);
+    const size_t n = (size_t)nx * ny;
+    const double *s0 = src + lin(ld, sx0, sy0);
+    double *d0 = dst + lin(ld, dx0, dy0);
+    if (nx == ld && n % 2 == 0 && (uintptr_t)s0 % 16 == 0 && (uintptr_t)d0 % 16 == 0 && n / 2 < ((size_t)1 << 31) * 256) {
+        // whole rows (field_copy_code over a whole field, copy_field of a field): contiguous
+        hipLaunchKernelGGL(copy_linear_k, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s0, d0,
+                           n / 2);
+    } else {
+        hipLaunchKernelGGL(copy_patch_k, grid2d(nx, ny), dim3(256), 0, (hipStream_t)stream, src, dst, ld,
+                           sx0 - 1, sy0 - 1, dx0 - 1, dy0 - 1, nx, ny);
+    }
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
