@@ -615,18 +615,42 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     };
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) return box(xstart, xstop, ystart, ystop);
-    // 1. frame: south row, north row, west column, east column (empty boxes are no-ops)
-    if (int rc = box(xstart, xstop, ystart, ystart)) return rc;
-    if (ystop > ystart)
-        if (int rc = box(xstart, xstop, ystop, ystop)) return rc;
-    if (int rc = box(xstart, xstart, ystart + 1, ystop - 1)) return rc;
-    if (xstop > xstart)
-        if (int rc = box(xstop, xstop, ystart + 1, ystop - 1)) return rc;
+    // 1. frame: the one-cell ring of the box in ONE launch (one cell per thread, all four sides), its
+    //    west/east columns written straight into the send buffers of the three new fields -- no pack
+    //    launches.  sw_dm_frame=0: the round-1 form (four thin boxes + pack kernels).
+    bool prepacked = false;
+    if (tuning("sw_dm_frame", 1)) {
+        FramePack3 fp{};
+        prepacked = true;
+        for (const Msg &m : p->sends) {
+            if (m.off < 0) continue;
+            const bool on_frame = m.nx == 1 && (m.i0 == xstart - 1 || m.i0 == xstop - 1) && m.j0 >= ystart - 1 &&
+                                  m.j0 + m.ny - 1 <= ystop - 1;
+            if (!on_frame || fp.n == FramePack::MAXS) { prepacked = false; break; }
+            fp.s[fp.n++] = FramePack::Col{m.i0, m.j0, m.ny, m.off};
+        }
+        if (prepacked && fp.n) {
+            if (int rc = ensure_buffers(p, 3)) return rc;
+            for (int k = 0; k < 3; k++) fp.buf[k] = p->sendbuf + (size_t)k * p->sendbuf_len;
+        } else {
+            fp.n = 0;
+        }
+        if (int rc = launch_shallow_frame(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew,
+                                          pnew, prepacked ? &fp : nullptr, s))
+            return rc;
+    } else {
+        if (int rc = box(xstart, xstop, ystart, ystart)) return rc;
+        if (ystop > ystart)
+            if (int rc = box(xstart, xstop, ystop, ystop)) return rc;
+        if (int rc = box(xstart, xstart, ystart + 1, ystop - 1)) return rc;
+        if (xstop > xstart)
+            if (int rc = box(xstop, xstop, ystart + 1, ystop - 1)) return rc;
+    }
     DLESM_HIP_TRY(hipEventRecord(p->ev_frame, s));
     // 2. grouped exchange of the three new fields on the side stream ...
     DLESM_HIP_TRY(hipStreamWaitEvent(side, p->ev_frame, 0));
     double *fields[3] = {unew, vnew, pnew};
-    if (int rc = exchange_on(p, fields, 3, DLESM_DIRS_ALL, side)) return rc;
+    if (int rc = exchange_on(p, fields, 3, DLESM_DIRS_ALL, side, prepacked)) return rc;
     DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
     // 3. ... behind the interior
     if (int rc = box(xstart + 1, xstop - 1, ystart + 1, ystop - 1)) return rc;

@@ -79,6 +79,18 @@ struct FramePack {
 };
 int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop,
                           int ystart, int ystop, hipStream_t s, const FramePack *pack = nullptr);
+// the one-cell frame of the shallow-water step in ONE launch (one cell per thread), its west/east
+// columns also written into the send buffers of the three new fields
+struct FramePack3 {
+    FramePack::Col s[FramePack::MAXS];
+    int n;
+    double *buf[3];               // send buffers of unew, vnew, pnew
+};
+int launch_shallow_frame(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                         const double *u, const double *v, const double *p, const double *uold,
+                         const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
+                         const FramePack3 *pack, hipStream_t s);
+
 // the frame as the first workgroups of the interior launch (jacobi5_tile_framed): when their last
 // one is done, `seq` is stored to `flag` (device memory; frame_flag_wait sleeps on it)
 struct FrameJob {

@@ -298,14 +298,11 @@ __device__ __forceinline__ long frame_cells(int w, int h)
 }
 // WT: store with device-scope write-through (relaxed agent-scope atomic stores), for frame cells that
 // another kernel reads while this one is still running.
-template <bool WT>
-__device__ __forceinline__ void frame_cell(long t, const double *__restrict__ in, double *__restrict__ out,
-                                           int ld, int x0, int x1, int y0, int y1, const FramePack &pk,
-                                           const FrameJob *fj = nullptr)
+// frame cell number t -> (i, j): south row, north row, then the west and east columns between them
+__device__ __forceinline__ void frame_index(long t, int x0, int x1, int y0, int y1, int &i, int &j)
 {
     const int w = x1 - x0 + 1, h = y1 - y0 + 1;
     const int ncol = h > 2 ? h - 2 : 0, nrows = h > 1 ? 2 : 1;
-    int i, j;
     if (t < (long)nrows * w) {
         j = t < w ? y0 : y1;
         i = x0 + (int)(t % w);
@@ -314,6 +311,15 @@ __device__ __forceinline__ void frame_cell(long t, const double *__restrict__ in
         if (w == 1) { i = x0; j = y0 + 1 + (int)k; }
         else { i = k < ncol ? x0 : x1; j = y0 + 1 + (int)(k % ncol); }
     }
+}
+
+template <bool WT>
+__device__ __forceinline__ void frame_cell(long t, const double *__restrict__ in, double *__restrict__ out,
+                                           int ld, int x0, int x1, int y0, int y1, const FramePack &pk,
+                                           const FrameJob *fj = nullptr)
+{
+    int i, j;
+    frame_index(t, x0, x1, y0, y1, i, j);
     const size_t o = (size_t)j * ld + i;
     // WT (frame inside the interior launch): the operand OUTSIDE the box is a halo cell the exchange may
     // have written after this kernel started -- read it at device scope, past this XCD's L2.  The
@@ -790,16 +796,11 @@ int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xst
 // 3 written = 72 B/cell of algorithmic traffic.
 // First, direct form: neighbours come from L1/L2.
 // ===========================================================================
-__global__ __launch_bounds__(256) void shallow_step_direct(
-    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, const double *__restrict__ u,
-    const double *__restrict__ v, const double *__restrict__ p, const double *__restrict__ uold,
-    const double *__restrict__ vold, const double *__restrict__ pold, double *__restrict__ unew,
-    double *__restrict__ vnew, double *__restrict__ pnew)
+__device__ __forceinline__ void shallow_point_ne(
+    const dlesm_sw_params &q, int ld, size_t o, const double *__restrict__ u, const double *__restrict__ v,
+    const double *__restrict__ p, const double *__restrict__ uold, const double *__restrict__ vold,
+    const double *__restrict__ pold, double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew)
 {
-    const int i = x0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = y0 + blockIdx.y;
-    if (i > x1 || j > y1) return;
-    const size_t o = (size_t)j * ld + i;
 #define U_(di, dj) u[o + (di) + (long)(dj) * ld]
 #define V_(di, dj) v[o + (di) + (long)(dj) * ld]
 #define P_(di, dj) p[o + (di) + (long)(dj) * ld]
@@ -827,6 +828,74 @@ __global__ __launch_bounds__(256) void shallow_step_direct(
 #undef CV
 #undef Z
 #undef H
+}
+
+__global__ __launch_bounds__(256) void shallow_step_direct(
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, const double *__restrict__ u,
+    const double *__restrict__ v, const double *__restrict__ p, const double *__restrict__ uold,
+    const double *__restrict__ vold, const double *__restrict__ pold, double *__restrict__ unew,
+    double *__restrict__ vnew, double *__restrict__ pnew)
+{
+    const int i = x0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > x1) return;
+    for (int j = y0 + blockIdx.y; j <= y1; j += gridDim.y)
+        shallow_point_ne(q, ld, (size_t)j * ld + i, u, v, p, uold, vold, pold, unew, vnew, pnew);
+}
+
+// the same for boxes a few columns wide and many rows tall (frame columns): lanes run along j
+__global__ __launch_bounds__(256) void shallow_step_direct_cols(
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, const double *__restrict__ u,
+    const double *__restrict__ v, const double *__restrict__ p, const double *__restrict__ uold,
+    const double *__restrict__ vold, const double *__restrict__ pold, double *__restrict__ unew,
+    double *__restrict__ vnew, double *__restrict__ pnew)
+{
+    const int j = y0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > y1) return;
+    for (int i = x0; i <= x1; i++)
+        shallow_point_ne(q, ld, (size_t)j * ld + i, u, v, p, uold, vold, pold, unew, vnew, pnew);
+}
+
+// the one-cell frame of the box (the cells a neighbour needs first in the distributed step): one cell
+// per thread, all four sides in ONE launch; west/east column cells also go into the send buffers of
+// the three new fields, in the pack loop's j order (parallel_comms_mod.f90:1678-1683)
+__global__ __launch_bounds__(256) void shallow_frame_k(
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, const double *__restrict__ u,
+    const double *__restrict__ v, const double *__restrict__ p, const double *__restrict__ uold,
+    const double *__restrict__ vold, const double *__restrict__ pold, double *__restrict__ unew,
+    double *__restrict__ vnew, double *__restrict__ pnew, FramePack3 pk)
+{
+    const long total = frame_cells(x1 - x0 + 1, y1 - y0 + 1);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        int i, j;
+        frame_index(t, x0, x1, y0, y1, i, j);
+        const size_t o = (size_t)j * ld + i;
+        shallow_point_ne(q, ld, o, u, v, p, uold, vold, pold, unew, vnew, pnew);
+        for (int k = 0; k < pk.n; k++)
+            if (i == pk.s[k].i && j >= pk.s[k].j0 && j < pk.s[k].j0 + pk.s[k].nj) {
+                const long slot = pk.s[k].off + (j - pk.s[k].j0);
+                pk.buf[0][slot] = unew[o];
+                pk.buf[1][slot] = vnew[o];
+                pk.buf[2][slot] = pnew[o];
+            }
+    }
+}
+
+int launch_shallow_frame(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                         const double *u, const double *v, const double *p, const double *uold,
+                         const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
+                         const FramePack3 *pack, hipStream_t s)
+{
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("shallow frame", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    const long cells = 2L * (xstop - xstart + 1) + 2L * (ystop - ystart + 1);
+    int blocks = (int)((cells + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    FramePack3 pk{};
+    if (pack) pk = *pack;
+    hipLaunchKernelGGL(shallow_frame_k, dim3(blocks), dim3(256), 0, s, q, ld, xstart - 1, xstop - 1, ystart - 1,
+                       ystop - 1, u, v, p, uold, vold, pold, unew, vnew, pnew, pk);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
 }
 
 // ===========================================================================
@@ -1049,17 +1118,23 @@ extern "C" int dlesm_shallow_step_f64(const dlesm_sw_params *q, int ld, int ny, 
         aligned = aligned && ((uintptr_t)f % 16 == 0);
     // sw_kernel: 0 (default) = register-tiled sweep of dlesm_shallow.hip, 73.7 % of HBM peak at
     // 8192^2; 1 = direct form, 62 % (scripts/shallow_probe.py, profiles/r01_shallow_*.txt)
-    if (aligned && tuning("sw_kernel", 0) == 0) {
+    // boxes a few columns wide (the west/east frame columns of the distributed step): a wave tile would load
+    // 128 columns x 4 rows of three arrays for two useful cells -- one cell per thread moves 6 x less
+    const bool thin = nx <= tuning("sw_thin_box", 8) && nyb > 8;
+    if (aligned && tuning("sw_kernel", 0) == 0 && !thin) {
         launch_shallow_tile(*q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold,
                             unew, vnew, pnew, (hipStream_t)stream);
         DLESM_HIP_TRY(hipGetLastError());
         return DLESM_OK;
     }
-    // odd leading dimension: direct form, neighbours through L1/L2
-    dim3 block(256), grid((nx + 255) / 256, nyb);
-    DLESM_REQUIRE(nyb <= 65535, "box too tall for the direct kernel");
-    hipLaunchKernelGGL(shallow_step_direct, grid, block, 0, (hipStream_t)stream, *q, ld, xstart - 1,
-                       xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold, unew, vnew, pnew);
+    // odd leading dimension / thin boxes: direct form, neighbours through L1/L2
+    if (thin)
+        hipLaunchKernelGGL(shallow_step_direct_cols, dim3((nyb + 255) / 256), dim3(256), 0, (hipStream_t)stream, *q, ld,
+                           xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold, unew, vnew, pnew);
+    else
+        hipLaunchKernelGGL(shallow_step_direct, dim3((nx + 255) / 256, nyb > 4096 ? 4096 : nyb), dim3(256), 0,
+                           (hipStream_t)stream, *q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold,
+                           vold, pold, unew, vnew, pnew);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }

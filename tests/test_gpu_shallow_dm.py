@@ -27,11 +27,15 @@ def D():
 
 
 @pytest.mark.parametrize("nx,ny,alignment", [(1, 1, 2), (2, 3, 2), (5, 1, 2), (1, 7, 2), (40, 33, 8), (257, 66, 64),
-                                             (130, 9, None)])
-def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment):
+                                             (130, 9, None), (700, 300, 64)])
+@pytest.mark.parametrize("one_launch_frame", [1, 0])
+def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame):
+    """one_launch_frame: the ring of the box in one launch that also fills the send buffers (default)
+    / the round-1 form, four thin boxes + pack kernels"""
     import torch
     from dm_overhead import loopback_tables
     L = D._cabi.lib()
+    L.dlesm_set_tuning(b"sw_dm_frame", one_launch_frame)
     if alignment is None:
         os.environ.pop("DL_ESM_ALIGNMENT", None)
     else:
@@ -83,3 +87,4 @@ def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment):
         assert np.array_equal(F[n].get_data(), want[n]), n
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
     g._halo_plan = None
+    L.dlesm_set_tuning(b"sw_dm_frame", 1)
