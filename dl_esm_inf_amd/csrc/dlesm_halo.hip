@@ -425,7 +425,7 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
     // the one-launch form on the same stream, its frame workgroups wait for that exchange on the
     // device (halo_flag) and the caller's stream needs no event wait at all; otherwise join now.
     const bool can_chain = pipelined && p->pending && p->pending_stream == s && p->frame_flag &&
-                           tuning("j5_dm_fused", 1) && tuning("j5_dm_chain", 1);
+                           tuning("j5_dm_fused", 1) && tuning("j5_dm_chain", 1) && streams_run_concurrently(s);
     if (!can_chain)
         if (int rc = join_pending(p, s)) return rc;
     // The 5-point stencil never reads a corner halo: exchange the four edge directions only
@@ -456,7 +456,7 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
     bool fused = false;
     DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
                   "an earlier distributed step gave up waiting for a flag (frame or halo wait timed out)");
-    if (p->frame_flag && tuning("j5_dm_fused", 1)) {
+    if (p->frame_flag && tuning("j5_dm_fused", 1) && streams_run_concurrently(s)) {
         FrameJob job{};
         job.pk = fp;
         job.counter = p->frame_counter;

@@ -117,6 +117,9 @@ int launch_stencil5_framed(const double *in, double *out, int ld, int ny, int xs
                            int ystop, FrameJob job, hipStream_t s, bool *fused);
 // park stream `s` (one sleeping wave) until *flag >= seq; bounded, see frame_flag_wait
 int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s);
+// true when kernels of two streams execute side by side in this process (probed once; false under
+// kernel-serialising tools): precondition of the one-launch / time-loop forms of the distributed step
+bool streams_run_concurrently(hipStream_t callers);
 // *flag = seq, stream ordered (one thread): publishes "the exchange before this point has landed"
 int launch_flag_set(unsigned long long *flag, unsigned long long seq, hipStream_t s);
 

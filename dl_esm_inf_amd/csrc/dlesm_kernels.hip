@@ -719,13 +719,14 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
 // bounded (about 20 s of the 100 MHz real-time counter): if the frame never reports -- which only a
 // failed launch could cause -- the kernel gives up, raises *timed_out (pinned host memory, checked
 // by the next step call) and lets the stream drain instead of hanging the device.
-__global__ void frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out)
+__global__ void frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out,
+                                unsigned long long max_ticks)
 {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
         __builtin_amdgcn_s_sleep(64);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {   // ~20 s of the 100 MHz counter
+        if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) {        // 100 MHz counter
             __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
@@ -746,9 +747,42 @@ int launch_flag_set(unsigned long long *flag, unsigned long long seq, hipStream_
 
 int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(frame_flag_wait, dim3(1), dim3(64), 0, s, flag, seq, timed_out);
+    hipLaunchKernelGGL(frame_flag_wait, dim3(1), dim3(64), 0, s, flag, seq, timed_out, 2000000000ull);   // ~20 s
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
+}
+
+// Do kernels of two streams really run side by side in this process?  The one-launch and time-loop forms
+// of the distributed step park a waiting kernel on the side stream while the kernel that will release it
+// runs on the caller's stream; under a tool that serialises kernel execution (rocprofv3 --pmc,
+// AMD_SERIALIZE_KERNEL) the waiter would run alone and only leave through its time-out (seen: a --pmc
+// run of the loop-back script crawled from time-out to time-out).  Probe once per process: a waiter
+// with a 50 ms bound on the side stream, the releasing store on the caller's stream.
+bool streams_run_concurrently(hipStream_t callers)
+{
+    static int cached = -1;
+    if (cached >= 0) return cached != 0;
+    cached = 0;
+    unsigned long long *flag = nullptr;
+    int *timed_out = nullptr;
+    if (hipMalloc((void **)&flag, 64) != hipSuccess) return false;
+    if (hipHostMalloc((void **)&timed_out, sizeof(int), hipHostMallocMapped) != hipSuccess) {
+        (void)hipFree(flag);
+        return false;
+    }
+    *timed_out = 0;
+    hipStream_t a = side_stream(), b = callers;          // the two streams the step itself will use
+    bool ok = hipMemset(flag, 0, 64) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(frame_flag_wait, dim3(1), dim3(64), 0, a, flag, 1ull, timed_out, 5000000ull);   // 50 ms
+        hipLaunchKernelGGL(flag_set, dim3(1), dim3(64), 0, b, flag, 1ull);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(a) == hipSuccess &&
+             hipStreamSynchronize(b) == hipSuccess;
+    }
+    if (ok && *(volatile int *)timed_out == 0) cached = 1;
+    (void)hipFree(flag);
+    (void)hipHostFree(timed_out);
+    return cached != 0;
 }
 
 int launch_stencil5_framed(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart,
