@@ -772,6 +772,7 @@ bool streams_run_concurrently(hipStream_t callers)
     }
     *timed_out = 0;
     hipStream_t a = side_stream(), b = callers;          // the two streams the step itself will use
+    // one-time: drain everything first, so that the probe's two kernels start at once
     bool ok = hipMemset(flag, 0, 64) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(frame_flag_wait, dim3(1), dim3(64), 0, a, flag, 1ull, timed_out, 5000000ull);   // 50 ms
