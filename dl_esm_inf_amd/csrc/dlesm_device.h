@@ -1,0 +1,88 @@
+// Device-side helpers shared by the kernels of several translation units (frame numbering, the
+// one-cell shallow-water update).  Included after dlesm_internal.h.
+#ifndef DLESM_DEVICE_H
+#define DLESM_DEVICE_H
+
+#include "dlesm_internal.h"
+
+namespace dlesm {
+
+// One cell of the one-cell-wide frame of the box (x0:x1, y0:y1), numbered t = 0 .. frame_cells-1:
+// south row, north row, then the west and east columns between them.  Cells of a west/east column
+// that a neighbour will receive also go into their send-buffer slot, in the j order of the pack
+// loop (parallel_comms_mod.f90:1678-1683).
+__device__ __forceinline__ long frame_cells(int w, int h)
+{
+    const int ncol = h > 2 ? h - 2 : 0, nrows = h > 1 ? 2 : 1;
+    return (long)nrows * w + 2L * ncol * (w > 1 ? 1 : 0) + (w == 1 ? ncol : 0);
+}
+
+// frame cell number t -> (i, j): south row, north row, then the west and east columns between them
+__device__ __forceinline__ void frame_index(long t, int x0, int x1, int y0, int y1, int &i, int &j)
+{
+    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+    const int ncol = h > 2 ? h - 2 : 0, nrows = h > 1 ? 2 : 1;
+    if (t < (long)nrows * w) {
+        j = t < w ? y0 : y1;
+        i = x0 + (int)(t % w);
+    } else {
+        long k = t - (long)nrows * w;
+        if (w == 1) { i = x0; j = y0 + 1 + (int)k; }
+        else { i = k < ncol ? x0 : x1; j = y0 + 1 + (int)(k % ncol); }
+    }
+}
+
+struct SwPoint { double un, vn, pn; };
+
+// the NE-offset update of ONE cell, operands straight from memory: the
+// expression trees of the oracle's compute_*_code
+__device__ __forceinline__ SwPoint shallow_values_ne(
+    const dlesm_sw_params &q, int ld, size_t o, const double *__restrict__ u, const double *__restrict__ v,
+    const double *__restrict__ p, const double *__restrict__ uold, const double *__restrict__ vold,
+    const double *__restrict__ pold)
+{
+#define U_(di, dj) u[o + (di) + (long)(dj) * ld]
+#define V_(di, dj) v[o + (di) + (long)(dj) * ld]
+#define P_(di, dj) p[o + (di) + (long)(dj) * ld]
+    // cu(a,b) = 0.5*(p(a+1,b)+p(a,b))*u(a,b) ; cv(a,b) = 0.5*(p(a,b+1)+p(a,b))*v(a,b)
+#define CU(di, dj) (0.5 * (P_((di) + 1, dj) + P_(di, dj)) * U_(di, dj))
+#define CV(di, dj) (0.5 * (P_(di, (dj) + 1) + P_(di, dj)) * V_(di, dj))
+    // z(a,b) at the NE corner of T(a,b)
+#define Z(di, dj)                                                                                   \
+    ((q.fsdx * (V_((di) + 1, dj) - V_(di, dj)) - q.fsdy * (U_(di, (dj) + 1) - U_(di, dj))) /         \
+     (P_(di, dj) + P_((di) + 1, dj) + P_((di) + 1, (dj) + 1) + P_(di, (dj) + 1)))
+#define H(di, dj)                                                                                   \
+    (P_(di, dj) + 0.25 * (U_(di, dj) * U_(di, dj) + U_((di)-1, dj) * U_((di)-1, dj) +                \
+                          V_(di, dj) * V_(di, dj) + V_(di, (dj)-1) * V_(di, (dj)-1)))
+    const double z00 = Z(0, 0), z0m = Z(0, -1), zm0 = Z(-1, 0);
+    const double h00 = H(0, 0), hp0 = H(1, 0), h0p = H(0, 1);
+    const double cu00 = CU(0, 0), cum0 = CU(-1, 0), cu0p = CU(0, 1), cump = CU(-1, 1);
+    const double cv00 = CV(0, 0), cv0m = CV(0, -1), cvp0 = CV(1, 0), cvpm = CV(1, -1);
+    SwPoint r;
+    r.un = uold[o] + q.tdts8 * (z00 + z0m) * (cvp0 + cv00 + cv0m + cvpm) - q.tdtsdx * (hp0 - h00);
+    r.vn = vold[o] - q.tdts8 * (z00 + zm0) * (cu0p + cump + cum0 + cu00) - q.tdtsdy * (h0p - h00);
+    r.pn = pold[o] - q.tdtsdx * (cu00 - cum0) - q.tdtsdy * (cv00 - cv0m);
+#undef U_
+#undef V_
+#undef P_
+#undef CU
+#undef CV
+#undef Z
+#undef H
+    return r;
+}
+
+__device__ __forceinline__ void shallow_point_ne(
+    const dlesm_sw_params &q, int ld, size_t o, const double *__restrict__ u, const double *__restrict__ v,
+    const double *__restrict__ p, const double *__restrict__ uold, const double *__restrict__ vold,
+    const double *__restrict__ pold, double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew)
+{
+    const SwPoint r = shallow_values_ne(q, ld, o, u, v, p, uold, vold, pold);
+    unew[o] = r.un;
+    vnew[o] = r.vn;
+    pnew[o] = r.pn;
+}
+
+} // namespace dlesm
+
+#endif

@@ -615,12 +615,13 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     };
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) return box(xstart, xstop, ystart, ystop);
-    // 1. frame: the one-cell ring of the box in ONE launch (one cell per thread, all four sides), its
-    //    west/east columns written straight into the send buffers of the three new fields -- no pack
-    //    launches.  sw_dm_frame=0: the round-1 form (four thin boxes + pack kernels).
+    // 1. frame: the one-cell ring of the box, one cell per thread, all four sides, its west/east columns
+    //    written straight into the send buffers of the three new fields -- no pack launches.
+    //    sw_dm_frame=0: the round-1 form (four thin boxes + pack kernels).
     bool prepacked = false;
-    if (tuning("sw_dm_frame", 1)) {
-        FramePack3 fp{};
+    FramePack3 fp{};
+    const bool one_frame = tuning("sw_dm_frame", 1) != 0;
+    if (one_frame) {
         prepacked = true;
         for (const Msg &m : p->sends) {
             if (m.off < 0) continue;
@@ -635,6 +636,32 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
         } else {
             fp.n = 0;
         }
+    }
+    double *fields[3] = {unew, vnew, pnew};
+    // One launch (as the Jacobi step): the ring as the first workgroups of the interior sweep, a device flag
+    // hands it to the exchange on the side stream -- no frame launch, no event record on the caller's stream.
+    DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
+                  "an earlier distributed step gave up waiting for a flag (frame wait timed out)");
+    if (one_frame && p->frame_flag && tuning("sw_dm_fused", 1) && streams_run_concurrently(s)) {
+        SwFrameJob job{};
+        job.pk = fp;
+        job.counter = p->frame_counter;
+        job.flag = p->frame_flag;
+        job.seq = p->frame_seq + 1;
+        bool fused = false;
+        if (int rc = launch_shallow_framed(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew,
+                                           pnew, job, s, &fused))
+            return rc;
+        if (fused) {
+            p->frame_seq = job.seq;
+            if (int rc = launch_frame_flag_wait(p->frame_flag, job.seq, p->frame_timed_out, side)) return rc;
+            if (int rc = exchange_on(p, fields, 3, DLESM_DIRS_ALL, side, prepacked)) return rc;
+            DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
+            DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
+            return DLESM_OK;
+        }
+    }
+    if (one_frame) {
         if (int rc = launch_shallow_frame(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew,
                                           pnew, prepacked ? &fp : nullptr, s))
             return rc;
@@ -649,7 +676,6 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     DLESM_HIP_TRY(hipEventRecord(p->ev_frame, s));
     // 2. grouped exchange of the three new fields on the side stream ...
     DLESM_HIP_TRY(hipStreamWaitEvent(side, p->ev_frame, 0));
-    double *fields[3] = {unew, vnew, pnew};
     if (int rc = exchange_on(p, fields, 3, DLESM_DIRS_ALL, side, prepacked)) return rc;
     DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
     // 3. ... behind the interior

@@ -132,11 +132,26 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
 // block shape (waves per workgroup, padded tiles per row) of a linear tile sweep
 void choose_block_shape(int *nxw_io, int *tpb_out, int prefer = 0);
 int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart, int ystop, int ring);
+// the shallow-water frame as the first workgroups of the interior launch (shallow_tile_framed)
+struct SwFrameJob {
+    FramePack3 pk;
+    int fx0, fx1, fy0, fy1;       // 0-based frame box
+    int nblocks;                  // filled in by the launcher
+    unsigned *counter;
+    unsigned long long *flag;
+    unsigned long long seq;
+};
 // shallow-water step, register-tiled linear sweep (dlesm_shallow.hip); 0-based inclusive box
 void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,
                          const double *u, const double *v, const double *p, const double *uold,
                          const double *vold, const double *pold, double *unew, double *vnew,
-                         double *pnew, hipStream_t s, bool sw_offset = false);
+                         double *pnew, hipStream_t s, bool sw_offset = false, SwFrameJob *fj = nullptr);
+// frame of the box + interior sweep of the NE shallow-water step in one launch; *fused = false (nothing
+// launched) when the arrays do not qualify for the tile kernel
+int launch_shallow_framed(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                          const double *u, const double *v, const double *p, const double *uold,
+                          const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
+                          SwFrameJob job, hipStream_t s, bool *fused);
 
 } // namespace dlesm
 

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "dlesm_internal.h"
+#include "dlesm_device.h"
 
 // 1: tile indices of jacobi5_tile on the scalar unit (readfirstlane of the wave number).  Measured
 // A/B on one box at 16384^2: 0.732 ms per launch against 0.718 ms with the per-lane form -- the
@@ -287,32 +288,8 @@ __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ 
     jacobi5_tile_body<VEC, R, NT>(in, out, ld, x0, x1, y0, y1, c_first, nxw, flags, blockIdx.x);
 }
 
-// One cell of the one-cell-wide frame of the box (x0:x1, y0:y1), numbered t = 0 .. frame_cells-1:
-// south row, north row, then the west and east columns between them.  Cells of a west/east column
-// that a neighbour will receive also go into their send-buffer slot, in the j order of the pack
-// loop (parallel_comms_mod.f90:1678-1683).
-__device__ __forceinline__ long frame_cells(int w, int h)
-{
-    const int ncol = h > 2 ? h - 2 : 0, nrows = h > 1 ? 2 : 1;
-    return (long)nrows * w + 2L * ncol * (w > 1 ? 1 : 0) + (w == 1 ? ncol : 0);
-}
 // WT: store with device-scope write-through (relaxed agent-scope atomic stores), for frame cells that
 // another kernel reads while this one is still running.
-// frame cell number t -> (i, j): south row, north row, then the west and east columns between them
-__device__ __forceinline__ void frame_index(long t, int x0, int x1, int y0, int y1, int &i, int &j)
-{
-    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-    const int ncol = h > 2 ? h - 2 : 0, nrows = h > 1 ? 2 : 1;
-    if (t < (long)nrows * w) {
-        j = t < w ? y0 : y1;
-        i = x0 + (int)(t % w);
-    } else {
-        long k = t - (long)nrows * w;
-        if (w == 1) { i = x0; j = y0 + 1 + (int)k; }
-        else { i = k < ncol ? x0 : x1; j = y0 + 1 + (int)(k % ncol); }
-    }
-}
-
 template <bool WT>
 __device__ __forceinline__ void frame_cell(long t, const double *__restrict__ in, double *__restrict__ out,
                                            int ld, int x0, int x1, int y0, int y1, const FramePack &pk,
@@ -831,40 +808,6 @@ int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xst
 // 3 written = 72 B/cell of algorithmic traffic.
 // First, direct form: neighbours come from L1/L2.
 // ===========================================================================
-__device__ __forceinline__ void shallow_point_ne(
-    const dlesm_sw_params &q, int ld, size_t o, const double *__restrict__ u, const double *__restrict__ v,
-    const double *__restrict__ p, const double *__restrict__ uold, const double *__restrict__ vold,
-    const double *__restrict__ pold, double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew)
-{
-#define U_(di, dj) u[o + (di) + (long)(dj) * ld]
-#define V_(di, dj) v[o + (di) + (long)(dj) * ld]
-#define P_(di, dj) p[o + (di) + (long)(dj) * ld]
-    // cu(a,b) = 0.5*(p(a+1,b)+p(a,b))*u(a,b) ; cv(a,b) = 0.5*(p(a,b+1)+p(a,b))*v(a,b)
-#define CU(di, dj) (0.5 * (P_((di) + 1, dj) + P_(di, dj)) * U_(di, dj))
-#define CV(di, dj) (0.5 * (P_(di, (dj) + 1) + P_(di, dj)) * V_(di, dj))
-    // z(a,b) at the NE corner of T(a,b)
-#define Z(di, dj)                                                                                   \
-    ((q.fsdx * (V_((di) + 1, dj) - V_(di, dj)) - q.fsdy * (U_(di, (dj) + 1) - U_(di, dj))) /         \
-     (P_(di, dj) + P_((di) + 1, dj) + P_((di) + 1, (dj) + 1) + P_(di, (dj) + 1)))
-#define H(di, dj)                                                                                   \
-    (P_(di, dj) + 0.25 * (U_(di, dj) * U_(di, dj) + U_((di)-1, dj) * U_((di)-1, dj) +                \
-                          V_(di, dj) * V_(di, dj) + V_(di, (dj)-1) * V_(di, (dj)-1)))
-    const double z00 = Z(0, 0), z0m = Z(0, -1), zm0 = Z(-1, 0);
-    const double h00 = H(0, 0), hp0 = H(1, 0), h0p = H(0, 1);
-    const double cu00 = CU(0, 0), cum0 = CU(-1, 0), cu0p = CU(0, 1), cump = CU(-1, 1);
-    const double cv00 = CV(0, 0), cv0m = CV(0, -1), cvp0 = CV(1, 0), cvpm = CV(1, -1);
-    unew[o] = uold[o] + q.tdts8 * (z00 + z0m) * (cvp0 + cv00 + cv0m + cvpm) - q.tdtsdx * (hp0 - h00);
-    vnew[o] = vold[o] - q.tdts8 * (z00 + zm0) * (cu0p + cump + cum0 + cu00) - q.tdtsdy * (h0p - h00);
-    pnew[o] = pold[o] - q.tdtsdx * (cu00 - cum0) - q.tdtsdy * (cv00 - cv0m);
-#undef U_
-#undef V_
-#undef P_
-#undef CU
-#undef CV
-#undef Z
-#undef H
-}
-
 __global__ __launch_bounds__(256) void shallow_step_direct(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, const double *__restrict__ u,
     const double *__restrict__ v, const double *__restrict__ p, const double *__restrict__ uold,

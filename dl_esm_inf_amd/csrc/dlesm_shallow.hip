@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "dlesm_internal.h"
+#include "dlesm_device.h"
 
 namespace dlesm {
 
@@ -56,16 +57,16 @@ template <bool DPP> __device__ __forceinline__ V2 west_of(const V2 &a) { return 
 // bit 1: the new time level is stored non-temporally.  u, v, p keep the default policy: their
 // rows are re-read by the tile below.
 template <int R, bool DPP, int NTM>
-__global__ __launch_bounds__(512) void shallow_tile(
-    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
+__device__ __forceinline__ void shallow_tile_body(
+    const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
     const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
-    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew)
+    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, unsigned block)
 {
     auto east = [](const V2 &a) { return east_of<DPP>(a); };
     auto west = [](const V2 &a) { return west_of<DPP>(a); };
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int w = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int xw = w % nxw, strip = w / nxw;
     const int jb = y0 + strip * R;
     if (jb > y1) return;
@@ -169,6 +170,63 @@ __global__ __launch_bounds__(512) void shallow_tile(
     }
 }
 
+
+template <int R, bool DPP, int NTM>
+__global__ __launch_bounds__(512) void shallow_tile(
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
+    const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
+    const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
+    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew)
+{
+    shallow_tile_body<R, DPP, NTM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, blockIdx.x);
+}
+
+// The distributed shallow-water step in ONE launch on the caller's stream (as jacobi5_tile_framed): the
+// first fj.nblocks workgroups compute the one-cell ring of the box (fx0:fx1, fy0:fy1), one cell per thread
+// from memory, store it write-through at device scope -- the exchange reads it while this kernel is still
+// running -- into the fields and, for the west/east columns, into the three send buffers; the last of them
+// publishes `seq` in the flag the side stream's waiter sleeps on.  All other workgroups are the ordinary
+// tile sweep over the interior.
+template <int R, bool DPP, int NTM>
+__global__ __launch_bounds__(512) void shallow_tile_framed(
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
+    const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
+    const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
+    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, SwFrameJob fj)
+{
+    if (blockIdx.x >= (unsigned)fj.nblocks) {
+        shallow_tile_body<R, DPP, NTM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew,
+                                       blockIdx.x - fj.nblocks);
+        return;
+    }
+    auto put = [](double *ptr, double val) { __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const long total = frame_cells(fj.fx1 - fj.fx0 + 1, fj.fy1 - fj.fy0 + 1);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)fj.nblocks * blockDim.x) {
+        int i, j;
+        frame_index(t, fj.fx0, fj.fx1, fj.fy0, fj.fy1, i, j);
+        const size_t o = (size_t)j * ld + i;
+        const SwPoint r = shallow_values_ne(q, ld, o, u, v, p, uold, vold, pold);
+        put(unew + o, r.un);
+        put(vnew + o, r.vn);
+        put(pnew + o, r.pn);
+        for (int k = 0; k < fj.pk.n; k++)
+            if (i == fj.pk.s[k].i && j >= fj.pk.s[k].j0 && j < fj.pk.s[k].j0 + fj.pk.s[k].nj) {
+                const long slot = fj.pk.s[k].off + (j - fj.pk.s[k].j0);
+                put(fj.pk.buf[0] + slot, r.un);
+                put(fj.pk.buf[1] + slot, r.vn);
+                put(fj.pk.buf[2] + slot, r.pn);
+            }
+    }
+    __builtin_amdgcn_s_waitcnt(0);        // this wave's stores have been acknowledged ...
+    __syncthreads();                      // ... and those of every wave of the group ...
+    if (threadIdx.x == 0) {               // ... before the group is counted as done
+        const unsigned done = __hip_atomic_fetch_add(fj.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (unsigned)fj.nblocks - 1) {
+            __hip_atomic_store(fj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fj.flag, fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 // The SW-offset step in the same wave-tile form: the mirror image of
 // shallow_tile -- cu, cv, z look WEST/SOUTH, h looks EAST/NORTH -- with its own expression trees
@@ -337,7 +395,7 @@ static void sw_rule_shape(int ld, int x0, int x1, int *nxw_out, int *tpb_out)
 void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,
                          const double *u, const double *v, const double *p, const double *uold,
                          const double *vold, const double *pold, double *unew, double *vnew,
-                         double *pnew, hipStream_t s, bool sw_offset)
+                         double *pnew, hipStream_t s, bool sw_offset, SwFrameJob *fj)
 {
     const int cb = x0 / 2;                               // first chunk holding an output column
     int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & 3;
@@ -355,6 +413,19 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     const long tiles = (long)nxw * strips;
     const unsigned grid = (unsigned)((tiles + tpb - 1) / tpb);
     const bool dpp = tuning("sw_dpp", 1);
+    if (fj) {   // NE offset, R = 2, the default wave shifts: the one form the distributed step uses
+        const long cells = 2L * (fj->fx1 - fj->fx0 + 1) + 2L * (fj->fy1 - fj->fy0 + 1);
+        long nb = ((cells + 64 * tpb - 1) / (64 * tpb) + 7) & ~7L;    // a multiple of 8: tile groups keep their XCD
+        fj->nblocks = (int)(nb < 8 ? 8 : nb > 512 ? 512 : nb);
+        const unsigned g2 = grid + (unsigned)fj->nblocks;
+        switch (ntm) {
+        case 1: hipLaunchKernelGGL((shallow_tile_framed<2, true, 1>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj); break;
+        case 2: hipLaunchKernelGGL((shallow_tile_framed<2, true, 2>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj); break;
+        case 3: hipLaunchKernelGGL((shallow_tile_framed<2, true, 3>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj); break;
+        default: hipLaunchKernelGGL((shallow_tile_framed<2, true, 0>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj); break;
+        }
+        return;
+    }
 #define DLESM_SW3(RR, DD, NN)                                                                                  \
     do {                                                                                                       \
         if (sw_offset)                                                                                         \
@@ -387,6 +458,27 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
 }
 
 } // namespace dlesm
+
+int dlesm::launch_shallow_framed(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart,
+                                 int ystop, const double *u, const double *v, const double *p, const double *uold,
+                                 const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
+                                 SwFrameJob job, hipStream_t s, bool *fused)
+{
+    *fused = false;
+    if (xstop - xstart < 2 || ystop - ystart < 2) return DLESM_OK;          // no interior: two-launch path
+    if (int rc = check_box("dlesm_shallow_step_dm", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    bool aligned = ld % 2 == 0 || (xstop - 2) + 1 <= 2 * (ld / 2) - 1;
+    for (const double *f : {u, v, p, uold, vold, pold, (const double *)unew, (const double *)vnew,
+                            (const double *)pnew})
+        aligned = aligned && ((uintptr_t)f % 16 == 0);
+    if (!aligned || tuning("sw_kernel", 0) != 0 || tuning("sw_tile_rows", 2) != 2 || !tuning("sw_dpp", 1)) return DLESM_OK;
+    job.fx0 = xstart - 1, job.fx1 = xstop - 1, job.fy0 = ystart - 1, job.fy1 = ystop - 1;
+    launch_shallow_tile(q, ld, xstart, xstop - 2, ystart, ystop - 2, u, v, p, uold, vold, pold, unew, vnew, pnew, s,
+                        false, &job);
+    DLESM_HIP_TRY(hipGetLastError());
+    *fused = true;
+    return DLESM_OK;
+}
 
 using namespace dlesm;
 

@@ -28,14 +28,16 @@ def D():
 
 @pytest.mark.parametrize("nx,ny,alignment", [(1, 1, 2), (2, 3, 2), (5, 1, 2), (1, 7, 2), (40, 33, 8), (257, 66, 64),
                                              (130, 9, None), (700, 300, 64)])
-@pytest.mark.parametrize("one_launch_frame", [1, 0])
-def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame):
-    """one_launch_frame: the ring of the box in one launch that also fills the send buffers (default)
-    / the round-1 form, four thin boxes + pack kernels"""
+@pytest.mark.parametrize("one_launch_frame,fused", [(1, 1), (1, 0), (0, 0)])
+def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, fused):
+    """fused: the ring as the first workgroups of the interior launch + device flag (default) /
+    one_launch_frame: the ring in its own launch that also fills the send buffers / the round-1 form,
+    four thin boxes + pack kernels"""
     import torch
     from dm_overhead import loopback_tables
     L = D._cabi.lib()
     L.dlesm_set_tuning(b"sw_dm_frame", one_launch_frame)
+    L.dlesm_set_tuning(b"sw_dm_fused", fused)
     if alignment is None:
         os.environ.pop("DL_ESM_ALIGNMENT", None)
     else:
@@ -88,3 +90,4 @@ def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame):
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
     g._halo_plan = None
     L.dlesm_set_tuning(b"sw_dm_frame", 1)
+    L.dlesm_set_tuning(b"sw_dm_fused", 1)
