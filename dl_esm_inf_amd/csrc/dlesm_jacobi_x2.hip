@@ -333,9 +333,33 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
     const int last = std::max(b.x1, b.ex1 + b.ge * g) + 1;
     const bool vec2 = !(tuning("j5_variant", 0) & 4) && last <= 2 * (ld / 2) - 1 && ((uintptr_t)in % 16 == 0) &&
                       ((uintptr_t)out % 16 == 0);
+    if (!vec2 && nsteps != 2) {
+        // Arrays that do not meet the 16-byte-lane conditions (odd leading dimension with the east ring column
+        // in the last chunk, unaligned bases): no fused kernel -- the same result through nsteps single
+        // sweeps and two stream-ordered scratch copies of the field, exactly the definition in the header:
+        // t_0 = in; t_s = J(t_{s-1}) on the stage box E_s, t_{s-1} elsewhere; out = J(t_{nsteps-1}) on the box.
+        const size_t bytes = (size_t)ld * ny * sizeof(double);
+        double *ta = nullptr, *tb = nullptr;
+        DLESM_HIP_TRY(hipMallocAsync((void **)&ta, bytes, s));
+        if (hipMallocAsync((void **)&tb, bytes, s) != hipSuccess) {
+            (void)hipFreeAsync(ta, s);
+            return fail(DLESM_EHIP, "fused Jacobi steps (fallback): scratch allocation failed");
+        }
+        int rc = DLESM_OK;
+        if (hipMemcpyAsync(ta, in, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(DLESM_EHIP, "fallback copy failed");
+        for (int st = 1; st <= nsteps - 1 && !rc; st++) {
+            if (empty_e) break;                              // every stage box empty: t_s = in
+            const int k = nsteps - 1 - st;                   // growth of stage box E_st
+            if (hipMemcpyAsync(tb, ta, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = fail(DLESM_EHIP, "fallback copy failed"); break; }
+            rc = launch_stencil5(ta, tb, ld, ny, exstart - gw * k, exstop + ge * k, eystart - gs * k, eystop + gn * k, s);
+            std::swap(ta, tb);
+        }
+        if (!rc) rc = launch_stencil5(ta, out, ld, ny, xstart, xstop, ystart, ystop, s);
+        (void)hipFreeAsync(ta, s);
+        (void)hipFreeAsync(tb, s);
+        return rc;
+    }
     if (!vec2) {
-        DLESM_REQUIRE(nsteps == 2, "fused Jacobi steps: %d steps need 16-byte aligned arrays with the east ring "
-                                   "column inside the last even column pair", nsteps);
         dim3 grid((unsigned)((b.x1 - b.x0 + 256) / 256), 1);
         for (int yb = b.y0; yb <= b.y1; yb += 65535) {   // grid.y is limited to 65535 rows per launch
             const int ye = std::min(b.y1, yb + 65534);

@@ -75,8 +75,6 @@ def _tune(D, kw):
 @pytest.mark.parametrize("nsteps", STEPS)
 @pytest.mark.parametrize("tune", TUNES, ids=lambda t: "-".join(f"{k}{v}" for k, v in t.items()) or "default")
 def test_fused_steps_bit_exact(D, nx, ny, alignment, nsteps, tune):
-    if tune.get("j5_variant") == 4 and nsteps > 2:
-        pytest.skip("the one-cell-per-thread fallback exists for two steps only")
     _tune(D, {**DEFAULTS, **tune})
     try:
         g = _grid(D, nx, ny, alignment)
