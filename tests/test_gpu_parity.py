@@ -577,6 +577,47 @@ def test_pipelined_distributed_steps(D, nx, ny, alignment, nsteps, chain, lazy):
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
+def test_distributed_steps_at_the_weak_scaling_tile(D):
+    """BASELINE configs[4]'s per-GPU tile (8192^2, DL_ESM_ALIGNMENT=64) in RCCL loop-back: six steps in the
+    joined form, in the time-loop form (+ one join) and as plain stencil + edge exchange end in the same
+    field, every bit, halos included"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dm_overhead import loopback_tables
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    g = _grid(D, 8192, 8192, 64)
+    F = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(6)]
+    it = F[0].internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    D.psy.hash_init(F[0], SEED + 17)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, F[0].device_ptr, D._cabi.DIRS_ALL, None))
+    for f in F[1:]:
+        D.copy_field(F[0], f)
+    finals = []
+    for k, form in enumerate(("plain", "joined", "pipelined")):
+        a, b = F[2 * k], F[2 * k + 1]
+        for _ in range(6):
+            if form == "plain":
+                D.psy.invoke_jacobi5(b, a)
+                D._cabi.check(L.dlesm_halo_exchange_f64(plan, b.device_ptr, D._cabi.DIRS_EDGES_ONLY, None))
+            elif form == "joined":
+                D._cabi.check(L.dlesm_jacobi5_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), None))
+            else:
+                D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), None))
+            a, b = b, a
+        D._cabi.check(L.dlesm_halo_plan_join(plan, None))
+        torch.cuda.synchronize()
+        finals.append(a)
+    assert bool(torch.equal(finals[0].data, finals[1].data))
+    assert bool(torch.equal(finals[0].data, finals[2].data))
+    assert abs(D.field_checksum(finals[0]) - D.field_checksum(finals[2])) == 0.0
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
 # --------------------------------------------------------------------------- grid properties (f.4)
 @pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (64, 48, 8), (300, 70, 64), (257, 129, None), (1, 1, 2),
                                              (129, 3, 2), (1000, 37, 64), (4100, 9, 64)])
