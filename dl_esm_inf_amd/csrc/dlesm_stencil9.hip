@@ -1,0 +1,135 @@
+// A general 9-point (3 x 3) weighted stencil over an r2d_field: the PSy-layer loop nest of any
+// GOcean kernel of the form
+//     out(ji,jj) = SUM_{dj=-1..1} SUM_{di=-1..1} c(di,dj) * in(ji+di, jj+dj)
+// (metadata: go_arg(GO_WRITE, GO_CT, GO_POINTWISE), go_arg(GO_READ, GO_CT, GO_STENCIL(111,111,111)),
+// nine GO_R_SCALAR coefficients; argument_mod.f90:39-112).  Five-point kernels are the same entry
+// with zero corner weights.  The reference has no stencil loop: the evaluation
+// order is frozen in DESIGN.md section 5.9 --
+//     S = (c_sw*in(i-1,j-1) + c_s*in(i,j-1)) + c_se*in(i+1,j-1)
+//     M = (c_w *in(i-1,j  ) + c_c*in(i,j  )) + c_e *in(i+1,j  )
+//     N = (c_nw*in(i-1,j+1) + c_n*in(i,j+1)) + c_ne*in(i+1,j+1)
+//     out = (S + M) + N
+// every product and sum rounded (FMA contraction off), so that GPU and CPU agree bit for bit.
+//
+// 16 B/cell of algorithmic traffic, exactly as the Jacobi sweep, and the same kernel shape: wave
+// tiles of 64 lanes x 2 columns x 2 rows swept linearly, the four rows a tile needs loaded up front,
+// west/east values of all three stencil rows from the neighbouring lane, lanes 0 and 63 fetching the
+// one column outside the wave.
+#include "dlesm_internal.h"
+
+namespace dlesm {
+
+namespace {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct Coef9 { double sw, s, se, w, c, e, nw, n, ne; };
+
+__device__ __forceinline__ double point9(const Coef9 &k, double sw, double s, double se, double w, double c, double e,
+                                         double nw, double n, double ne)
+{
+    const double S = (k.sw * sw + k.s * s) + k.se * se;
+    const double M = (k.w * w + k.c * c) + k.e * e;
+    const double N = (k.nw * nw + k.n * n) + k.ne * ne;
+    return (S + M) + N;
+}
+
+constexpr int R = 2;
+
+__global__ __launch_bounds__(1024) void stencil9_tile(const double *__restrict__ in, double *__restrict__ out,
+                                                     Coef9 k, int ld, int x0, int x1, int y0, int y1, int c_first,
+                                                     int nxw)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int xw = w % nxw, jb = y0 + (w / nxw) * R;
+    if (jb > y1) return;
+    const int je = jb + R - 1 > y1 ? y1 : jb + R - 1;
+    const int c = c_first + xw * 64 + lane;              // this lane's chunk (2 columns)
+    if (c - lane > x1 / 2) return;                       // idle padding tile
+    const int c_last = x1 / 2, c_ld = ld / 2 - 1;
+    const int cl = c < c_ld ? c : c_ld;
+    const bool m0 = c <= c_last && c * 2 >= x0 && c * 2 <= x1;
+    const bool m1 = c <= c_last && c * 2 + 1 >= x0 && c * 2 + 1 <= x1;
+    int ecol = -1;                                       // the one column this wave cannot get from a lane
+    if (lane == 0 && m0) ecol = c * 2 - 1;
+    if (lane == 63 && m1) ecol = c * 2 + 2;
+
+    d2 v[R + 2];
+    double ev[R + 2];
+#pragma unroll
+    for (int r = 0; r < R + 2; r++) {
+        int jj = jb - 1 + r;
+        if (jj > je + 1) jj = je + 1;
+        const size_t o = (size_t)jj * ld;
+        v[r] = *(const d2 *)(in + o + (size_t)cl * 2);
+        ev[r] = ecol >= 0 ? in[o + ecol] : 0.0;
+    }
+    // west neighbour of column .x and east neighbour of column .y, for every loaded row
+    double vw[R + 2], ve[R + 2];
+#pragma unroll
+    for (int r = 0; r < R + 2; r++) {
+        vw[r] = __shfl_up(v[r].y, 1);
+        ve[r] = __shfl_down(v[r].x, 1);
+        if (lane == 0) vw[r] = ev[r];
+        if (lane == 63) ve[r] = ev[r];
+    }
+#pragma unroll
+    for (int r = 1; r <= R; r++) {
+        if (jb + r - 1 > je) break;
+        const double o0 = point9(k, vw[r - 1], v[r - 1].x, v[r - 1].y, vw[r], v[r].x, v[r].y, vw[r + 1], v[r + 1].x, v[r + 1].y);
+        const double o1 = point9(k, v[r - 1].x, v[r - 1].y, ve[r - 1], v[r].x, v[r].y, ve[r], v[r + 1].x, v[r + 1].y, ve[r + 1]);
+        double *po = out + (size_t)(jb + r - 1) * ld + (size_t)c * 2;
+        if (m0 && m1) *(d2 *)po = d2{o0, o1};
+        else {
+            if (m0) po[0] = o0;
+            if (m1) po[1] = o1;
+        }
+    }
+}
+
+// one cell per thread: odd leading dimensions and unaligned bases
+__global__ __launch_bounds__(256) void stencil9_direct(const double *__restrict__ in, double *__restrict__ out, Coef9 k,
+                                                      int ld, int x0, int x1, int y0, int y1)
+{
+    const int i = x0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > x1) return;
+    for (int j = y0 + blockIdx.y; j <= y1; j += gridDim.y) {
+        const size_t o = (size_t)j * ld + i;
+        out[o] = point9(k, in[o - ld - 1], in[o - ld], in[o - ld + 1], in[o - 1], in[o], in[o + 1], in[o + ld - 1],
+                        in[o + ld], in[o + ld + 1]);
+    }
+}
+
+} // namespace
+
+} // namespace dlesm
+
+using namespace dlesm;
+
+extern "C" int dlesm_stencil9_f64(const double *in, double *out, const double *coef, int ld, int ny, int xstart,
+                                  int xstop, int ystart, int ystop, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;   // empty box: a zero-trip loop nest
+    if (int rc = check_box("dlesm_stencil9_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    DLESM_REQUIRE(in != nullptr && out != nullptr && coef != nullptr && in != out, "stencil9: null or aliased arrays");
+    const Coef9 k{coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[7], coef[8]};
+    hipStream_t s = (hipStream_t)stream;
+    const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
+    const bool tile = ld % 2 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0 && tuning("s9_kernel", 0) == 0;
+    if (tile) {
+        const int c_first = (x0 / 2) & ~7, c_last = x1 / 2;  // tiles anchored on 128-byte lines of the row
+        int nxw = (c_last - c_first + 64) / 64, tpb = 4;
+        choose_block_shape(&nxw, &tpb);
+        const int strips = (y1 - y0 + R) / R;
+        const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
+        hipLaunchKernelGGL(stencil9_tile, dim3(grid), dim3(64 * tpb), 0, s, in, out, k, ld, x0, x1, y0, y1, c_first, nxw);
+    } else {
+        const int h = y1 - y0 + 1;
+        hipLaunchKernelGGL(stencil9_direct, dim3((x1 - x0 + 256) / 256, h > 4096 ? 4096 : h), dim3(256), 0, s, in, out, k,
+                           ld, x0, x1, y0, y1);
+    }
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}

@@ -48,7 +48,7 @@ module dlesm_psy_mod
   private
 
   public :: invoke_jacobi5_masked, invoke_jacobi5_dm_pipelined, halo_join
-  public :: invoke_shallow_step_sw, invoke_periodic_halos
+  public :: invoke_shallow_step_sw, invoke_periodic_halos, invoke_stencil9
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
   public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5, plan_shallow_step
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
@@ -76,6 +76,29 @@ contains
                             int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_jacobi5: ' // dlesm_error_text())
   end subroutine invoke_jacobi5
+
+  !> A general 3x3 weighted stencil: out(ji,jj) = SUM coef(di,dj)*in(ji+di,jj+dj) over out%internal --
+  !! the PSy layer of a kernel with a GO_STENCIL(111,111,111) read argument and nine real scalars.
+  subroutine invoke_stencil9(out, in, coef)
+    type(r2d_field), intent(inout), target :: out, in
+    real(go_wp), intent(in) :: coef(-1:1, -1:1)
+    real(c_double) :: c9(9)
+    integer(c_int) :: rc
+    integer :: di, dj
+    call need_device(in);  call need_device(out)
+    ! di fastest, south row first: the C order coef[(dj+1)*3 + (di+1)].  (Explicit loops: amdflang 22 -O2
+    ! turns reshape() of an array with lower bounds -1 into a broadcast of its first element.)
+    do dj = -1, 1
+       do di = -1, 1
+          c9(3 * (dj + 1) + di + 2) = coef(di, dj)
+       end do
+    end do
+    rc = dlesm_stencil9_f64(field_device_data(in), field_device_data(out), c9, &
+                            int(out%grid%nx, c_int), int(out%grid%ny, c_int), &
+                            int(out%internal%xstart, c_int), int(out%internal%xstop, c_int), &
+                            int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_stencil9: ' // dlesm_error_text())
+  end subroutine invoke_stencil9
 
   !> The PSy layer of a kernel whose metadata requests the T mask,
   !!   go_arg(GO_WRITE, GO_CT, GO_POINTWISE), go_arg(GO_READ, GO_CT, GO_STENCIL(010,111,010)),

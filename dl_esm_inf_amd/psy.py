@@ -17,6 +17,17 @@ def invoke_jacobi5(out_fld, in_fld, stream=None):
                                          _stream_ptr(stream)))
 
 
+def invoke_stencil9(out_fld, in_fld, coef, stream=None):
+    """general 3x3 weighted stencil over out_fld%internal; coef: 9 weights, south-west row first
+    (sw, s, se, w, c, e, nw, n, ne) or a 3x3 array indexed [dj+1][di+1]"""
+    import numpy as np
+    c = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(9))
+    g, it = out_fld.grid, out_fld.internal
+    check(_cabi.lib().dlesm_stencil9_f64(in_fld.device_ptr, out_fld.device_ptr,
+                                         c.ctypes.data_as(C.POINTER(C.c_double)), g.nx, g.ny,
+                                         it.xstart, it.xstop, it.ystart, it.ystop, _stream_ptr(stream)))
+
+
 def invoke_jacobi5_masked(out_fld, in_fld, stream=None):
     """the masked Jacobi kernel (metadata: GO_GRID_MASK_T): the PSy layer hands the kernel the
     grid's T mask, here its device mirror"""

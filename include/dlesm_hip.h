@@ -228,6 +228,16 @@ int dlesm_stencil5_multi_f64(const double *in, double *out, int ld, int ny, int 
                              int exstart, int exstop, int eystart, int eystop,
                              int grow_w, int grow_e, int grow_s, int grow_n, void *stream);
 
+/* A general 9-point (3 x 3) weighted stencil -- the loop nest of any kernel of the form
+ *   out(ji,jj) = SUM_{dj,di = -1..1} coef(di,dj) * in(ji+di, jj+dj)
+ * (go_arg(GO_READ, GO_CT, GO_STENCIL(111,111,111)) + nine real scalars, argument_mod.f90:39-112).
+ * coef[(dj+1)*3 + (di+1)]: south-west, south, south-east, west, centre, east, north-west, north,
+ * north-east -- the storage order of a Fortran coef(-1:1,-1:1).  Five-point kernels pass zero corners.
+ * Evaluation order: out = ((c_sw*sw + c_s*s) + c_se*se  +  (c_w*w + c_c*c) + c_e*e)
+ * + ((c_nw*nw + c_n*n) + c_ne*ne), each row left to right, rows south to north, no FMA contraction. */
+int dlesm_stencil9_f64(const double *in, double *out, const double *coef, int ld, int ny,
+                       int xstart, int xstop, int ystart, int ystop, void *stream);
+
 /* The same loop nest for a kernel that requests a GRID PROPERTY: the T-point land/sea mask
  * (GO_GRID_MASK_T in the kernel metadata, argument_mod.f90:75-112; the PSy layer passes
  * grid%tmask, here its device mirror grid%tmask_device, grid_mod.f90:104-106).  tmask is a

@@ -602,6 +602,23 @@ void orc_tmask_fill(const int *user, int user_ld, int nx, int ny, int xstart, in
         for (int jj = 1; jj <= ny; jj++) tmask[IDX(nx, ji, jj)] = tmask[IDX(nx, xstop + 1, jj)];
 }
 
+/* A general 3x3 weighted stencil in GOcean kernel form; coef[(dj+1)*3 + (di+1)].  Evaluation order
+ * frozen in DESIGN.md section 5.9: rows south to north, each row west to east. */
+static inline void stencil9_code(int ji, int jj, double *out, const double *in, const double *c, int ld)
+{
+    const double S = (c[0] * in[IDX(ld, ji - 1, jj - 1)] + c[1] * in[IDX(ld, ji, jj - 1)]) + c[2] * in[IDX(ld, ji + 1, jj - 1)];
+    const double M = (c[3] * in[IDX(ld, ji - 1, jj)] + c[4] * in[IDX(ld, ji, jj)]) + c[5] * in[IDX(ld, ji + 1, jj)];
+    const double N = (c[6] * in[IDX(ld, ji - 1, jj + 1)] + c[7] * in[IDX(ld, ji, jj + 1)]) + c[8] * in[IDX(ld, ji + 1, jj + 1)];
+    out[IDX(ld, ji, jj)] = (S + M) + N;
+}
+
+void orc_stencil9(const double *in, double *out, const double *coef, int ld,
+                  int xstart, int xstop, int ystart, int ystop)
+{
+    for (int jj = ystart; jj <= ystop; jj++)
+        for (int ji = xstart; ji <= xstop; ji++) stencil9_code(ji, jj, out, in, coef, ld);
+}
+
 void orc_jacobi5_omp(const double *in, double *out, int ld,
                      int xstart, int xstop, int ystart, int ystop, int nthreads)
 {

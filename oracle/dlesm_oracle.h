@@ -112,6 +112,9 @@ double orc_hash_u01(uint64_t seed, int64_t gi, int64_t gj);
 void orc_jacobi5(const double *in, double *out, int ld,
                  int xstart, int xstop, int ystart, int ystop);
 /* same loops with an OpenMP `parallel for` over jj (what PSyclone's OMP transformation emits) */
+/* general 3x3 weighted stencil, coef[(dj+1)*3 + (di+1)] */
+void orc_stencil9(const double *in, double *out, const double *coef, int ld,
+                  int xstart, int xstop, int ystart, int ystop);
 /* masked 5-point Jacobi (kernel with a GO_GRID_MASK_T argument); grid_init's tmask fill */
 void orc_jacobi5_masked(const double *in, double *out, const int *tmask, int ld,
                         int xstart, int xstop, int ystart, int ystop);

@@ -49,6 +49,8 @@ def timed(name, fn, bytes_per_cell, n=30):
 
 
 timed("jacobi5 (reference point)", lambda: D.psy.invoke_jacobi5(b, a, stream=s), 16)
+timed("stencil9 (general 3x3 weights)", lambda: D.psy.invoke_stencil9(b, a, [0.0625, 0.125, 0.0625, 0.125, 0.25, 0.125,
+                                                                                  0.0625, 0.125, 0.0625], stream=s), 16)
 timed("jacobi5 masked, all-wet mask", lambda: D.psy.invoke_jacobi5_masked(b, a, stream=s), 20)
 timed("copy_field (whole field)", lambda: D.copy_field(a, b, stream=s), 16)
 timed("set_field (fill)", lambda: D.set_field(b, 1.0, stream=s), 8)

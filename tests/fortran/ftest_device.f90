@@ -89,6 +89,22 @@ program ftest_device
   ! ---- (2c) a kernel that takes the grid's T mask (GO_GRID_MASK_T) ---------------
   call masked_model(nx, ny, nsteps)
 
+  ! ---- (2d) a general 3x3 weighted stencil (coef(-1:1,-1:1)) -----------------------
+  block
+    real(go_wp) :: coef(-1:1, -1:1)
+    integer :: di, dj
+    do dj = -1, 1
+       do di = -1, 1
+          coef(di, dj) = 0.05_go_wp * real(3*(dj + 1) + (di + 1) + 1, go_wp) - 0.2_go_wp
+       end do
+    end do
+    call invoke_hash_init(a, 909_c_int64_t)
+    call invoke_copy(b, a)
+    call invoke_stencil9(b, a, coef)
+    h => b%get_data()
+    write(*, '("G: s9 ",3(ES24.16E3,1x))') field_checksum(b), h(2, 2), h(nx + 1, ny + 1)
+  end block
+
   ! ---- (3) one shallow-water step through the PSy layer ------------------------
   call shallow_step(model_grid)
   call free_field(a);  call free_field(b);  call free_field(test_field)

@@ -94,6 +94,7 @@ def lib():
     L.orc_jacobi5.argtypes = [_dp, _dp] + [C.c_int] * 5
     L.orc_jacobi5_omp.argtypes = [_dp, _dp] + [C.c_int] * 6
     _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    L.orc_stencil9.argtypes = [_dp, _dp, _dp] + [C.c_int] * 5
     L.orc_jacobi5_masked.argtypes = [_dp, _dp, _ip] + [C.c_int] * 5
     L.orc_tmask_fill.argtypes = [C.c_void_p] + [C.c_int] * 7 + [_ip]
     L.orc_sw_step.argtypes = [C.POINTER(SwParams)] + [C.c_int] * 5 + [_dp] * 13
@@ -271,3 +272,8 @@ def periodic_halos(internal, bcx, bcy):
 def apply_periodic_halos(f, ld, internal, bcx, bcy):
     it = Region(0, 0, *internal)
     lib().orc_apply_periodic_halos(f, ld, C.byref(it), bcx, bcy)
+
+
+def stencil9(inp, out, coef, ld, xs, xe, ys, ye):
+    c = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(9))
+    lib().orc_stencil9(inp, out, c, ld, xs, xe, ys, ye)

@@ -246,6 +246,14 @@ def test_fortran_device_io_and_jacobi_on_gpu(exe):
     row = [float(x) for x in g["masked"][0]]
     assert abs(row[0] - csm) <= 1e-12 * csm
     assert row[1:] == [a[1, 1], a[ny // 2, nx // 2], a[ny, nx]]
+    # (2d) the general 3x3 stencil through the Fortran PSy wrapper (coef(-1:1,-1:1) -> C order)
+    a9 = O.hash_field(909, nyy, ld, 0, 0, 1, nx + 2, 1, ny + 2)
+    b9 = a9.copy()
+    coef = [0.05 * (k + 1) - 0.2 for k in range(9)]
+    O.stencil9(a9, b9, coef, ld, 2, nx + 1, 2, ny + 1)
+    cs9 = O.lib().orc_checksum(b9, ld, 2, nx + 1, 2, ny + 1)
+    row = [float(x) for x in g["s9"][0]]
+    assert abs(row[0] - cs9) <= 1e-12 * cs9 and row[1:] == [b9[1, 1], b9[ny, nx]]
     # (3) one fused shallow-water step launched from Fortran == oracle
     import ctypes as C
     H = []

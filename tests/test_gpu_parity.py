@@ -667,6 +667,58 @@ def test_masked_jacobi_all_wet_is_the_plain_step_at_full_size(D):
     assert bool(torch.equal(b.data, c.data))
 
 
+# --------------------------------------------------------------------------- general 9-point stencil
+@pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (64, 48, 8), (300, 70, 64), (257, 129, None), (1, 1, 2),
+                                             (129, 3, 2), (1000, 37, 64), (4100, 9, 64)])
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_stencil9_matches_oracle(D, nx, ny, alignment, kernel):
+    """dlesm_stencil9_f64 (wave-tile form and one-cell-per-thread form) against orc_stencil9, bit for
+    bit, three ping-pong steps with random weights; cells outside the box untouched"""
+    import torch
+    _set_tuning(D, s9_kernel=kernel)
+    g = _grid(D, nx, ny, alignment)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = a.internal
+    coef = np.random.default_rng(nx + ny).random(9) - 0.45
+    D.psy.hash_init(a, SEED + 51)
+    D.set_field(b, -3.0)
+    ha, hb = a.get_data(), b.get_data()
+    for _ in range(3):
+        D.psy.invoke_stencil9(b, a, coef)
+        O.stencil9(ha, hb, coef, g.nx, *it.box())
+        torch.cuda.synchronize()
+        assert np.array_equal(b.get_data(), hb)
+        a, b, ha, hb = b, a, hb, ha
+    _set_tuning(D, s9_kernel=0)
+
+
+def test_stencil9_full_size_properties(D):
+    """16384^2: with the Jacobi weights the result equals dlesm_stencil5_f64 to rounding (the
+    association differs); a constant field is scaled by the sum of the weights exactly; sampled rows
+    against oracle slabs bit for bit"""
+    import torch
+    n = 16384
+    g = _grid(D, n, n, 64)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = a.internal
+    coef = np.array([0.0625, 0.125, 0.0625, 0.125, 0.25, 0.125, 0.0625, 0.125, 0.0625])     # sums to 1, exact in binary
+    D.set_field(a, 3.0)
+    D.set_field(b, -1.0)
+    D.psy.invoke_stencil9(b, a, coef)
+    inner = b.data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop]
+    assert bool((inner == 3.0).all())
+    D.psy.hash_init(a, SEED)
+    D.psy.invoke_stencil9(b, a, coef)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(5)
+    for jj in sorted(set([it.ystart, it.ystop] + [int(r) for r in rng.integers(it.ystart, it.ystop + 1, 10)])):
+        slab = a.data[jj - 2:jj + 1, :].cpu().numpy()
+        want = np.full_like(slab, -1.0)
+        O.stencil9(slab, want, coef, g.nx, it.xstart, it.xstop, 2, 2)
+        assert np.array_equal(b.data[jj - 1, :].cpu().numpy(), want[1]), jj
+    assert bool((b.data[0, :] == -1.0).all()) and bool((b.data[:, 0] == -1.0).all())
+
+
 # --------------------------------------------------------------------------- shallow water
 @pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (5, 4, 2), (64, 48, 8), (300, 70, 64), (257, 129, None),
                                              (1, 1, 2), (123, 3, 2), (124, 5, 2), (125, 2, 2), (1000, 37, 64),

@@ -419,3 +419,30 @@ def test_periodic_sw_model_conserves_mass_and_is_translation_invariant():
     b, _ = run((5, 3))
     for fa, fb in zip(a, b):
         assert np.array_equal(np.roll(fa[1:n + 1, 1:n + 1], (5, 3), axis=(0, 1)), fb[1:n + 1, 1:n + 1])
+
+
+# --------------------------------------------------------------------------- general 9-point stencil
+def test_stencil9_against_numpy():
+    """PARITY UNPINNED by the reference (it has no stencil).  orc_stencil9 (per-point GOcean kernel
+    form) against a whole-array numpy evaluation of DESIGN.md section 5.9, bit for bit; a 5-point
+    Laplacian and the identity as special cases"""
+    rng = np.random.default_rng(9)
+    for n, m, ld in [(37, 23, 44), (64, 48, 67), (5, 3, 8), (1, 1, 3)]:
+        a = rng.random((m + 3, ld)) - 0.3
+        c = rng.random(9) - 0.5
+        out = np.full_like(a, -7.0)
+        O.stencil9(a, out, c, ld, 2, n + 1, 2, m + 1)
+        V = lambda dj, di: a[1 + dj:m + 1 + dj, 1 + di:n + 1 + di]            # noqa: E731
+        S = (c[0] * V(-1, -1) + c[1] * V(-1, 0)) + c[2] * V(-1, 1)
+        M = (c[3] * V(0, -1) + c[4] * V(0, 0)) + c[5] * V(0, 1)
+        N = (c[6] * V(1, -1) + c[7] * V(1, 0)) + c[8] * V(1, 1)
+        assert np.array_equal(out[1:m + 1, 1:n + 1], (S + M) + N)
+        out[1:m + 1, 1:n + 1] = -7.0
+        assert np.all(out == -7.0)
+    a = rng.random((20, 24))
+    o = np.zeros_like(a)
+    O.stencil9(a, o, [0, 0, 0, 0, 1, 0, 0, 0, 0], 24, 2, 22, 2, 18)
+    assert np.array_equal(o[1:18, 1:22], a[1:18, 1:22])
+    O.stencil9(a, o, [0, 1, 0, 1, -4, 1, 0, 1, 0], 24, 2, 22, 2, 18)
+    lap = (a[0:17, 1:22] + a[2:19, 1:22] + a[1:18, 0:21] + a[1:18, 2:23]) - 4 * a[1:18, 1:22]
+    assert np.allclose(o[1:18, 1:22], lap, rtol=0, atol=1e-14)
