@@ -109,6 +109,7 @@ PROTOTYPES = {
     "dlesm_transfer_sync": (_i, []),
     "dlesm_stencil5_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_stencil9_f64": (_i, [_vp, _vp, C.POINTER(_d), _i, _i, _i, _i, _i, _i, _vp]),
+    "dlesm_stencil9_step_dm": (_i, [_vp, _vp, _vp, C.POINTER(_d), _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_stencil5_masked_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_stencil5_autotune_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_stencil5_x2_f64": (_i, [_vp, _vp] + [_i] * 10 + [_vp]),

@@ -535,6 +535,47 @@ extern "C" int dlesm_jacobi5_step_dm_pipelined(dlesm_halo_plan *p, const double 
     return jacobi5_step_dm_impl(p, in, out, ld, ny, xstart, xstop, ystart, ystop, (hipStream_t)stream, true);
 }
 
+// The distributed step of ANY 3x3 weighted kernel: frame of `out` (its west/east columns written
+// into the send buffer too), full eight-direction exchange of `out` on the side stream -- corner
+// halos are operands of a 9-point stencil -- while the interior sweeps on the caller's stream,
+// join.  A coefficient set with zero corner weights exchanges the four edges only.
+extern "C" int dlesm_stencil9_step_dm(dlesm_halo_plan *p, const double *in, double *out, const double *coef, int ld,
+                                      int ny, int xstart, int xstop, int ystart, int ystop, void *stream)
+{
+    DLESM_REQUIRE(p != nullptr && in != nullptr && out != nullptr && coef != nullptr, "null pointer");
+    DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
+    if (int rc = ensure_device()) return rc;
+    hipStream_t s = (hipStream_t)stream, side = side_stream();
+    if (int rc = join_pending(p, s)) return rc;
+    if (p->sends.empty() && p->recvs.empty()) return launch_stencil9(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, s);
+    const bool corners = coef[0] != 0.0 || coef[2] != 0.0 || coef[6] != 0.0 || coef[8] != 0.0;
+    const unsigned mask = corners ? DLESM_DIRS_ALL : (DLESM_DIRS_ALL | DLESM_DIRS_NO_DIAGONALS);
+    FramePack fp{};
+    bool prepacked = true;
+    for (const Msg &m : p->sends) {
+        if (m.off < 0 || !dir_enabled(mask, m.dir)) continue;
+        const bool on_frame = m.nx == 1 && (m.i0 == xstart - 1 || m.i0 == xstop - 1) && m.j0 >= ystart - 1 &&
+                              m.j0 + m.ny - 1 <= ystop - 1;
+        if (!on_frame || fp.n == FramePack::MAXS) { prepacked = false; break; }
+        fp.s[fp.n++] = FramePack::Col{m.i0, m.j0, m.ny, m.off};
+    }
+    if (prepacked && fp.n) {
+        if (int rc = ensure_buffers(p, 1)) return rc;
+        fp.buf = p->sendbuf;
+    } else {
+        fp.n = 0;
+    }
+    if (int rc = launch_stencil9_frame(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, s, prepacked ? &fp : nullptr))
+        return rc;
+    DLESM_HIP_TRY(hipEventRecord(p->ev_frame, s));
+    DLESM_HIP_TRY(hipStreamWaitEvent(side, p->ev_frame, 0));
+    if (int rc = exchange_on(p, out, mask, side, prepacked)) return rc;
+    DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
+    if (int rc = launch_stencil9(in, out, coef, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, s)) return rc;
+    DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
+    return DLESM_OK;
+}
+
 // Distributed form of the fused steps (temporal blocking across tiles): `in` holds valid
 // depth-nsteps halos, the plan was built from depth-nsteps tables (dlesm_map_comms_depth).
 // Stage boxes grow towards every side that has a neighbour; the nsteps-deep frame of `out` is

@@ -79,6 +79,13 @@ struct FramePack {
 };
 int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop,
                           int ystart, int ystop, hipStream_t s, const FramePack *pack = nullptr);
+// general 3x3 weighted stencil (dlesm_stencil9.hip): the sweep over a box, and the one-cell frame of a
+// box in one launch (its west/east columns also written into the send buffer)
+int launch_stencil9(const double *in, double *out, const double *coef, int ld, int ny, int xstart, int xstop,
+                    int ystart, int ystop, hipStream_t s);
+int launch_stencil9_frame(const double *in, double *out, const double *coef, int ld, int ny, int xstart, int xstop,
+                          int ystart, int ystop, hipStream_t s, const FramePack *pack);
+
 // the one-cell frame of the shallow-water step in ONE launch (one cell per thread), its west/east
 // columns also written into the send buffers of the three new fields
 struct FramePack3 {

@@ -16,6 +16,7 @@
 // west/east values of all three stencil rows from the neighbouring lane, lanes 0 and 63 fetching the
 // one column outside the wave.
 #include "dlesm_internal.h"
+#include "dlesm_device.h"
 
 namespace dlesm {
 
@@ -101,21 +102,51 @@ __global__ __launch_bounds__(256) void stencil9_direct(const double *__restrict_
     }
 }
 
+// the one-cell frame of the box, one cell per thread, all four sides; west/east column cells also into
+// their send-buffer slot (pack loop order, parallel_comms_mod.f90:1678-1683)
+__global__ __launch_bounds__(256) void stencil9_frame_k(const double *__restrict__ in, double *__restrict__ out, Coef9 k,
+                                                       int ld, int x0, int x1, int y0, int y1, FramePack pk)
+{
+    const long total = frame_cells(x1 - x0 + 1, y1 - y0 + 1);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        int i, j;
+        frame_index(t, x0, x1, y0, y1, i, j);
+        const size_t o = (size_t)j * ld + i;
+        const double r = point9(k, in[o - ld - 1], in[o - ld], in[o - ld + 1], in[o - 1], in[o], in[o + 1],
+                                in[o + ld - 1], in[o + ld], in[o + ld + 1]);
+        out[o] = r;
+        for (int q = 0; q < pk.n; q++)
+            if (i == pk.s[q].i && j >= pk.s[q].j0 && j < pk.s[q].j0 + pk.s[q].nj) pk.buf[pk.s[q].off + (j - pk.s[q].j0)] = r;
+    }
+}
+
 } // namespace
 
-} // namespace dlesm
-
-using namespace dlesm;
-
-extern "C" int dlesm_stencil9_f64(const double *in, double *out, const double *coef, int ld, int ny, int xstart,
-                                  int xstop, int ystart, int ystop, void *stream)
+int launch_stencil9_frame(const double *in, double *out, const double *coef, int ld, int ny, int xstart, int xstop,
+                          int ystart, int ystop, hipStream_t s, const FramePack *pack)
 {
-    if (int rc = ensure_device()) return rc;
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("stencil9 frame", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    DLESM_REQUIRE(in != nullptr && out != nullptr && coef != nullptr && in != out, "stencil9: null or aliased arrays");
+    const Coef9 k{coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[7], coef[8]};
+    const long cells = 2L * (xstop - xstart + 1) + 2L * (ystop - ystart + 1);
+    int blocks = (int)((cells + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    FramePack pk{};
+    if (pack) pk = *pack;
+    hipLaunchKernelGGL(stencil9_frame_k, dim3(blocks), dim3(256), 0, s, in, out, k, ld, xstart - 1, xstop - 1, ystart - 1,
+                       ystop - 1, pk);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+int launch_stencil9(const double *in, double *out, const double *coef, int ld, int ny, int xstart, int xstop,
+                    int ystart, int ystop, hipStream_t s)
+{
     if (xstop < xstart || ystop < ystart) return DLESM_OK;   // empty box: a zero-trip loop nest
     if (int rc = check_box("dlesm_stencil9_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     DLESM_REQUIRE(in != nullptr && out != nullptr && coef != nullptr && in != out, "stencil9: null or aliased arrays");
     const Coef9 k{coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[7], coef[8]};
-    hipStream_t s = (hipStream_t)stream;
     const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
     const bool tile = ld % 2 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0 && tuning("s9_kernel", 0) == 0;
     if (tile) {
@@ -132,4 +163,15 @@ extern "C" int dlesm_stencil9_f64(const double *in, double *out, const double *c
     }
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
+}
+
+} // namespace dlesm
+
+using namespace dlesm;
+
+extern "C" int dlesm_stencil9_f64(const double *in, double *out, const double *coef, int ld, int ny, int xstart,
+                                  int xstop, int ystart, int ystop, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    return launch_stencil9(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, (hipStream_t)stream);
 }

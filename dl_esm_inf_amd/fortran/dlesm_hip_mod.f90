@@ -167,6 +167,14 @@ module dlesm_hip_mod
        integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
        integer(c_int) :: rc
      end function
+     function dlesm_stencil9_step_dm(plan, in, out, coef, ld, ny, xstart, xstop, ystart, ystop, stream) &
+          bind(C, name="dlesm_stencil9_step_dm") result(rc)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: plan, in, out, stream
+       real(c_double), intent(in) :: coef(9)
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       integer(c_int) :: rc
+     end function
      function dlesm_stencil5_masked_f64(in, out, tmask, ld, ny, xstart, xstop, ystart, ystop, stream) &
           bind(C, name="dlesm_stencil5_masked_f64") result(rc)
        import :: c_int, c_ptr

@@ -48,7 +48,7 @@ module dlesm_psy_mod
   private
 
   public :: invoke_jacobi5_masked, invoke_jacobi5_dm_pipelined, halo_join
-  public :: invoke_shallow_step_sw, invoke_periodic_halos, invoke_stencil9
+  public :: invoke_shallow_step_sw, invoke_periodic_halos, invoke_stencil9, invoke_stencil9_dm
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
   public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5, plan_shallow_step
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
@@ -99,6 +99,33 @@ contains
                             int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_stencil9: ' // dlesm_error_text())
   end subroutine invoke_stencil9
+
+  !> invoke_stencil9 + out%halo_exchange(1), the exchange hidden behind the interior sweep
+  !! (all eight directions when a corner weight is non-zero, the four edges otherwise).
+  subroutine invoke_stencil9_dm(out, in, coef)
+    use parallel_comms_mod, only: halo_plan_for
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(r2d_field), intent(inout), target :: out, in
+    real(go_wp), intent(in) :: coef(-1:1, -1:1)
+    real(c_double) :: c9(9)
+    integer(c_int) :: rc
+    integer :: di, dj
+    if (.not. DIST_MEM_ENABLED) then
+       call invoke_stencil9(out, in, coef)
+       return
+    end if
+    call need_device(in);  call need_device(out)
+    do dj = -1, 1
+       do di = -1, 1
+          c9(3 * (dj + 1) + di + 2) = coef(di, dj)
+       end do
+    end do
+    rc = dlesm_stencil9_step_dm(halo_plan_for(out%grid%nx, out%grid%ny), field_device_data(in), &
+                                field_device_data(out), c9, int(out%grid%nx, c_int), int(out%grid%ny, c_int), &
+                                int(out%internal%xstart, c_int), int(out%internal%xstop, c_int), &
+                                int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_stencil9_dm: ' // dlesm_error_text())
+  end subroutine invoke_stencil9_dm
 
   !> The PSy layer of a kernel whose metadata requests the T mask,
   !!   go_arg(GO_WRITE, GO_CT, GO_POINTWISE), go_arg(GO_READ, GO_CT, GO_STENCIL(010,111,010)),

@@ -28,6 +28,17 @@ def invoke_stencil9(out_fld, in_fld, coef, stream=None):
                                          it.xstart, it.xstop, it.ystart, it.ystop, _stream_ptr(stream)))
 
 
+def invoke_stencil9_dm(out_fld, in_fld, coef, stream=None):
+    """distributed step of a 3x3 weighted kernel: frame, exchange(out) (eight directions when a
+    corner weight is non-zero) beside the interior sweep, join"""
+    import numpy as np
+    c = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(9))
+    g, it = out_fld.grid, out_fld.internal
+    check(_cabi.lib().dlesm_stencil9_step_dm(grid_mod.halo_plan(g), in_fld.device_ptr, out_fld.device_ptr,
+                                             c.ctypes.data_as(C.POINTER(C.c_double)), g.nx, g.ny,
+                                             it.xstart, it.xstop, it.ystart, it.ystop, _stream_ptr(stream)))
+
+
 def invoke_jacobi5_masked(out_fld, in_fld, stream=None):
     """the masked Jacobi kernel (metadata: GO_GRID_MASK_T): the PSy layer hands the kernel the
     grid's T mask, here its device mirror"""

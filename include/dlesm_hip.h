@@ -395,6 +395,17 @@ int dlesm_jacobi5_step_dm_pipelined(dlesm_halo_plan *plan, const double *in, dou
 /* order `stream` behind the exchange a pipelined step left in flight (no-op when there is none) */
 int dlesm_halo_plan_join(dlesm_halo_plan *plan, void *stream);
 
+/* The distributed step of any 3 x 3 weighted kernel (dlesm_stencil9_f64's coefficients and
+ * evaluation order): out = stencil9(in) on the box, then the halos of `out` valid as after
+ * out%halo_exchange(1) -- all eight directions when a corner weight is non-zero (corner halos are
+ * operands of the next step), the four edges when all four are zero (the diagonal halo cells are
+ * then left untouched).  `in` must hold valid halos for the same directions.  The frame of `out` is
+ * computed first (west/east columns straight into the send buffer), the exchange runs on the
+ * library's side stream beside the interior sweep, the call returns with `stream` ordered behind
+ * both.  Bit-identical to dlesm_stencil9_f64 + dlesm_halo_exchange_f64. */
+int dlesm_stencil9_step_dm(dlesm_halo_plan *plan, const double *in, double *out, const double *coef,
+                           int ld, int ny, int xstart, int xstop, int ystart, int ystop, void *stream);
+
 /* nsteps (2..8) distributed Jacobi time steps per call, ONE depth-nsteps exchange per call
  * (temporal blocking across tiles; dlesm_stencil5_multi_f64 with stage boxes grown towards
  * every neighbouring tile).  `plan` must come from dlesm_map_comms_depth(depth = nsteps) tables

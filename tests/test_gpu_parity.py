@@ -719,6 +719,44 @@ def test_stencil9_full_size_properties(D):
     assert bool((b.data[0, :] == -1.0).all()) and bool((b.data[:, 0] == -1.0).all())
 
 
+@pytest.mark.parametrize("nx,ny,alignment", [(300, 41, 64), (37, 23, 8), (130, 5, None), (1500, 700, 64)])
+@pytest.mark.parametrize("corner_weights", [True, False])
+def test_stencil9_distributed_step_loopback(D, nx, ny, alignment, corner_weights):
+    """dlesm_stencil9_step_dm = stencil9 + the exchange its weights need (eight directions with
+    corner weights, the four edges without), bit for bit over several steps; loop-back tables"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dm_overhead import loopback_tables
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    g = _grid(D, nx, ny, alignment)
+    x, y = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = x.internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    coef = np.random.default_rng(nx * 3 + ny).random(9) - 0.4
+    if not corner_weights:
+        coef[[0, 2, 6, 8]] = 0.0
+    cp = coef.ctypes.data_as(C.POINTER(C.c_double))
+    D.psy.hash_init(x, SEED + 61)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+    D.copy_field(x, y)
+    for _ in range(4):
+        hx = x.get_data()
+        want = y.get_data()
+        O.stencil9(hx, want, coef, g.nx, *it.box())
+        assert O.exchange_dirs([want], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=not corner_weights) == 0
+        D._cabi.check(L.dlesm_stencil9_step_dm(plan, x.device_ptr, y.device_ptr, cp, g.nx, g.ny, *it.box(), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(y.get_data(), want)
+        x, y = y, x
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
 # --------------------------------------------------------------------------- shallow water
 @pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (5, 4, 2), (64, 48, 8), (300, 70, 64), (257, 129, None),
                                              (1, 1, 2), (123, 3, 2), (124, 5, 2), (125, 2, 2), (1000, 37, 64),
