@@ -196,7 +196,7 @@ extern "C" int dlesm_comm_finalize(void)
 extern "C" int dlesm_comm_rank(void) { return g_rank; }
 extern "C" int dlesm_comm_size(void) { return g_size; }
 
-static int ensure_buffers(dlesm_halo_plan *p, int nfields);
+static int ensure_buffers(dlesm_halo_plan *p, int nfields, hipStream_t s = nullptr);
 
 static bool by_peer_dir(const Msg &a, const Msg &b)
 {
@@ -301,10 +301,26 @@ extern "C" int dlesm_halo_plan_destroy(dlesm_halo_plan *p)
     return DLESM_OK;
 }
 
+// A stream that is being captured into a hipGraph (hipStreamBeginCapture): the steps then take
+// their event form only -- fork to the side stream and join back are graph edges, every replay
+// runs the same nodes -- because the one-launch forms hand over through sequence numbers that are
+// baked into kernel arguments and advance per call on the host.
+static bool capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
 // Pack buffers hold one slot set per field of a multi-field exchange.
-static int ensure_buffers(dlesm_halo_plan *p, int nfields)
+static int ensure_buffers(dlesm_halo_plan *p, int nfields, hipStream_t s)
 {
     if (nfields <= p->buf_fields) return DLESM_OK;
+    DLESM_REQUIRE(!s || !capturing(s), "pack buffers for %d field(s) are not allocated yet: run the call once before "
+                  "capturing it into a graph", nfields);
     DLESM_HIP_TRY(hipDeviceSynchronize());               // nobody may still be using the old ones
     if (p->sendbuf) DLESM_HIP_TRY(hipFree(p->sendbuf));
     if (p->recvbuf) DLESM_HIP_TRY(hipFree(p->recvbuf));
@@ -315,11 +331,27 @@ static int ensure_buffers(dlesm_halo_plan *p, int nfields)
     return DLESM_OK;
 }
 
+// Checked by every entry that may put RCCL calls into a capture, BEFORE it enqueues anything (a refusal
+// then leaves the caller's capture intact).  Measured (scripts/graphprobe.hip): a captured
+// ncclSend/ncclRecv group is fine with RCCL 2.27.7 / HIP 7.2 and segfaults inside hipStreamEndCapture
+// with the RCCL 2.26.6 / HIP 7.0 pair that PyTorch 2.10 bundles.
+static int capture_ok(const dlesm_halo_plan *p, hipStream_t s)
+{
+    if ((p->sends.empty() && p->recvs.empty()) || !capturing(s)) return DLESM_OK;
+    int v = 0;
+    DLESM_NCCL_TRY(ncclGetVersion(&v));
+    DLESM_REQUIRE(v >= 22707 || tuning("dm_graph_force", 0),
+                  "RCCL %d.%d.%d in this process cannot be captured into a hipGraph (needs >= 2.27.7): issue the "
+                  "exchange outside the capture", v / 10000, v / 100 % 100, v % 100);
+    return DLESM_OK;
+}
+
 // A pipelined step leaves its exchange in flight: whoever touches the plan or the halos next on
 // stream `s` is ordered behind it first.
 static int join_pending(dlesm_halo_plan *p, hipStream_t s)
 {
     if (!p->pending) return DLESM_OK;
+    DLESM_REQUIRE(!capturing(s), "a pipelined step is in flight: call dlesm_halo_plan_join before capturing a graph");
     DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
     p->pending = false;
     if (p->pending_field && p->n_rpack) {      // the unpack the pipelined step left out
@@ -355,7 +387,8 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
         if (dir_enabled(mask, m.dir)) { any = true; any_rpack |= m.off >= 0; }
     if (!any) return DLESM_OK; // serial run, or no direction enabled: nothing to do (pcomms:1546,1557-1571)
     DLESM_REQUIRE(g_comm != nullptr, "halo exchange before dlesm_comm_init");
-    if (int rc = ensure_buffers(p, nf)) return rc;
+    if (int rc = capture_ok(p, s)) return rc;
+    if (int rc = ensure_buffers(p, nf, s)) return rc;
     int gx = (p->max_strip + 255) / 256;
     if (gx > 64) gx = 64;
     if (any_spack && !prepacked)
@@ -418,12 +451,15 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
     if (int rc = ensure_device()) return rc;
     hipStream_t side = side_stream();
+    if (int rc = capture_ok(p, s)) return rc;
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) // single tile: one launch over the whole box
         return launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s);
     // The previous step of a pipelined sequence left its exchange in flight.  If this step can take
     // the one-launch form on the same stream, its frame workgroups wait for that exchange on the
     // device (halo_flag) and the caller's stream needs no event wait at all; otherwise join now.
+    const bool graph = capturing(s);
+    if (graph) pipelined = false;                        // a captured step joins inside the graph
     const bool can_chain = pipelined && p->pending && p->pending_stream == s && p->frame_flag &&
                            tuning("j5_dm_fused", 1) && tuning("j5_dm_chain", 1) && streams_run_concurrently(s);
     if (!can_chain)
@@ -445,7 +481,7 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
         fp.s[fp.n++] = FramePack::Col{m.i0, m.j0, m.ny, m.off};
     }
     if (prepacked && fp.n) {
-        if (int rc = ensure_buffers(p, 1)) return rc;
+        if (int rc = ensure_buffers(p, 1, s)) return rc;
         fp.buf = p->sendbuf;
     } else {
         fp.n = 0;
@@ -456,7 +492,7 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
     bool fused = false;
     DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
                   "an earlier distributed step gave up waiting for a flag (frame or halo wait timed out)");
-    if (p->frame_flag && tuning("j5_dm_fused", 1) && streams_run_concurrently(s)) {
+    if (!graph && p->frame_flag && tuning("j5_dm_fused", 1) && streams_run_concurrently(s)) {
         FrameJob job{};
         job.pk = fp;
         job.counter = p->frame_counter;
@@ -546,6 +582,7 @@ extern "C" int dlesm_stencil9_step_dm(dlesm_halo_plan *p, const double *in, doub
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
     if (int rc = ensure_device()) return rc;
     hipStream_t s = (hipStream_t)stream, side = side_stream();
+    if (int rc = capture_ok(p, s)) return rc;
     if (int rc = join_pending(p, s)) return rc;
     if (p->sends.empty() && p->recvs.empty()) return launch_stencil9(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, s);
     const bool corners = coef[0] != 0.0 || coef[2] != 0.0 || coef[6] != 0.0 || coef[8] != 0.0;
@@ -560,7 +597,7 @@ extern "C" int dlesm_stencil9_step_dm(dlesm_halo_plan *p, const double *in, doub
         fp.s[fp.n++] = FramePack::Col{m.i0, m.j0, m.ny, m.off};
     }
     if (prepacked && fp.n) {
-        if (int rc = ensure_buffers(p, 1)) return rc;
+        if (int rc = ensure_buffers(p, 1, s)) return rc;
         fp.buf = p->sendbuf;
     } else {
         fp.n = 0;
@@ -591,6 +628,7 @@ extern "C" int dlesm_jacobi5_multi_step_dm(dlesm_halo_plan *p, const double *in,
     DLESM_REQUIRE(nsteps >= 2 && nsteps <= 8, "fused distributed step: nsteps = %d (2..8 supported)", nsteps);
     if (int rc = ensure_device()) return rc;
     hipStream_t s = (hipStream_t)stream, side = side_stream();
+    if (int rc = capture_ok(p, s)) return rc;
     if (int rc = join_pending(p, s)) return rc;
     const int T = nsteps;
     int hasW = 0, hasE = 0, hasS = 0, hasN = 0;
@@ -650,6 +688,7 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
     if (int rc = ensure_device()) return rc;
     hipStream_t s = (hipStream_t)stream, side = side_stream();
+    if (int rc = capture_ok(p, s)) return rc;
     if (int rc = join_pending(p, s)) return rc;
     auto box = [&](int xs, int xe, int ys, int ye) {
         return dlesm_shallow_step_f64(q, ld, ny, xs, xe, ys, ye, u, v, pf, uold, vold, pold, unew, vnew, pnew, s);
@@ -672,7 +711,7 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
             fp.s[fp.n++] = FramePack::Col{m.i0, m.j0, m.ny, m.off};
         }
         if (prepacked && fp.n) {
-            if (int rc = ensure_buffers(p, 3)) return rc;
+            if (int rc = ensure_buffers(p, 3, s)) return rc;
             for (int k = 0; k < 3; k++) fp.buf[k] = p->sendbuf + (size_t)k * p->sendbuf_len;
         } else {
             fp.n = 0;
@@ -683,7 +722,7 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     // hands it to the exchange on the side stream -- no frame launch, no event record on the caller's stream.
     DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
                   "an earlier distributed step gave up waiting for a flag (frame wait timed out)");
-    if (one_frame && p->frame_flag && tuning("sw_dm_fused", 1) && streams_run_concurrently(s)) {
+    if (one_frame && !capturing(s) && p->frame_flag && tuning("sw_dm_fused", 1) && streams_run_concurrently(s)) {
         SwFrameJob job{};
         job.pk = fp;
         job.counter = p->frame_counter;

@@ -20,6 +20,12 @@
  *   - `stream` arguments are hipStream_t handles passed as void*; NULL is the
  *     HIP null stream.  Device entry points are asynchronous on that stream
  *     unless stated otherwise.
+ *   - hipGraph capture: the kernel entries, the halo exchange and the distributed steps may be
+ *     called on a stream that is being captured (hipStreamBeginCapture), so that a whole time loop
+ *     replays as one graph launch.  Planning calls, checksums, gathers and anything documented as
+ *     synchronising may not.  Under capture a distributed step forks to the library's side stream
+ *     and joins back inside the graph (the *_pipelined form then equals the joined form); run the
+ *     call once uncaptured first -- pack buffers are allocated on first use.
  */
 #ifndef DLESM_HIP_H
 #define DLESM_HIP_H

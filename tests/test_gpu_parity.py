@@ -757,6 +757,85 @@ def test_stencil9_distributed_step_loopback(D, nx, ny, alignment, corner_weights
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
+# --------------------------------------------------------------------------- hipGraph capture
+def test_time_loop_captured_into_a_graph(D):
+    """two ping-pong Jacobi steps + two 9-point steps captured into one hipGraph on a side stream and
+    replayed: equal to the same steps issued one by one (oracle), bit for bit"""
+    import torch
+    g = _grid(D, 300, 70, 64)
+    a, b = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = a.internal
+    coef = np.random.default_rng(9).random(9) - 0.4
+    D.psy.hash_init(a, SEED + 71)
+    D.copy_field(a, b)
+    ha, hb = a.get_data(), b.get_data()
+    s = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
+        D.psy.invoke_jacobi5(b, a, stream=s)
+        D.psy.invoke_stencil9(a, b, coef, stream=s)
+    for _ in range(3):
+        graph.replay()
+        O.jacobi5(ha, hb, g.nx, *it.box())
+        O.stencil9(hb, ha, coef, g.nx, *it.box())
+    torch.cuda.synchronize()
+    assert np.array_equal(a.get_data(), ha) and np.array_equal(b.get_data(), hb)
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_distributed_steps_captured_into_a_graph(D, pipelined):
+    """the distributed Jacobi step under stream capture: fork to the side stream, RCCL group, join --
+    all graph nodes; three replays of a two-step graph equal six oracle steps + exchanges.  With an RCCL
+    that cannot be captured the step refuses cleanly and nothing has run."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dm_overhead import loopback_tables
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    g = _grid(D, 300, 41, 64)
+    x, y = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = x.internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    step = L.dlesm_jacobi5_step_dm_pipelined if pipelined else L.dlesm_jacobi5_step_dm
+    D.psy.hash_init(x, SEED + 73)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+    D.copy_field(x, y)
+    s = torch.cuda.Stream()
+    sp = C.c_void_p(s.cuda_stream)
+    # once uncaptured: buffers, RCCL channels; then rewind
+    D._cabi.check(step(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), sp))
+    D._cabi.check(L.dlesm_halo_plan_join(plan, sp))
+    s.synchronize()
+    D.copy_field(x, y)
+    hx, hy = x.get_data(), y.get_data()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
+        rcs = [step(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), sp),
+               step(plan, y.device_ptr, x.device_ptr, g.nx, g.ny, *it.box(), sp)]
+    if torch.cuda.nccl.version() < (2, 27, 7):
+        # the RCCL inside this torch build crashes in hipStreamEndCapture (scripts/graphprobe.hip): the library
+        # must refuse before it has put anything into the capture; examples/graph_demo.c covers the working case
+        assert rcs == [D._cabi.EINVAL, D._cabi.EINVAL] and b"cannot be captured" in L.dlesm_last_error()
+    else:
+        assert rcs == [0, 0], L.dlesm_last_error()
+        for _ in range(3):
+            graph.replay()
+            for src, dst in ((hx, hy), (hy, hx)):
+                O.jacobi5(src, dst, g.nx, *it.box())
+                assert O.exchange_dirs([dst], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+        torch.cuda.synchronize()
+    assert np.array_equal(x.get_data(), hx) and np.array_equal(y.get_data(), hy)
+    del graph
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
 # --------------------------------------------------------------------------- shallow water
 @pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (5, 4, 2), (64, 48, 8), (300, 70, 64), (257, 129, None),
                                              (1, 1, 2), (123, 3, 2), (124, 5, 2), (125, 2, 2), (1000, 37, 64),
