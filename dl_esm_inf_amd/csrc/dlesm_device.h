@@ -35,15 +35,21 @@ __device__ __forceinline__ void frame_index(long t, int x0, int x1, int y0, int 
 struct SwPoint { double un, vn, pn; };
 
 // the NE-offset update of ONE cell, operands straight from memory: the
-// expression trees of the oracle's compute_*_code
+// expression trees of the oracle's compute_*_code.  DEV: the current fields are read at device
+// scope (past this XCD's L2) -- halo cells an exchange may have written after this kernel started.
+template <bool DEV = false>
 __device__ __forceinline__ SwPoint shallow_values_ne(
     const dlesm_sw_params &q, int ld, size_t o, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ p, const double *__restrict__ uold, const double *__restrict__ vold,
     const double *__restrict__ pold)
 {
-#define U_(di, dj) u[o + (di) + (long)(dj) * ld]
-#define V_(di, dj) v[o + (di) + (long)(dj) * ld]
-#define P_(di, dj) p[o + (di) + (long)(dj) * ld]
+    auto get = [](const double *ptr) {
+        if constexpr (DEV) return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *ptr;
+    };
+#define U_(di, dj) get(u + (o + (di) + (long)(dj) * ld))
+#define V_(di, dj) get(v + (o + (di) + (long)(dj) * ld))
+#define P_(di, dj) get(p + (o + (di) + (long)(dj) * ld))
     // cu(a,b) = 0.5*(p(a+1,b)+p(a,b))*u(a,b) ; cv(a,b) = 0.5*(p(a,b+1)+p(a,b))*v(a,b)
 #define CU(di, dj) (0.5 * (P_((di) + 1, dj) + P_(di, dj)) * U_(di, dj))
 #define CV(di, dj) (0.5 * (P_(di, (dj) + 1) + P_(di, dj)) * V_(di, dj))

@@ -88,6 +88,17 @@ struct dlesm_halo_plan {
     long sendbuf_len = 0, recvbuf_len = 0;   // doubles per field
     int buf_fields = 0;                      // fields the buffers currently have room for
     int max_strip = 0;
+    // Aggregated exchanges of several fields (dlesm_halo_exchange_multi_f64, the shallow-water step): ONE
+    // message per neighbour and direction carries the strips of all nf fields, field after field --
+    // measured in loop-back, an RCCL group costs ~4 us per send/recv pair whatever its size up to a
+    // row of 8192 doubles, so 3 fields x 8 directions as 24 messages take 3x as long as 8.  Every
+    // message (rows too) then has a slot: message m of nf fields lives at nf * agg[m], count * nf doubles.
+    std::vector<long> sagg, ragg;            // per message, in the sorted order of sends / recvs
+    long sagg_len = 0, ragg_len = 0;         // doubles per field
+    Strip *d_sall = nullptr, *d_rall = nullptr;   // device tables of ALL messages (off = agg offset)
+    int max_msg = 0;
+    double *sendagg = nullptr, *recvagg = nullptr;
+    int agg_fields = 0;
     // frame-done / exchange-done events of the overlapped steps: per plan, so that two grids
     // stepped on different streams never share one.  ONE exchange per plan may be in flight
     // (its pack buffers are single): the steps below serialise on the caller's stream.
@@ -155,6 +166,36 @@ __global__ void unpack_strips(double *__restrict__ f, int ld, const Strip *__res
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
         const int j = (int)(t / s.nx), i = (int)(t % s.nx);
         f[(size_t)(s.j0 + j) * ld + s.i0 + i] = buf[s.off + t];
+    }
+}
+
+struct FieldSet { double *f[16]; };
+
+// aggregated forms: grid.y = message, grid.z = field; slot of field k of message s = nf*s.off + k*nx*ny
+__global__ void pack_agg(FieldSet fs, int nf, int ld, const Strip *__restrict__ tab, double *__restrict__ buf, unsigned mask)
+{
+    const Strip s = tab[blockIdx.y];
+    if (!dir_enabled(mask, s.dir)) return;
+    const long n = (long)s.nx * s.ny;
+    const double *__restrict__ f = fs.f[blockIdx.z];
+    double *__restrict__ dst = buf + (long)nf * s.off + (long)blockIdx.z * n;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int j = s.ny == 1 ? 0 : (int)(t / s.nx), i = (int)(t - (long)j * s.nx);
+        dst[t] = f[(size_t)(s.j0 + j) * ld + s.i0 + i];
+    }
+}
+
+__global__ void unpack_agg(FieldSet fs, int nf, int ld, const Strip *__restrict__ tab, const double *__restrict__ buf,
+                           unsigned mask)
+{
+    const Strip s = tab[blockIdx.y];
+    if (!dir_enabled(mask, s.dir)) return;
+    const long n = (long)s.nx * s.ny;
+    double *__restrict__ f = fs.f[blockIdx.z];
+    const double *__restrict__ src = buf + (long)nf * s.off + (long)blockIdx.z * n;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int j = s.ny == 1 ? 0 : (int)(t / s.nx), i = (int)(t - (long)j * s.nx);
+        f[(size_t)(s.j0 + j) * ld + s.i0 + i] = src[t];
     }
 }
 
@@ -244,13 +285,25 @@ extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny
     std::stable_sort(p->recvs.begin(), p->recvs.end(), by_peer_dir);
     p->n_spack = (int)spack.size();
     p->n_rpack = (int)rpack.size();
+    std::vector<Strip> sall, rall;
+    auto aggregate = [&](const std::vector<Msg> &list, std::vector<long> &agg, long &len, std::vector<Strip> &all) {
+        for (const Msg &m : list) {
+            agg.push_back(len);
+            all.push_back(Strip{m.i0, m.j0, m.nx, m.ny, len, m.dir});
+            len += (m.count + 15) & ~15L;                // every message starts on a 128-byte line
+            if (m.count > p->max_msg) p->max_msg = (int)m.count;
+        }
+    };
+    aggregate(p->sends, p->sagg, p->sagg_len, sall);
+    aggregate(p->recvs, p->ragg, p->ragg_len, rall);
     auto upload = [&](const std::vector<Strip> &v, Strip **d) -> int {
         if (v.empty()) return DLESM_OK;
         DLESM_HIP_TRY(hipMalloc((void **)d, v.size() * sizeof(Strip)));
         DLESM_HIP_TRY(hipMemcpy(*d, v.data(), v.size() * sizeof(Strip), hipMemcpyHostToDevice));
         return DLESM_OK;
     };
-    if ((rc = upload(spack, &p->d_spack)) || (rc = upload(rpack, &p->d_rpack))) {
+    if ((rc = upload(spack, &p->d_spack)) || (rc = upload(rpack, &p->d_rpack)) || (rc = upload(sall, &p->d_sall)) ||
+        (rc = upload(rall, &p->d_rall))) {
         dlesm_halo_plan_destroy(p);
         return rc;
     }
@@ -291,6 +344,10 @@ extern "C" int dlesm_halo_plan_destroy(dlesm_halo_plan *p)
     (void)hipDeviceSynchronize();
     if (p->d_spack) (void)hipFree(p->d_spack);
     if (p->d_rpack) (void)hipFree(p->d_rpack);
+    if (p->d_sall) (void)hipFree(p->d_sall);
+    if (p->d_rall) (void)hipFree(p->d_rall);
+    if (p->sendagg) (void)hipFree(p->sendagg);
+    if (p->recvagg) (void)hipFree(p->recvagg);
     if (p->sendbuf) (void)hipFree(p->sendbuf);
     if (p->recvbuf) (void)hipFree(p->recvbuf);
     if (p->frame_flag) (void)hipFree(p->frame_flag);
@@ -373,6 +430,66 @@ extern "C" int dlesm_halo_plan_join(dlesm_halo_plan *p, void *stream)
     return join_pending(p, (hipStream_t)stream);
 }
 
+static int ensure_agg(dlesm_halo_plan *p, int nfields, hipStream_t s)
+{
+    if (nfields <= p->agg_fields) return DLESM_OK;
+    DLESM_REQUIRE(!s || !capturing(s), "aggregated buffers for %d fields are not allocated yet: run the call once "
+                  "before capturing it into a graph", nfields);
+    DLESM_HIP_TRY(hipDeviceSynchronize());               // nobody may still be using the old ones
+    if (p->sendagg) DLESM_HIP_TRY(hipFree(p->sendagg));
+    if (p->recvagg) DLESM_HIP_TRY(hipFree(p->recvagg));
+    p->sendagg = p->recvagg = nullptr;
+    if (p->sagg_len) DLESM_HIP_TRY(hipMalloc((void **)&p->sendagg, (size_t)nfields * p->sagg_len * sizeof(double)));
+    if (p->ragg_len) DLESM_HIP_TRY(hipMalloc((void **)&p->recvagg, (size_t)nfields * p->ragg_len * sizeof(double)));
+    p->agg_fields = nfields;
+    return DLESM_OK;
+}
+
+// nf > 1 fields, ONE message per neighbour and direction (see dlesm_halo_plan::sagg).  Between a pair of
+// ranks messages match in issue order: ascending direction code on both sides.  `prepacked`: the caller's
+// kernel has already written every enabled strip of every field into the aggregated send buffer.
+static int exchange_agg(dlesm_halo_plan *p, double *const *fields, int nf, unsigned mask, hipStream_t s, bool prepacked)
+{
+    bool any = false;
+    for (const Msg &m : p->sends) any |= dir_enabled(mask, m.dir);
+    for (const Msg &m : p->recvs) any |= dir_enabled(mask, m.dir);
+    if (!any) return DLESM_OK;
+    DLESM_REQUIRE(g_comm != nullptr, "halo exchange before dlesm_comm_init");
+    DLESM_REQUIRE(nf <= 16, "at most 16 fields per aggregated exchange");
+    if (int rc = capture_ok(p, s)) return rc;
+    if (int rc = ensure_agg(p, nf, s)) return rc;
+    FieldSet fs{};
+    for (int k = 0; k < nf; k++) fs.f[k] = fields[k];
+    int gx = (p->max_msg + 255) / 256;
+    if (gx > 32) gx = 32;
+    if (!prepacked && !p->sends.empty())
+        hipLaunchKernelGGL(pack_agg, dim3(gx, (unsigned)p->sends.size(), nf), dim3(256), 0, s, fs, nf, p->ld, p->d_sall,
+                           p->sendagg, mask);
+    const int skip = tuning("dm_skip_parts", 0);         // diagnostics, see exchange_on
+    if (!(skip & 1)) {
+        DLESM_NCCL_TRY(ncclGroupStart());
+        ncclResult_t err = ncclSuccess;
+        for (size_t k = 0; k < p->recvs.size(); k++) {
+            const Msg &m = p->recvs[k];
+            if (!dir_enabled(mask, m.dir)) continue;
+            DLESM_NCCL_IN_GROUP(err, ncclRecv(p->recvagg + (size_t)nf * p->ragg[k], (size_t)nf * m.count, ncclDouble, m.peer,
+                                              g_comm, s));
+        }
+        for (size_t k = 0; k < p->sends.size(); k++) {
+            const Msg &m = p->sends[k];
+            if (!dir_enabled(mask, m.dir)) continue;
+            DLESM_NCCL_IN_GROUP(err, ncclSend(p->sendagg + (size_t)nf * p->sagg[k], (size_t)nf * m.count, ncclDouble, m.peer,
+                                              g_comm, s));
+        }
+        if (int rc = group_end(err, "aggregated halo exchange (ncclSend/ncclRecv)")) return rc;
+    }
+    if (!(skip & 2) && !p->recvs.empty())
+        hipLaunchKernelGGL(unpack_agg, dim3(gx, (unsigned)p->recvs.size(), nf), dim3(256), 0, s, fs, nf, p->ld, p->d_rall,
+                           p->recvagg, mask);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
 // The exchange of `nf` fields of the plan's shape in ONE grouped launch.  Between a pair of
 // ranks messages match in issue order: field-major, then ascending direction code, on both sides.
 // `prepacked`: the caller's kernel has already written the enabled strided strips of every field
@@ -386,6 +503,10 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
     for (const Msg &m : p->recvs)
         if (dir_enabled(mask, m.dir)) { any = true; any_rpack |= m.off >= 0; }
     if (!any) return DLESM_OK; // serial run, or no direction enabled: nothing to do (pcomms:1546,1557-1571)
+    // (a single field on its own goes the same way: rows staged through the buffer travel faster than rows
+    //  sent in place from their 8-byte-aligned position in the field -- 42 against 52 us at 8192^2)
+    if ((nf > 1 || (!prepacked && !skip_unpack && tuning("dm_aggregate_single", 1))) && tuning("dm_aggregate", 1))
+        return exchange_agg(p, fields, nf, mask, s, prepacked);
     DLESM_REQUIRE(g_comm != nullptr, "halo exchange before dlesm_comm_init");
     if (int rc = capture_ok(p, s)) return rc;
     if (int rc = ensure_buffers(p, nf, s)) return rc;
@@ -395,6 +516,11 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
         for (int k = 0; k < nf; k++)
             hipLaunchKernelGGL(pack_strips, dim3(gx, p->n_spack), dim3(256), 0, s, fields[k], p->ld, p->d_spack,
                                p->sendbuf + (size_t)k * p->sendbuf_len, mask);
+    // diagnostics (profiling only, results are then wrong): price the parts of an exchange
+    const int skip = tuning("dm_skip_parts", 0);         // bit0: no RCCL group, bit1: no unpack
+    if (skip & 2) skip_unpack = true;
+    if (skip & 1) goto after_group;
+    {
     DLESM_NCCL_TRY(ncclGroupStart());
     ncclResult_t err = ncclSuccess;
     for (int k = 0; k < nf; k++) {
@@ -411,6 +537,8 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
         }
     }
     if (int rc = group_end(err, "halo exchange (ncclSend/ncclRecv)")) return rc;
+    }
+after_group:
     if (any_rpack && !skip_unpack)
         for (int k = 0; k < nf; k++)
             hipLaunchKernelGGL(unpack_strips, dim3(gx, p->n_rpack), dim3(256), 0, s, fields[k], p->ld, p->d_rpack,
@@ -678,18 +806,26 @@ extern "C" int dlesm_jacobi5_multi_step_dm(dlesm_halo_plan *p, const double *in,
 // then ONE grouped exchange of the three new fields on the side stream while the interior is
 // computed on the caller's stream; join.  The new fields leave with valid depth-1 halos
 // (corners included: the 3x3 footprint needs them).
-extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *q, int ld, int ny, int xstart,
-                                     int xstop, int ystart, int ystop, const double *u, const double *v,
-                                     const double *pf, const double *uold, const double *vold,
-                                     const double *pold, double *unew, double *vnew, double *pnew,
-                                     void *stream)
+static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, int ld, int ny, int xstart,
+                                int xstop, int ystart, int ystop, const double *u, const double *v,
+                                const double *pf, const double *uold, const double *vold,
+                                const double *pold, double *unew, double *vnew, double *pnew,
+                                hipStream_t s, bool pipelined)
 {
     DLESM_REQUIRE(p != nullptr && q != nullptr, "null pointer");
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
     if (int rc = ensure_device()) return rc;
-    hipStream_t s = (hipStream_t)stream, side = side_stream();
+    hipStream_t side = side_stream();
     if (int rc = capture_ok(p, s)) return rc;
-    if (int rc = join_pending(p, s)) return rc;
+    const bool graph = capturing(s);
+    if (graph) pipelined = false;
+    // time-loop form: a previous pipelined step on this stream left its exchange in flight; the frame
+    // workgroups of this launch wait for it on the device (halo flag) instead of the stream (event)
+    const bool can_chain = pipelined && p->pending && p->pending_stream == s && !p->pending_field && p->frame_flag &&
+                           tuning("sw_dm_frame", 1) && tuning("sw_dm_fused", 1) && tuning("sw_dm_chain", 1) &&
+                           streams_run_concurrently(s);
+    if (!can_chain)
+        if (int rc = join_pending(p, s)) return rc;
     auto box = [&](int xs, int xe, int ys, int ye) {
         return dlesm_shallow_step_f64(q, ld, ny, xs, xe, ys, ye, u, v, pf, uold, vold, pold, unew, vnew, pnew, s);
     };
@@ -701,19 +837,24 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     bool prepacked = false;
     FramePack3 fp{};
     const bool one_frame = tuning("sw_dm_frame", 1) != 0;
-    if (one_frame) {
+    if (one_frame && tuning("dm_aggregate", 1)) {
+        // every message of a depth-1 exchange is a piece of the frame ring: the frame cells go straight
+        // into their slots of the aggregated send buffer (3 strips per message), no pack launch
         prepacked = true;
-        for (const Msg &m : p->sends) {
-            if (m.off < 0) continue;
-            const bool on_frame = m.nx == 1 && (m.i0 == xstart - 1 || m.i0 == xstop - 1) && m.j0 >= ystart - 1 &&
-                                  m.j0 + m.ny - 1 <= ystop - 1;
-            if (!on_frame || fp.n == FramePack::MAXS) { prepacked = false; break; }
-            fp.s[fp.n++] = FramePack::Col{m.i0, m.j0, m.ny, m.off};
+        const int fx0 = xstart - 1, fx1 = xstop - 1, fy0 = ystart - 1, fy1 = ystop - 1;
+        for (size_t k = 0; k < p->sends.size(); k++) {
+            const Msg &m = p->sends[k];
+            const bool in_box = m.i0 >= fx0 && m.i0 + m.nx - 1 <= fx1 && m.j0 >= fy0 && m.j0 + m.ny - 1 <= fy1;
+            const bool on_ring = in_box && ((m.ny == 1 && (m.j0 == fy0 || m.j0 == fy1)) ||
+                                            (m.nx == 1 && (m.i0 == fx0 || m.i0 == fx1)));
+            if (!on_ring || fp.n == FramePack3::MAXS) { prepacked = false; break; }
+            fp.s[fp.n++] = FramePack3::S{m.i0, m.j0, m.nx, m.ny, 3 * p->sagg[k]};
         }
         if (prepacked && fp.n) {
-            if (int rc = ensure_buffers(p, 3, s)) return rc;
-            for (int k = 0; k < 3; k++) fp.buf[k] = p->sendbuf + (size_t)k * p->sendbuf_len;
+            if (int rc = ensure_agg(p, 3, s)) return rc;
+            fp.buf = p->sendagg;
         } else {
+            prepacked = false;
             fp.n = 0;
         }
     }
@@ -722,24 +863,40 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     // hands it to the exchange on the side stream -- no frame launch, no event record on the caller's stream.
     DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
                   "an earlier distributed step gave up waiting for a flag (frame wait timed out)");
-    if (one_frame && !capturing(s) && p->frame_flag && tuning("sw_dm_fused", 1) && streams_run_concurrently(s)) {
+    if (one_frame && !graph && p->frame_flag && tuning("sw_dm_fused", 1) && streams_run_concurrently(s)) {
         SwFrameJob job{};
         job.pk = fp;
         job.counter = p->frame_counter;
         job.flag = p->frame_flag;
         job.seq = p->frame_seq + 1;
+        job.halo_flag = p->halo_flag;
+        job.halo_seq = can_chain ? p->pending_seq : 0;
+        job.timed_out = p->frame_timed_out;
         bool fused = false;
         if (int rc = launch_shallow_framed(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew,
                                            pnew, job, s, &fused))
             return rc;
         if (fused) {
             p->frame_seq = job.seq;
+            p->pending = false;                          // the chained wait (if any) is inside the launch
             if (int rc = launch_frame_flag_wait(p->frame_flag, job.seq, p->frame_timed_out, side)) return rc;
             if (int rc = exchange_on(p, fields, 3, DLESM_DIRS_ALL, side, prepacked)) return rc;
+            if (int rc = launch_flag_set(p->halo_flag, job.seq, side)) return rc;
             DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
+            if (pipelined) {                             // joined by the next step's frame workgroups, or by a join
+                p->pending = true;
+                p->pending_seq = job.seq;
+                p->pending_stream = s;
+                p->pending_field = nullptr;
+                return DLESM_OK;
+            }
             DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
             return DLESM_OK;
         }
+        if (can_chain)                                   // the arrays do not qualify: fall back to the event join
+            if (int rc = join_pending(p, s)) return rc;
+    } else if (can_chain) {
+        if (int rc = join_pending(p, s)) return rc;
     }
     if (one_frame) {
         if (int rc = launch_shallow_frame(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew,
@@ -762,6 +919,26 @@ extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *
     if (int rc = box(xstart + 1, xstop - 1, ystart + 1, ystop - 1)) return rc;
     DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
     return DLESM_OK;
+}
+
+extern "C" int dlesm_shallow_step_dm(dlesm_halo_plan *p, const dlesm_sw_params *q, int ld, int ny, int xstart,
+                                     int xstop, int ystart, int ystop, const double *u, const double *v,
+                                     const double *pf, const double *uold, const double *vold,
+                                     const double *pold, double *unew, double *vnew, double *pnew,
+                                     void *stream)
+{
+    return shallow_step_dm_impl(p, q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew,
+                                (hipStream_t)stream, false);
+}
+
+extern "C" int dlesm_shallow_step_dm_pipelined(dlesm_halo_plan *p, const dlesm_sw_params *q, int ld, int ny,
+                                               int xstart, int xstop, int ystart, int ystop, const double *u,
+                                               const double *v, const double *pf, const double *uold,
+                                               const double *vold, const double *pold, double *unew, double *vnew,
+                                               double *pnew, void *stream)
+{
+    return shallow_step_dm_impl(p, q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew,
+                                (hipStream_t)stream, true);
 }
 
 extern "C" int dlesm_global_sum_f64(double *value)

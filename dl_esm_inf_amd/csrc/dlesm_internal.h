@@ -86,12 +86,23 @@ int launch_stencil9(const double *in, double *out, const double *coef, int ld, i
 int launch_stencil9_frame(const double *in, double *out, const double *coef, int ld, int ny, int xstart, int xstop,
                           int ystart, int ystop, hipStream_t s, const FramePack *pack);
 
-// the one-cell frame of the shallow-water step in ONE launch (one cell per thread), its west/east
-// columns also written into the send buffers of the three new fields
+// the one-cell frame of the shallow-water step in ONE launch (one cell per thread).  Every frame cell
+// that a neighbour will receive (rows, columns and corners) is also written into the AGGREGATED send
+// buffer of the three new fields: one message per neighbour and direction carries all three strips,
+// field after field, each in the pack loop's order (j outer, i inner; parallel_comms_mod.f90:1678-1683).
 struct FramePack3 {
-    FramePack::Col s[FramePack::MAXS];
+    static constexpr int MAXS = 8;
+    struct S { int i0, j0, ni, nj; long off; } s[MAXS];   // 0-based strip; off = offset of the message's slot
     int n;
-    double *buf[3];               // send buffers of unew, vnew, pnew
+    double *buf;                  // aggregated send buffer; field k of strip q at off + k*ni*nj
+    __host__ __device__ long slot(int q, int k, int i, int j) const
+    {
+        return s[q].off + (long)k * s[q].ni * s[q].nj + (long)(j - s[q].j0) * s[q].ni + (i - s[q].i0);
+    }
+    __host__ __device__ bool holds(int q, int i, int j) const
+    {
+        return i >= s[q].i0 && i < s[q].i0 + s[q].ni && j >= s[q].j0 && j < s[q].j0 + s[q].nj;
+    }
 };
 int launch_shallow_frame(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                          const double *u, const double *v, const double *p, const double *uold,
@@ -147,6 +158,11 @@ struct SwFrameJob {
     unsigned *counter;
     unsigned long long *flag;
     unsigned long long seq;
+    // pipelined steps (as FrameJob): the frame workgroups first wait until *halo_flag >= halo_seq -- the
+    // previous step's exchange has landed in the halos of u, v, p and is done with the send buffers
+    const unsigned long long *halo_flag;
+    unsigned long long halo_seq;  // 0: no wait
+    int *timed_out;
 };
 // shallow-water step, register-tiled linear sweep (dlesm_shallow.hip); 0-based inclusive box
 void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,

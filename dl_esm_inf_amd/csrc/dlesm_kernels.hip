@@ -834,8 +834,8 @@ __global__ __launch_bounds__(256) void shallow_step_direct_cols(
 }
 
 // the one-cell frame of the box (the cells a neighbour needs first in the distributed step): one cell
-// per thread, all four sides in ONE launch; west/east column cells also go into the send buffers of
-// the three new fields, in the pack loop's j order (parallel_comms_mod.f90:1678-1683)
+// per thread, all four sides in ONE launch; cells a neighbour will receive also go into the aggregated
+// send buffer of the three new fields (FramePack3)
 __global__ __launch_bounds__(256) void shallow_frame_k(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, const double *__restrict__ u,
     const double *__restrict__ v, const double *__restrict__ p, const double *__restrict__ uold,
@@ -849,11 +849,10 @@ __global__ __launch_bounds__(256) void shallow_frame_k(
         const size_t o = (size_t)j * ld + i;
         shallow_point_ne(q, ld, o, u, v, p, uold, vold, pold, unew, vnew, pnew);
         for (int k = 0; k < pk.n; k++)
-            if (i == pk.s[k].i && j >= pk.s[k].j0 && j < pk.s[k].j0 + pk.s[k].nj) {
-                const long slot = pk.s[k].off + (j - pk.s[k].j0);
-                pk.buf[0][slot] = unew[o];
-                pk.buf[1][slot] = vnew[o];
-                pk.buf[2][slot] = pnew[o];
+            if (pk.holds(k, i, j)) {
+                pk.buf[pk.slot(k, 0, i, j)] = unew[o];
+                pk.buf[pk.slot(k, 1, i, j)] = vnew[o];
+                pk.buf[pk.slot(k, 2, i, j)] = pnew[o];
             }
     }
 }

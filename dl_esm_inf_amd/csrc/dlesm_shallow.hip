@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512) void shallow_tile(
 // The distributed shallow-water step in ONE launch on the caller's stream (as jacobi5_tile_framed): the
 // first fj.nblocks workgroups compute the one-cell ring of the box (fx0:fx1, fy0:fy1), one cell per thread
 // from memory, store it write-through at device scope -- the exchange reads it while this kernel is still
-// running -- into the fields and, for the west/east columns, into the three send buffers; the last of them
+// running -- into the fields and, where a neighbour will receive it, into the aggregated send buffer; the last of them
 // publishes `seq` in the flag the side stream's waiter sleeps on.  All other workgroups are the ordinary
 // tile sweep over the interior.
 template <int R, bool DPP, int NTM>
@@ -201,20 +201,37 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
     }
     auto put = [](double *ptr, double val) { __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const long total = frame_cells(fj.fx1 - fj.fx0 + 1, fj.fy1 - fj.fy0 + 1);
+    const bool chained = fj.halo_seq != 0;
+    if (chained) {
+        // time-loop form: the halos of u, v, p (and the send buffers) belong to the previous step's exchange
+        // until its completion flag is up -- in steady state long since.  Bounded, as in jacobi5_tile_framed.
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(fj.halo_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fj.halo_seq) {
+                __builtin_amdgcn_s_sleep(32);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {   // ~20 s of the 100 MHz counter
+                    __hip_atomic_store(fj.timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)fj.nblocks * blockDim.x) {
         int i, j;
         frame_index(t, fj.fx0, fj.fx1, fj.fy0, fj.fy1, i, j);
         const size_t o = (size_t)j * ld + i;
-        const SwPoint r = shallow_values_ne(q, ld, o, u, v, p, uold, vold, pold);
+        // chained: the halo operands were unpacked by a kernel that ran beside this one, on whatever XCD
+        const SwPoint r = chained ? shallow_values_ne<true>(q, ld, o, u, v, p, uold, vold, pold)
+                                  : shallow_values_ne<false>(q, ld, o, u, v, p, uold, vold, pold);
         put(unew + o, r.un);
         put(vnew + o, r.vn);
         put(pnew + o, r.pn);
         for (int k = 0; k < fj.pk.n; k++)
-            if (i == fj.pk.s[k].i && j >= fj.pk.s[k].j0 && j < fj.pk.s[k].j0 + fj.pk.s[k].nj) {
-                const long slot = fj.pk.s[k].off + (j - fj.pk.s[k].j0);
-                put(fj.pk.buf[0] + slot, r.un);
-                put(fj.pk.buf[1] + slot, r.vn);
-                put(fj.pk.buf[2] + slot, r.pn);
+            if (fj.pk.holds(k, i, j)) {
+                put(fj.pk.buf + fj.pk.slot(k, 0, i, j), r.un);
+                put(fj.pk.buf + fj.pk.slot(k, 1, i, j), r.vn);
+                put(fj.pk.buf + fj.pk.slot(k, 2, i, j), r.pn);
             }
     }
     __builtin_amdgcn_s_waitcnt(0);        // this wave's stores have been acknowledged ...

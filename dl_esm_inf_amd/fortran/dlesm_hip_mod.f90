@@ -371,6 +371,15 @@ module dlesm_hip_mod
        type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
        integer(c_int) :: rc
      end function
+     function dlesm_shallow_step_dm_pipelined(plan, params, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
+          uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_step_dm_pipelined") result(rc)
+       import :: c_int, c_ptr, c_sw_params
+       type(c_ptr), value :: plan
+       type(c_sw_params), intent(in) :: params
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
+       integer(c_int) :: rc
+     end function
      function dlesm_global_sum_f64(val) bind(C, name="dlesm_global_sum_f64") result(rc)
        import :: c_int, c_double
        real(c_double), intent(inout) :: val

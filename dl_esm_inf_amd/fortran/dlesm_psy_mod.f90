@@ -50,6 +50,7 @@ module dlesm_psy_mod
   public :: invoke_jacobi5_masked, invoke_jacobi5_dm_pipelined, halo_join
   public :: invoke_shallow_step_sw, invoke_periodic_halos, invoke_stencil9, invoke_stencil9_dm
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
+  public :: invoke_shallow_step_dm_pipelined
   public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5, plan_shallow_step
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
 
@@ -354,6 +355,32 @@ contains
                                c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_shallow_step_dm: ' // dlesm_error_text())
   end subroutine invoke_shallow_step_dm
+
+  !> The same step for a time loop: returns with the exchange of the new fields in flight; the next
+  !! invoke_shallow_step_dm_pipelined on this grid waits for it on the device; halo_join(grid) after the loop.
+  subroutine invoke_shallow_step_dm_pipelined(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)
+    use parallel_comms_mod, only: halo_plan_for
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(c_sw_params), intent(in) :: prm
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew
+    integer(c_int) :: rc
+    if (.not. DIST_MEM_ENABLED) then
+       call invoke_shallow_step(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)
+       return
+    end if
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    rc = dlesm_shallow_step_dm_pipelined(halo_plan_for(p%grid%nx, p%grid%ny), prm, &
+                               int(p%grid%nx, c_int), int(p%grid%ny, c_int), &
+                               int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                               int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                               field_device_data(u), field_device_data(v), field_device_data(p), &
+                               field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                               field_device_data(unew), field_device_data(vnew), field_device_data(pnew), &
+                               c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_dm_pipelined: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_dm_pipelined
 
   !> halo_exchange(1) of several fields of one grid in a single grouped RCCL launch
   subroutine halo_exchange_multi(f1, f2, f3)

@@ -175,6 +175,18 @@ def invoke_shallow_step_dm(params, u, v, p, uold, vold, pold, unew, vnew, pnew, 
                                             pnew.device_ptr, _stream_ptr(stream)))
 
 
+def invoke_shallow_step_dm_pipelined(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
+    """the distributed shallow-water step inside a time loop: returns with the exchange of the new
+    fields in flight; the next such step waits for it on the device.  halo_join(grid) before anything
+    else reads their halos."""
+    g, it = p.grid, p.internal
+    check(_cabi.lib().dlesm_shallow_step_dm_pipelined(grid_mod.halo_plan(g), C.byref(params), g.nx, g.ny,
+                                                      it.xstart, it.xstop, it.ystart, it.ystop, u.device_ptr,
+                                                      v.device_ptr, p.device_ptr, uold.device_ptr, vold.device_ptr,
+                                                      pold.device_ptr, unew.device_ptr, vnew.device_ptr,
+                                                      pnew.device_ptr, _stream_ptr(stream)))
+
+
 def halo_exchange_multi(fields, stream=None, dirs=_cabi.DIRS_ALL):
     """halo_exchange(1) of several fields of one grid in a single grouped RCCL launch"""
     g = fields[0].grid

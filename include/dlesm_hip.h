@@ -430,6 +430,17 @@ int dlesm_shallow_step_dm(dlesm_halo_plan *plan, const dlesm_sw_params *params, 
                           const double *uold, const double *vold, const double *pold,
                           double *unew, double *vnew, double *pnew, void *stream);
 
+/* The same step for a TIME LOOP (the contract of dlesm_jacobi5_step_dm_pipelined): returns with the
+ * exchange of unew/vnew/pnew in flight on the side stream; the next pipelined step on the same plan
+ * and stream -- which reads them as u/v/p -- waits for it on the device, in its frame workgroups;
+ * every other entry that takes the plan joins first; dlesm_halo_plan_join orders a stream behind it.
+ * Between pipelined steps the caller only rotates the nine pointers.  Same results, bit for bit. */
+int dlesm_shallow_step_dm_pipelined(dlesm_halo_plan *plan, const dlesm_sw_params *params, int ld, int ny,
+                                    int xstart, int xstop, int ystart, int ystop,
+                                    const double *u, const double *v, const double *p,
+                                    const double *uold, const double *vold, const double *pold,
+                                    double *unew, double *vnew, double *pnew, void *stream);
+
 /* global_sum, parallel_utils_mod.f90:230-238: in-place sum of one host double
  * over all ranks (synchronous). */
 int dlesm_global_sum_f64(double *value);

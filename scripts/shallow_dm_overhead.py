@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Price the distributed shallow-water step on ONE GPU with RCCL in loop-back (rank 0 is its own eight
-neighbours): plain fused step / step then grouped exchange of unew, vnew, pnew / dlesm_shallow_step_dm.
+neighbours): plain fused step / step then grouped exchange of unew, vnew, pnew / dlesm_shallow_step_dm /
+its time-loop form dlesm_shallow_step_dm_pipelined (+ one join at the end, inside the timed region).
     python scripts/shallow_dm_overhead.py [tile]"""
 import ctypes as C
 import json
@@ -55,22 +56,28 @@ def run(kind):
                 elif kind == "serial":
                     D.psy.invoke_shallow_step(prm, *cur, *old, *new, stream=s)
                     D.psy.halo_exchange_multi(new, stream=s)
+                elif kind == "pipelined":
+                    D.psy.invoke_shallow_step_dm_pipelined(prm, *cur, *old, *new, stream=s)
                 else:
                     D.psy.invoke_shallow_step_dm(prm, *cur, *old, *new, stream=s)
                 old, cur, new = cur, new, old
+            if kind == "pipelined":
+                D.psy.halo_join(g, stream=s)             # inside the timed region
             e1.record(s)
     s.synchronize()
     return e0.elapsed_time(e1) / steps, cur[2].data.clone()
 
 
 res = {}
-for kind in ("plain", "plain", "serial", "overlapped", "serial", "overlapped", "plain"):
+for kind in ("plain", "plain", "serial", "overlapped", "pipelined", "serial", "overlapped", "pipelined", "plain"):
     ms, fin = run(kind)
     res[kind] = min(ms, res.get(kind, (1e9,))[0]), fin
 w = F["p"].whole      # compare the field proper (the padding beyond `whole` accumulates the re-initialisation shifts)
 cut = lambda t_: t_[w.ystart - 1:w.ystop, w.xstart - 1:w.xstop]      # noqa: E731
-same = bool(torch.equal(cut(res["serial"][1]), cut(res["overlapped"][1])))
+same = bool(torch.equal(cut(res["serial"][1]), cut(res["overlapped"][1])) and
+            torch.equal(cut(res["serial"][1]), cut(res["pipelined"][1])))
 out = {"tile": tile, "ms_per_step": {k: v[0] for k, v in res.items()}, "overlapped_equals_serial_bitwise": same,
-       "overlapped_over_plain": res["plain"][0] / res["overlapped"][0]}
+       "overlapped_over_plain": res["plain"][0] / res["overlapped"][0],
+       "pipelined_over_plain": res["plain"][0] / res["pipelined"][0]}
 print(json.dumps(out, indent=1))
 assert same

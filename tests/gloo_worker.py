@@ -3,8 +3,8 @@ backend, no GPU).  It drives the PRODUCT's host logic for its own rank -- parall
 grid_type%decompose, grid_init (-> map_comms through the C ABI) -- and then plays the
 reference's dist_mem tests (test_halos / test_gsum / test_reduction) with numpy arrays as the
 fields and gloo send/recv as a TEST-ONLY transport that follows the product's message tables and,
-like RCCL, uses NO tags: messages between a pair of ranks match purely by issue order (field-major,
-then per peer ascending direction code), so the ordering rule of dlesm_halo.hip is what is tested.  What this checks is
+like RCCL, uses NO tags: messages between a pair of ranks match purely by issue order (per peer
+ascending direction code, the strips of all fields of a grouped exchange in one message), so the ordering rule of dlesm_halo.hip is what is tested.  What this checks is
 everything about the N>1 path that is not the GPU itself: tile ownership, message tables,
 peer/ordering logic, scatter/gather index maps.
 
@@ -40,27 +40,30 @@ def dir_enabled(mask, d):
 
 
 def exchange_multi(fields, tables, rank, mask=DIRS_ALL):
-    """halo exchange of several (ny, ld) numpy fields over gloo, issued EXACTLY as exchange_on() of
-    dlesm_halo.hip issues its ncclSend/ncclRecv: no tags (every message carries tag 0, as RCCL has
-    none), field-major, and per field the receives then the sends, each list sorted by (peer,
-    direction code).  Between a pair of ranks the k-th send therefore has to meet the k-th receive:
+    """halo exchange of several (ny, ld) numpy fields over gloo, issued EXACTLY as dlesm_halo.hip
+    issues its ncclSend/ncclRecv: no tags (every message carries tag 0, as RCCL has none), the
+    receives then the sends, each list sorted by (peer, direction code); with more than one field
+    ONE message per neighbour and direction carries the strips of all fields, field after field
+    (exchange_agg).  Between a pair of ranks the k-th send therefore has to meet the k-th receive:
     the ordering rule itself is what this transport tests."""
     sends = sorted((m for m in tables.sends() if dir_enabled(mask, m["dir"])), key=lambda m: (m["dest"], m["dir"]))
     recvs = sorted((m for m in tables.recvs() if dir_enabled(mask, m["dir"])), key=lambda m: (m["src"], m["dir"]))
+    nf = len(fields)
     reqs, bufs = [], []
-    for k, field in enumerate(fields):
-        for m in recvs:
-            buf = torch.empty(m["nx"] * m["ny"], dtype=torch.float64)
-            reqs.append(dist.irecv(buf, src=m["src"], tag=0))
-            bufs.append((k, m, buf))
-        for m in sends:
-            patch = field[m["jsrc"] - 1:m["jsrc"] - 1 + m["ny"], m["isrc"] - 1:m["isrc"] - 1 + m["nx"]]
-            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(patch).reshape(-1)), dst=m["dest"], tag=0))
+    for m in recvs:
+        buf = torch.empty(nf * m["nx"] * m["ny"], dtype=torch.float64)
+        reqs.append(dist.irecv(buf, src=m["src"], tag=0))
+        bufs.append((m, buf))
+    for m in sends:
+        strips = [np.ascontiguousarray(f[m["jsrc"] - 1:m["jsrc"] - 1 + m["ny"], m["isrc"] - 1:m["isrc"] - 1 + m["nx"]]).reshape(-1)
+                  for f in fields]
+        reqs.append(dist.isend(torch.from_numpy(np.concatenate(strips)), dst=m["dest"], tag=0))
     for q in reqs:
         q.wait()
-    for k, m, buf in bufs:
-        fields[k][m["jdes"] - 1:m["jdes"] - 1 + m["ny"], m["ides"] - 1:m["ides"] - 1 + m["nx"]] = \
-            buf.numpy().reshape(m["ny"], m["nx"])
+    for m, buf in bufs:
+        got = buf.numpy().reshape(nf, m["ny"], m["nx"])
+        for k in range(nf):
+            fields[k][m["jdes"] - 1:m["jdes"] - 1 + m["ny"], m["ides"] - 1:m["ides"] - 1 + m["nx"]] = got[k]
 
 
 def exchange(field, tables, rank, mask=DIRS_ALL):

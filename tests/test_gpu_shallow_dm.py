@@ -91,3 +91,65 @@ def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, 
     g._halo_plan = None
     L.dlesm_set_tuning(b"sw_dm_frame", 1)
     L.dlesm_set_tuning(b"sw_dm_fused", 1)
+
+
+@pytest.mark.parametrize("nx,ny,alignment,nsteps", [(40, 33, 8, 7), (257, 66, 64, 5), (130, 9, None, 6), (700, 300, 64, 9),
+                                                    (2, 3, 2, 4)])
+@pytest.mark.parametrize("chain", [1, 0])
+def test_pipelined_shallow_time_loop(D, nx, ny, alignment, nsteps, chain):
+    """a leapfrog time loop of dlesm_shallow_step_dm_pipelined (three time levels rotated by pointer,
+    the exchange of step k joined on the device by step k+1's frame workgroups, one join at the end)
+    against the oracle's step + exchange, every field and halo, bit for bit.  chain=0: the same calls
+    with the device-side join switched off (event join at the start of each step)."""
+    import torch
+    from dm_overhead import loopback_tables
+    L = D._cabi.lib()
+    L.dlesm_set_tuning(b"sw_dm_chain", chain)
+    if alignment is None:
+        os.environ.pop("DL_ESM_ALIGNMENT", None)
+    else:
+        os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    g.decompose(nx, ny)
+    D.grid_init(g, 1.0, 1.0)
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    F = {n: D.r2d_field(g, pts[n[0]]) for n in names}
+    it = F["p"].internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    g._halo_plan = plan
+    for k, n in enumerate(names[:6]):
+        D.psy.hash_init(F[n], 200 + k)
+        F[n].data.mul_(0.01)
+        F[n].data.add_(1.0 if n[0] == "p" else -0.005)
+    for n in names[6:]:
+        D.set_field(F[n], 9.0)
+    D.psy.halo_exchange_multi([F[n] for n in names[:6]])
+    torch.cuda.synchronize()
+    H = {n: F[n].get_data() for n in names}
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 20.0)
+    op = O.SwParams(prm.fsdx, prm.fsdy, prm.tdts8, prm.tdtsdx, prm.tdtsdy)
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    scratch = [np.zeros((g.ny, g.nx)) for _ in range(4)]
+
+    cur, old, new = ["u", "v", "p"], ["uold", "vold", "pold"], ["unew", "vnew", "pnew"]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(nsteps):
+            D.psy.invoke_shallow_step_dm_pipelined(prm, *[F[n] for n in cur + old + new], stream=s)
+            O.lib().orc_sw_step(C.byref(op), g.nx, *it.box(), *[H[n] for n in cur + old], *scratch, *[H[n] for n in new])
+            for n in new:
+                assert O.exchange_all([H[n]], [g.nx], [oc]) == 0
+            cur, old, new = new, cur, old                # leapfrog rotation: pointers only
+        D.psy.halo_join(g, stream=s)
+    s.synchronize()
+    for n in names:
+        assert np.array_equal(F[n].get_data(), H[n]), n
+    assert np.isfinite(H[cur[2]]).all()
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+    g._halo_plan = None
+    L.dlesm_set_tuning(b"sw_dm_chain", 1)
