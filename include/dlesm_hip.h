@@ -370,7 +370,9 @@ int dlesm_halo_exchange_f64(dlesm_halo_plan *plan, double *field, unsigned dirs_
                             void *stream);
 
 /* The same for several fields of the plan's shape at once: ONE grouped launch for all of them
- * (what a time step that updates u, v and p needs).  At most 16 fields. */
+ * (what a time step that updates u, v and p needs), ONE message per neighbour and direction that
+ * carries the strips of all the fields, field after field (an RCCL send/recv pair costs microseconds
+ * whatever its size: message count is the lever).  At most 16 fields. */
 int dlesm_halo_exchange_multi_f64(dlesm_halo_plan *plan, double *const *fields, int nfields,
                                   unsigned dirs_mask, void *stream);
 
