@@ -163,6 +163,7 @@ struct SwFrameJob {
     const unsigned long long *halo_flag;
     unsigned long long halo_seq;  // 0: no wait
     int *timed_out;
+    int diag;                     // profiling only (results wrong): 1 = no frame cells, 2 = south/north rows only
 };
 // shallow-water step, register-tiled linear sweep (dlesm_shallow.hip); 0-based inclusive box
 void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,

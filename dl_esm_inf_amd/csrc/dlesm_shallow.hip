@@ -200,7 +200,9 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
         return;
     }
     auto put = [](double *ptr, double val) { __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    const long total = frame_cells(fj.fx1 - fj.fx0 + 1, fj.fy1 - fj.fy0 + 1);
+    long total = frame_cells(fj.fx1 - fj.fx0 + 1, fj.fy1 - fj.fy0 + 1);
+    if (fj.diag & 1) total = 0;
+    if (fj.diag & 2) total = 2L * (fj.fx1 - fj.fx0 + 1);
     const bool chained = fj.halo_seq != 0;
     if (chained) {
         // time-loop form: the halos of u, v, p (and the send buffers) belong to the previous step's exchange
@@ -379,9 +381,15 @@ static std::mutex g_sw_mu;
 static std::map<SwKey, SwShape> g_sw_cache;
 static SwShape g_sw_override = {0, 0, 0};
 
+// First chunk of the first wave tile of a row: anchored on a 128-byte line of the row, not on the box --
+// measured at 8192^2 (round 2): the same sweep over a box that starts one or two columns further east
+// (the interior of the distributed step) ran 8 us (1 %) slower when its tiles started at the box.
+// Lanes west of x0 are masked.
+static inline int sw_first_chunk(int x0) { return (x0 / 2) & ~7; }
+
 static void sw_rule_shape(int ld, int x0, int x1, int *nxw_out, int *tpb_out)
 {
-    const int cb = x0 / 2, c_last = x1 / 2;
+    const int cb = sw_first_chunk(x0), c_last = x1 / 2;
     int nxw = (c_last - cb + 62) / 62, tpb = 4;          // 62 output chunks per wave tile
     // This kernel's landscape differs from the Jacobi one (nine arrays in flight): an exhaustive search at
     // 8192^2 (scripts/shallow_probe.py 8192 search; 67 tiles per row) finds 8 waves per group JUST ABOVE a
@@ -414,7 +422,7 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
                          const double *vold, const double *pold, double *unew, double *vnew,
                          double *pnew, hipStream_t s, bool sw_offset, SwFrameJob *fj)
 {
-    const int cb = x0 / 2;                               // first chunk holding an output column
+    const int cb = sw_first_chunk(x0);
     int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & 3;
     {
         std::lock_guard<std::mutex> lk(g_sw_mu);
@@ -490,6 +498,7 @@ int dlesm::launch_shallow_framed(const dlesm_sw_params &q, int ld, int ny, int x
         aligned = aligned && ((uintptr_t)f % 16 == 0);
     if (!aligned || tuning("sw_kernel", 0) != 0 || tuning("sw_tile_rows", 2) != 2 || !tuning("sw_dpp", 1)) return DLESM_OK;
     job.fx0 = xstart - 1, job.fx1 = xstop - 1, job.fy0 = ystart - 1, job.fy1 = ystop - 1;
+    job.diag = tuning("sw_dm_diag", 0);
     launch_shallow_tile(q, ld, xstart, xstop - 2, ystart, ystop - 2, u, v, p, uold, vold, pold, unew, vnew, pnew, s,
                         false, &job);
     DLESM_HIP_TRY(hipGetLastError());
@@ -645,7 +654,7 @@ extern "C" int dlesm_shallow_autotune_f64(const dlesm_sw_params *q, int ld, int 
         return rc;
     if (xstop < xstart || ystop < ystart || tuning("sw_kernel", 0) != 0) return DLESM_OK;
     const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
-    const int nxw0 = (x1 / 2 - x0 / 2 + 62) / 62;
+    const int nxw0 = (x1 / 2 - sw_first_chunk(x0) + 62) / 62;
     if (nxw0 < 16 || tuning("sw_tile_rows", 2) != 2) return DLESM_OK;      // thin boxes: nothing to choose
     hipStream_t s = (hipStream_t)stream;
     std::vector<SwShape> cand;
