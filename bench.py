@@ -491,6 +491,80 @@ def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, step
     return out
 
 
+def shallow_water_dm(D, torch, dist, tile, alignment, world, P, Q, stream, steps):
+    """Secondary object of the N > 1 lines: the distributed shallow-water step (BASELINE configs[3]'s kernel on
+    configs[4]'s per-GPU tile), time-loop form -- frame workgroups inside the interior launch, ONE grouped exchange of
+    the three new fields (one message per neighbour and direction) hidden behind the interior, joined on the device
+    by the next step -- leapfrog rotation of the nine fields, one join closing the loop inside the timed region."""
+    steps = max(min(steps, 40), MIN_SECONDARY_LAUNCHES)
+    g = make_grid(D, tile * P, tile * Q, alignment)
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    F = {}
+    with torch.cuda.stream(stream):
+        for k, name in enumerate(names):
+            F[name] = D.r2d_field(g, pts[name[0]])
+            D.psy.hash_init(F[name], SEED + k, stream=stream)
+            F[name].data.add_(1.0 if name[0] == "p" else -0.5)
+        D.psy.halo_exchange_multi([F[n] for n in names[:6]], stream=stream)
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
+    cur, old, new = [F[n] for n in names[:3]], [F[n] for n in names[3:6]], [F[n] for n in names[6:]]
+    # before timing, on every rank: pipelined step + join == plain step + grouped exchange
+    chk = [D.r2d_field(g, pts[n[0]]) for n in names[6:]]
+    with torch.cuda.stream(stream):
+        for x, y in zip(new, chk):
+            D.copy_field(x, y, stream=stream)                # cells no step writes (the domain's ring) then agree
+        D.psy.invoke_shallow_step(prm, *cur, *old, *chk, stream=stream)
+        D.psy.halo_exchange_multi(chk, stream=stream)
+        D.psy.invoke_shallow_step_dm_pipelined(prm, *cur, *old, *new, stream=stream)
+        D.psy.halo_join(g, stream=stream)
+    stream.synchronize()
+    w = F["p"].whole
+    cut = lambda f: f.data[w.ystart - 1:w.ystop, w.xstart - 1:w.xstop]      # noqa: E731
+    ok = torch.tensor([1 if all(torch.equal(cut(x), cut(y)) for x, y in zip(new, chk)) else 0], device="cuda")
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    same = bool(int(ok[0]))
+    del chk
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        old, cur, new = cur, new, old
+        for _ in range(5):
+            D.psy.invoke_shallow_step_dm_pipelined(prm, *cur, *old, *new, stream=stream)
+            old, cur, new = cur, new, old
+        D.psy.halo_join(g, stream=stream)
+    barrier()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(steps):
+            D.psy.invoke_shallow_step_dm_pipelined(prm, *cur, *old, *new, stream=stream)
+            old, cur, new = cur, new, old
+        D.psy.halo_join(g, stream=stream)                    # the one join of the loop, inside the timed region
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt[0])
+    ms = wall / steps * 1e3
+    gbs = 72 * tile * tile / (ms * 1e-3) / 1e9
+    out = {"workload": f"shallow-water u/v/h fused step, {tile}x{tile} fp64 per GPU, {P}x{Q} decomposition, "
+                       f"grouped RCCL exchange of unew/vnew/pnew (8 directions, one message each) overlapped",
+           "tile": tile, "n_gpus": world, "steps": steps, "value": round(tile * tile * world * steps / wall / 1e6, 1),
+           "unit": "Mcells/s", "ms_per_step": round(ms, 5), "hbm_gbs_per_gpu": round(gbs, 1),
+           "frac_of_hbm_peak_per_gpu": round(gbs / HBM_PEAK_GBS, 4), "scaling": "weak",
+           "dm_step_equals_step_plus_exchange": same, "checksum_p": D.field_checksum(cur[2])}
+    del F, cur, old, new
+    torch.cuda.empty_cache()
+    return out
+
+
 _STAGE = {"name": "start", "t0": time.time()}
 
 
@@ -728,6 +802,10 @@ def main():
             if not args.no_temporal_blocking:
                 stage(rank, world, "secondary leg: fused 8-step distributed form")
                 out["temporal_blocking"] = temporal_blocking_dm(D, torch, dist, args.tile, P, Q, stream, args.steps)
+            if not args.no_shallow:
+                stage(rank, world, "secondary leg: distributed shallow-water step, 8192^2 per GPU")
+                out["shallow_water_dm"] = shallow_water_dm(D, torch, dist, min(WEAK_TILE, args.tile), args.alignment, world,
+                                                           P, Q, stream, args.steps)
         except Exception as e:                               # noqa: BLE001
             dog.cancel()
             bail(f"{type(e).__name__}: {e}", 4)              # the other ranks may be stuck in a collective

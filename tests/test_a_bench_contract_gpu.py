@@ -60,3 +60,5 @@ def test_rehearsal_of_the_multi_gpu_secondary_leg():
     assert tb["halo_depth"] == 8 and tb["bit_identical_to_single_steps_plus_exchange"] is True
     w = d["weak_scaling_tile"]                          # the 8192^2 object every N > 1 line carries
     assert w["tile"] == 8192 and w["value"] > 0 and "secondary_legs_error" not in d, d
+    sw = d["shallow_water_dm"]                          # the distributed shallow-water leg of the N > 1 lines
+    assert sw["value"] > 0 and sw["dm_step_equals_step_plus_exchange"] is True, sw
