@@ -28,16 +28,18 @@ def D():
 
 @pytest.mark.parametrize("nx,ny,alignment", [(1, 1, 2), (2, 3, 2), (5, 1, 2), (1, 7, 2), (40, 33, 8), (257, 66, 64),
                                              (130, 9, None), (700, 300, 64)])
-@pytest.mark.parametrize("one_launch_frame,fused", [(1, 1), (1, 0), (0, 0)])
-def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, fused):
+@pytest.mark.parametrize("one_launch_frame,fused,aggregate", [(1, 1, 1), (1, 0, 1), (0, 0, 1), (1, 1, 0), (0, 0, 0)])
+def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, fused, aggregate):
     """fused: the ring as the first workgroups of the interior launch + device flag (default) /
-    one_launch_frame: the ring in its own launch that also fills the send buffers / the round-1 form,
-    four thin boxes + pack kernels"""
+    one_launch_frame: the ring in its own launch that also fills the send buffer / the round-1 form,
+    four thin boxes + pack kernels.  aggregate=0: one message per field and direction (24 instead of 8),
+    the form before the aggregated exchange, kept as the comparison point."""
     import torch
     from dm_overhead import loopback_tables
     L = D._cabi.lib()
     L.dlesm_set_tuning(b"sw_dm_frame", one_launch_frame)
     L.dlesm_set_tuning(b"sw_dm_fused", fused)
+    L.dlesm_set_tuning(b"dm_aggregate", aggregate)
     if alignment is None:
         os.environ.pop("DL_ESM_ALIGNMENT", None)
     else:
@@ -91,6 +93,7 @@ def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, 
     g._halo_plan = None
     L.dlesm_set_tuning(b"sw_dm_frame", 1)
     L.dlesm_set_tuning(b"sw_dm_fused", 1)
+    L.dlesm_set_tuning(b"dm_aggregate", 1)
 
 
 @pytest.mark.parametrize("nx,ny,alignment,nsteps", [(40, 33, 8, 7), (257, 66, 64, 5), (130, 9, None, 6), (700, 300, 64, 9),
