@@ -662,6 +662,9 @@ def main():
             D.copy_field(a, b, stream=stream)            # b back to its starting state
         stream.synchronize()
         planned = True
+    # the kernel the planning call settled on (rows per tile is part of the plan), for the roofline object
+    shape = D.psy.planned_shape_jacobi5(b) if planned and world == 1 else (0, 0, 0)
+    j5_kernel = f"jacobi5_tile<2,{shape[2] or 2}>" if world == 1 else "jacobi5_tile_framed<2,2>"
     fused = args.fused
     if fused != 1:
         if world > 1 or not 2 <= fused <= 8 or args.steps % fused:
@@ -749,13 +752,14 @@ def main():
                    "ld": grid.nx,
                    "halo_exchange": "rccl send/recv of the four edges, overlapped; time-loop form (device-side join)"
                    if world > 1 else "none (1 tile)",
-                   "launch_shape": "planned (dlesm_stencil5_autotune_f64, before the warm-up)" if planned else "rule"},
+                   "launch_shape": "planned (dlesm_stencil5_autotune_f64, before the warm-up)" if planned else "rule",
+                   "planned_waves_tiles_rows": list(shape)},
         "hbm_gbs_per_gpu": round(achieved, 1),
         "checksum": checksum, "dm_step_equals_stencil_plus_exchange": selfcheck,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic_for(args.tile, args.alignment, fused), "traffic_source": TRAFFIC_SOURCE,
-                     "kernel": "jacobi5_tile<2,2>" if fused == 1 else f"jacobi5xt_tile<{fused},{XT_ROWS[fused]},dpp>",
+                     "kernel": j5_kernel if fused == 1 else f"jacobi5xt_tile<{fused},{XT_ROWS[fused]},dpp>",
                      "launch_ms": round(launch_ms, 5),
                      "algorithmic_bytes_per_launch": BYTES_PER_CELL * args.tile * args.tile},
     }

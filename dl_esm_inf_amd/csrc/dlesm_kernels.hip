@@ -492,10 +492,10 @@ struct ShapeKey {
         return std::tie(ld, x0, x1, y0, y1, vec) < std::tie(o.ld, o.x0, o.x1, o.y0, o.y1, o.vec);
     }
 };
-struct Shape { int tpb, nxw; };
+struct Shape { int tpb, nxw, rows; };                   // rows = 0: the default tile height
 static std::mutex g_shape_mu;
 static std::map<ShapeKey, Shape> g_shape_cache;
-static Shape g_shape_override = {0, 0};                 // set only while the autotuner is measuring
+static Shape g_shape_override = {0, 0, 0};              // set only while the autotuner is measuring
 
 template <int VEC, bool NT>
 static void launch_tile(const double *in, double *out, int ld, int x0, int x1, int y0, int y1, int R,
@@ -506,7 +506,6 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
     // every wave access covers whole lines whatever the box: lanes left of x0 are masked
     const int c_first = (x0 / VEC) & ~(128 / (8 * VEC) - 1), c_last = x1 / VEC;
     int nxw = (c_last - c_first + 64) / 64;             // wave tiles per row
-    const int strips = (y1 - y0 + R) / R;
     int tpb = 4;                                         // tiles (waves) per block
     // Blocks go round-robin to the 8 XCDs, so the tile below a given tile runs on the XCD
     // (blocks per row) mod 8 further on: the re-read of the shared rows is an L2 hit only when
@@ -515,11 +514,17 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
     // blocks-per-row closest above a multiple of 8, and skew an exact multiple by one idle tile.
     {
         std::lock_guard<std::mutex> lk(g_shape_mu);
-        auto it = g_shape_cache.find(ShapeKey{ld, x0, x1, y0, y1, VEC});
-        if (g_shape_override.tpb) { tpb = g_shape_override.tpb; nxw = g_shape_override.nxw; }
-        else if (it != g_shape_cache.end() && tuning("j5_use_tuned", 1)) { tpb = it->second.tpb; nxw = it->second.nxw; }
+        // (the framed launch is built for 2-row tiles: it takes the best 2-row shape, kept under VEC + 100)
+        auto it = g_shape_cache.find(ShapeKey{ld, x0, x1, y0, y1, fj ? VEC + 100 : VEC});
+        int rows = 0;
+        if (g_shape_override.tpb) { tpb = g_shape_override.tpb; nxw = g_shape_override.nxw; rows = g_shape_override.rows; }
+        else if (it != g_shape_cache.end() && tuning("j5_use_tuned", 1)) { tpb = it->second.tpb; nxw = it->second.nxw; rows = it->second.rows; }
         else choose_block_shape(&nxw, &tpb);
+        // a measured tile height (2 or 3 rows: which streams better depends on the row pitch) -- not for the
+        // framed launch, whose kernel is built for 2, and not against an explicit j5_tile_rows
+        if (rows > 0 && !fj && tuning("j5_tile_rows", 0) < 1) R = rows;
     }
+    const int strips = (y1 - y0 + R) / R;
     const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
     if (fj) {
         // frame workgroups first (they are dispatched first): a multiple of 8 of them, so that the tile
@@ -1021,25 +1026,32 @@ extern "C" int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld
     const int nxw = (c_last - c_first + 64) / 64;
     if (nxw < 8) return DLESM_OK;                                 // thin boxes: nothing to choose
     std::vector<Shape> cand;
-    auto add = [&](int tpb, int t) {
+    auto add = [&](int tpb, int t, int rows) {
         for (const Shape &c : cand)
-            if (c.tpb == tpb && c.nxw == t) return;
-        cand.push_back(Shape{tpb, t});
+            if (c.tpb == tpb && c.nxw == t && c.rows == rows) return;
+        cand.push_back(Shape{tpb, t, rows});
     };
     {
         int t = nxw, tpb = 4;
         choose_block_shape(&t, &tpb);
-        add(tpb, t);                                              // the rule's own choice first
+        add(tpb, t, 0);                                           // the rule's own choice first
     }
-    for (int tpb : {8, 4}) {
-        const int period = 8 * tpb, dmax = tpb == 8 ? 3 : 1;
-        for (int k = 0; k < 2; k++) {                             // this multiple of 8 groups and the next
-            const int base = (nxw / period + k) * period;
-            for (int d = 1; d <= dmax; d++) {
-                if (base - d >= nxw) add(tpb, base - d);
-                if (base + d >= nxw) add(tpb, base + d);
+    // tile heights: 2 rows (the default) and 3 -- at 4096^2 with a 33280-byte row pitch 3 rows measured 3-4 %
+    // faster, at 16384^2 2 rows; only the 16-byte-lane form, and only when the caller has not fixed it
+    const bool try_rows = vec2 && tuning("j5_tile_rows", 0) < 1 && tuning("j5_tune_rows", 1);
+    for (int rows : {0, 3}) {
+        if (rows && !try_rows) continue;
+        for (int tpb : {8, 4}) {
+            const int period = 8 * tpb, dmax = tpb == 8 ? 3 : 1;
+            for (int k = 0; k < 2; k++) {                         // this multiple of 8 groups and the next
+                const int base = (nxw / period + k) * period;
+                for (int d = 1; d <= dmax; d++) {
+                    if (base - d >= nxw) add(tpb, base - d, rows);
+                    if (base + d >= nxw) add(tpb, base + d, rows);
+                }
             }
         }
+        if (rows) add(cand[0].tpb, cand[0].nxw, rows);            // the rule's shape at the other height
     }
     hipEvent_t e0, e1;
     DLESM_HIP_TRY(hipEventCreate(&e0));
@@ -1056,7 +1068,7 @@ extern "C" int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld
             for (int rep = 0; rep < 4 && !rc; rep++)
                 rc = launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s);
             (void)hipEventRecord(e1, s);
-            { std::lock_guard<std::mutex> lk(g_shape_mu); g_shape_override = Shape{0, 0}; }
+            { std::lock_guard<std::mutex> lk(g_shape_mu); g_shape_override = Shape{0, 0, 0}; }
             if (hipEventSynchronize(e1) != hipSuccess) rc = fail(DLESM_EHIP, "autotune: event synchronisation failed");
             float ms = 0.f;
             if (!rc && k > 0 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_of[k - 1]) best_of[k - 1] = ms;
@@ -1064,12 +1076,32 @@ extern "C" int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc) return rc;
-    Shape best = cand[0];
-    float best_ms = best_of[0] * 0.995f;                 // the rule's choice stays unless beaten by 0.5 %
-    for (size_t k = 1; k < cand.size(); k++)
+    Shape best = cand[0], best2 = cand[0];               // over all tile heights / among the default height
+    float best_ms = best_of[0] * 0.995f, best2_ms = best_ms;   // the rule's choice stays unless beaten by 0.5 %
+    for (size_t k = 1; k < cand.size(); k++) {
         if (best_of[k] < best_ms) { best_ms = best_of[k]; best = cand[k]; }
+        if (cand[k].rows == 0 && best_of[k] < best2_ms) { best2_ms = best_of[k]; best2 = cand[k]; }
+    }
     std::lock_guard<std::mutex> lk(g_shape_mu);
     g_shape_cache[ShapeKey{ld, x0, x1, y0, y1, VEC}] = best;
+    g_shape_cache[ShapeKey{ld, x0, x1, y0, y1, VEC + 100}] = best2;
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_stencil5_planned_shape(int ld, int xstart, int xstop, int ystart, int ystop, int *waves_per_group,
+                                            int *tiles_per_row, int *rows_per_tile)
+{
+    DLESM_REQUIRE(waves_per_group && tiles_per_row && rows_per_tile, "null pointer");
+    *waves_per_group = *tiles_per_row = *rows_per_tile = 0;
+    std::lock_guard<std::mutex> lk(g_shape_mu);
+    for (int vec : {2, 1}) {
+        auto it = g_shape_cache.find(ShapeKey{ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, vec});
+        if (it == g_shape_cache.end()) continue;
+        *waves_per_group = it->second.tpb;
+        *tiles_per_row = it->second.nxw;
+        *rows_per_tile = it->second.rows ? it->second.rows : (vec == 2 ? 2 : 4);
+        break;
+    }
     return DLESM_OK;
 }
 

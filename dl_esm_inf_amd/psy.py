@@ -57,6 +57,15 @@ def autotune_jacobi5(out_fld, in_fld, stream=None):
                                                   _stream_ptr(stream)))
 
 
+def planned_shape_jacobi5(out_fld):
+    """(waves per workgroup, tiles per row, rows per tile) kept by autotune_jacobi5 for this geometry, or (0, 0, 0)"""
+    g, it = out_fld.grid, out_fld.internal
+    a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    check(_cabi.lib().dlesm_stencil5_planned_shape(g.nx, it.xstart, it.xstop, it.ystart, it.ystop, C.byref(a), C.byref(b),
+                                                   C.byref(c)))
+    return a.value, b.value, c.value
+
+
 def invoke_jacobi5_x2(out_fld, in_fld, ebox=None, stream=None):
     """TWO Jacobi steps in one sweep: out = J(t) on out_fld%internal, t = J(in) on `ebox`
     (default: the same box, i.e. a fixed boundary ring) and in elsewhere"""

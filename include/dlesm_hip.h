@@ -204,11 +204,15 @@ int dlesm_stencil5_f64(const double *in, double *out, int ld, int ny,
                        int xstart, int xstop, int ystart, int ystop, void *stream);
 
 /* Optional planning call for dlesm_stencil5_f64 (in the manner of an FFT plan): times about a dozen
- * launch shapes (waves per workgroup, tiles per row) on the caller's own arrays -- each is the same
- * valid step in -> out, the results do not depend on the shape -- and remembers the fastest for
- * later calls with this (ld, box).  Synchronises `stream`.  Without it a fitted rule picks the shape. */
+ * launch shapes (waves per workgroup, tiles per row, rows per tile) on the caller's own arrays -- each
+ * is the same valid step in -> out, the results do not depend on the shape -- and remembers the fastest
+ * for later calls with this (ld, box).  Synchronises `stream`.  Without it a fitted rule picks the shape. */
 int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld, int ny,
                                 int xstart, int xstop, int ystart, int ystop, void *stream);
+/* What the planning call kept for this (ld, box): waves per workgroup, wave tiles per row, rows per
+ * tile (all 0 when no planning call has been made for it).  Host only; for logs and profiles. */
+int dlesm_stencil5_planned_shape(int ld, int xstart, int xstop, int ystart, int ystop,
+                                 int *waves_per_group, int *tiles_per_row, int *rows_per_tile);
 
 /* TWO Jacobi steps in one sweep (temporal blocking; SURVEY section 8 f.4 -- an extension,
  * the reference stops at MAX_HALO_DEPTH = 1, parallel_comms_mod.f90:48):
