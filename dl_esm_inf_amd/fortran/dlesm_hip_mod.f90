@@ -175,6 +175,14 @@ module dlesm_hip_mod
        integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
        integer(c_int) :: rc
      end function
+     function dlesm_continuity_f64(rdt, ld, ny, xstart, xstop, ystart, ystop, sshn_t, sshn_u, sshn_v, hu, hv, &
+          un, vn, area_t, ssha, stream) bind(C, name="dlesm_continuity_f64") result(rc)
+       import :: c_int, c_ptr, c_double
+       real(c_double), value :: rdt
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: sshn_t, sshn_u, sshn_v, hu, hv, un, vn, area_t, ssha, stream
+       integer(c_int) :: rc
+     end function
      function dlesm_stencil5_masked_f64(in, out, tmask, ld, ny, xstart, xstop, ystart, ystop, stream) &
           bind(C, name="dlesm_stencil5_masked_f64") result(rc)
        import :: c_int, c_ptr

@@ -50,7 +50,7 @@ module dlesm_psy_mod
   public :: invoke_jacobi5_masked, invoke_jacobi5_dm_pipelined, halo_join
   public :: invoke_shallow_step_sw, invoke_periodic_halos, invoke_stencil9, invoke_stencil9_dm
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
-  public :: invoke_shallow_step_dm_pipelined
+  public :: invoke_shallow_step_dm_pipelined, invoke_continuity
   public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5, plan_shallow_step
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
 
@@ -145,6 +145,29 @@ contains
                                    int(out%internal%ystart, c_int), int(out%internal%ystop, c_int), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_jacobi5_masked: ' // dlesm_error_text())
   end subroutine invoke_jacobi5_masked
+
+  !> The PSy layer of a kernel on all three point types whose metadata requests the cell area,
+  !!   go_arg(GO_WRITE, GO_CT, GO_POINTWISE), go_arg(GO_READ, GO_CT, GO_POINTWISE),
+  !!   go_arg(GO_READ, GO_CU, GO_STENCIL(000,110,000)) x 3, go_arg(GO_READ, GO_CV, GO_STENCIL(000,010,010)) x 3,
+  !!   go_arg(GO_READ, GO_R_SCALAR, GO_POINTWISE), go_arg(GO_READ, GO_GRID_AREA_T)
+  !! i.e. `call continuity_code(ji, jj, ssha%data, sshn_t%data, sshn_u%data, sshn_v%data, hu%data, hv%data,
+  !! un%data, vn%data, rdt, ssha%grid%area_t)` over ssha%internal (the free-surface update of a
+  !! NEMOLite2D-class model): the kernel gets the grid's area_t, on the device its mirror.
+  subroutine invoke_continuity(ssha, sshn_t, sshn_u, sshn_v, hu, hv, un, vn, rdt)
+    type(r2d_field), intent(inout), target :: ssha, sshn_t, sshn_u, sshn_v, hu, hv, un, vn
+    real(go_wp), intent(in) :: rdt
+    integer(c_int) :: rc
+    call need_device(ssha);  call need_device(sshn_t);  call need_device(sshn_u);  call need_device(sshn_v)
+    call need_device(hu);  call need_device(hv);  call need_device(un);  call need_device(vn)
+    if (.not. c_associated(ssha%grid%area_t_device)) call grid_to_device(ssha%grid)
+    rc = dlesm_continuity_f64(real(rdt, c_double), int(ssha%grid%nx, c_int), int(ssha%grid%ny, c_int), &
+                              int(ssha%internal%xstart, c_int), int(ssha%internal%xstop, c_int), &
+                              int(ssha%internal%ystart, c_int), int(ssha%internal%ystop, c_int), &
+                              field_device_data(sshn_t), field_device_data(sshn_u), field_device_data(sshn_v), &
+                              field_device_data(hu), field_device_data(hv), field_device_data(un), &
+                              field_device_data(vn), ssha%grid%area_t_device, field_device_data(ssha), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_continuity: ' // dlesm_error_text())
+  end subroutine invoke_continuity
 
   !> Optional planning call (once per field geometry, outside the time loop): lets the library time
   !! its launch shapes for invoke_jacobi5 / invoke_jacobi5_dm on these fields and keep the fastest.

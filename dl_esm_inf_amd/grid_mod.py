@@ -36,6 +36,7 @@ class grid_type:
         self.halo_width = 1
         self.tmask = None              # host copy, (ny, nx) int32 (grid_mod.f90:100)
         self._tmask_device = None      # its HBM mirror (grid_mod.f90:104-106), made on first use
+        self._area_t_device = None
 
     @property
     def tmask_device(self):
@@ -50,6 +51,17 @@ class grid_type:
     @property
     def tmask_device_ptr(self):
         return C.c_void_p(self.tmask_device.data_ptr())
+
+    @property
+    def area_t_device(self):
+        """device mirror of grid%area_t (grid_mod.f90:104-150): dx*dy everywhere, as grid_init fills it
+        on a regular grid -- made on first use, a (ny, nx) float64 tensor"""
+        if self._area_t_device is None:
+            import torch
+            if not self.nx:
+                raise _cabi.GoceanStop(_cabi.EABORT, "grid%area_t requested before grid_init")
+            self._area_t_device = torch.full((self.ny, self.nx), self.dx * self.dy, dtype=torch.float64, device="cuda")
+        return self._area_t_device
 
     def decompose(self, domainx, domainy, ndomains=None, ndomainx=None, ndomainy=None, halo_width=1):
         """grid_mod.f90:183-211"""
@@ -78,6 +90,7 @@ def grid_init(grid, dxarg, dyarg, tmask=None):
     grid.dx, grid.dy = float(dxarg), float(dyarg)
     grid.tmask = _make_tmask(grid, tmask)
     grid._tmask_device = None
+    grid._area_t_device = None
     if nranks > 1:
         if periodic:                                       # grid_mod.f90:559-564
             raise _cabi.GoceanStop(_cabi.EABORT, "map_comms call needs to be implemented for "

@@ -39,6 +39,16 @@ def invoke_stencil9_dm(out_fld, in_fld, coef, stream=None):
                                              it.xstart, it.xstop, it.ystart, it.ystop, _stream_ptr(stream)))
 
 
+def invoke_continuity(ssha, sshn_t, sshn_u, sshn_v, hu, hv, un, vn, rdt, stream=None):
+    """the continuity kernel (metadata: GO_GRID_AREA_T): fields on T, U and V points, the grid's cell
+    area from the PSy layer (its device mirror), over ssha%internal"""
+    g, it = ssha.grid, ssha.internal
+    check(_cabi.lib().dlesm_continuity_f64(float(rdt), g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop,
+                                           sshn_t.device_ptr, sshn_u.device_ptr, sshn_v.device_ptr, hu.device_ptr,
+                                           hv.device_ptr, un.device_ptr, vn.device_ptr,
+                                           C.c_void_p(g.area_t_device.data_ptr()), ssha.device_ptr, _stream_ptr(stream)))
+
+
 def invoke_jacobi5_masked(out_fld, in_fld, stream=None):
     """the masked Jacobi kernel (metadata: GO_GRID_MASK_T): the PSy layer hands the kernel the
     grid's T mask, here its device mirror"""

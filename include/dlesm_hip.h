@@ -257,6 +257,20 @@ int dlesm_stencil9_f64(const double *in, double *out, const double *coef, int ld
 int dlesm_stencil5_masked_f64(const double *in, double *out, const int *tmask, int ld, int ny,
                               int xstart, int xstop, int ystart, int ystop, void *stream);
 
+/* A kernel on all three C-grid point types that also takes a double-precision GRID PROPERTY
+ * (GO_GRID_AREA_T, argument_mod.f90:75-112; the PSy layer passes grid%area_t, on the device its mirror
+ * grid%area_t_device, grid_mod.f90:104-150): the free-surface (continuity) update of a NEMOLite2D-class
+ * model over the box,
+ *   r1 = (sshn_u(ji,jj)+hu(ji,jj))*un(ji,jj)         r2 = the same at (ji-1,jj)
+ *   r3 = (sshn_v(ji,jj)+hv(ji,jj))*vn(ji,jj)         r4 = the same at (ji,jj-1)
+ *   ssha(ji,jj) = sshn_t(ji,jj) + (((r2 - r1) + r4) - r3) * rdt / area_t(ji,jj)
+ * (specification frozen in DESIGN.md section 5.10; the reference holds no such loop).  72 B/cell.
+ * ssha may alias sshn_t only. */
+int dlesm_continuity_f64(double rdt, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                         const double *sshn_t, const double *sshn_u, const double *sshn_v,
+                         const double *hu, const double *hv, const double *un, const double *vn,
+                         const double *area_t, double *ssha, void *stream);
+
 /* Shallow-water u/v/h update: reads u,v,p (3x3 footprint)
  * and uold,vold,pold, writes unew,vnew,pnew on the box. */
 typedef struct dlesm_sw_params {

@@ -619,6 +619,30 @@ void orc_stencil9(const double *in, double *out, const double *coef, int ld,
         for (int ji = xstart; ji <= xstop; ji++) stencil9_code(ji, jj, out, in, coef, ld);
 }
 
+/* Free-surface (continuity) update of a NEMOLite2D-class model in GOcean kernel form: fields on T, U and V
+ * points plus the grid property area_t (GO_GRID_AREA_T, argument_mod.f90:75-112).  Specification frozen in
+ * DESIGN.md section 5.10; the Fortran expression `(rtmp2 - rtmp1 + rtmp4 - rtmp3) * rdt / e12t` evaluates
+ * left to right.  PARITY UNPINNED by the reference (it holds no such kernel). */
+static inline void continuity_code(int ji, int jj, double *ssha, const double *sshn_t, const double *sshn_u,
+                                   const double *sshn_v, const double *hu, const double *hv, const double *un,
+                                   const double *vn, double rdt, const double *area_t, int ld)
+{
+    const double rtmp1 = (sshn_u[IDX(ld, ji, jj)] + hu[IDX(ld, ji, jj)]) * un[IDX(ld, ji, jj)];
+    const double rtmp2 = (sshn_u[IDX(ld, ji - 1, jj)] + hu[IDX(ld, ji - 1, jj)]) * un[IDX(ld, ji - 1, jj)];
+    const double rtmp3 = (sshn_v[IDX(ld, ji, jj)] + hv[IDX(ld, ji, jj)]) * vn[IDX(ld, ji, jj)];
+    const double rtmp4 = (sshn_v[IDX(ld, ji, jj - 1)] + hv[IDX(ld, ji, jj - 1)]) * vn[IDX(ld, ji, jj - 1)];
+    ssha[IDX(ld, ji, jj)] = sshn_t[IDX(ld, ji, jj)] + (rtmp2 - rtmp1 + rtmp4 - rtmp3) * rdt / area_t[IDX(ld, ji, jj)];
+}
+
+void orc_continuity(double rdt, int ld, int xstart, int xstop, int ystart, int ystop, const double *sshn_t,
+                    const double *sshn_u, const double *sshn_v, const double *hu, const double *hv, const double *un,
+                    const double *vn, const double *area_t, double *ssha)
+{
+    for (int jj = ystart; jj <= ystop; jj++)
+        for (int ji = xstart; ji <= xstop; ji++)
+            continuity_code(ji, jj, ssha, sshn_t, sshn_u, sshn_v, hu, hv, un, vn, rdt, area_t, ld);
+}
+
 void orc_jacobi5_omp(const double *in, double *out, int ld,
                      int xstart, int xstop, int ystart, int ystop, int nthreads)
 {

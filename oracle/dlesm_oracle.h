@@ -115,6 +115,10 @@ void orc_jacobi5(const double *in, double *out, int ld,
 /* general 3x3 weighted stencil, coef[(dj+1)*3 + (di+1)] */
 void orc_stencil9(const double *in, double *out, const double *coef, int ld,
                   int xstart, int xstop, int ystart, int ystop);
+/* continuity (free-surface) update: T, U, V fields + the grid property area_t */
+void orc_continuity(double rdt, int ld, int xstart, int xstop, int ystart, int ystop, const double *sshn_t,
+                    const double *sshn_u, const double *sshn_v, const double *hu, const double *hv, const double *un,
+                    const double *vn, const double *area_t, double *ssha);
 /* masked 5-point Jacobi (kernel with a GO_GRID_MASK_T argument); grid_init's tmask fill */
 void orc_jacobi5_masked(const double *in, double *out, const int *tmask, int ld,
                         int xstart, int xstop, int ystart, int ystop);

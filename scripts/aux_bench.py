@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Rates of the utility kernels around the hot path (one MI355X): masked Jacobi (20 B/cell), checksum
+"""Rates of the other kernels around the hot path (one MI355X): masked Jacobi (20 B/cell), continuity (72 B/cell), checksum
 (8 B/cell read), whole-field copy (16 B/cell), fill (8 B/cell written), hash init (8 B/cell written),
 gather pack + unpack (16 B/cell each), periodic halo copies.   python scripts/aux_bench.py [tile]"""
 import ctypes as C
@@ -52,6 +52,13 @@ timed("jacobi5 (reference point)", lambda: D.psy.invoke_jacobi5(b, a, stream=s),
 timed("stencil9 (general 3x3 weights)", lambda: D.psy.invoke_stencil9(b, a, [0.0625, 0.125, 0.0625, 0.125, 0.25, 0.125,
                                                                                   0.0625, 0.125, 0.0625], stream=s), 16)
 timed("jacobi5 masked, all-wet mask", lambda: D.psy.invoke_jacobi5_masked(b, a, stream=s), 20)
+CF = [D.r2d_field(g, p) for p in (D.GO_T_POINTS, D.GO_T_POINTS, D.GO_U_POINTS, D.GO_V_POINTS, D.GO_U_POINTS,
+                                  D.GO_V_POINTS, D.GO_U_POINTS, D.GO_V_POINTS)]
+for k, f in enumerate(CF[1:]):
+    D.psy.hash_init(f, 40 + k, stream=s)
+g.area_t_device
+timed("continuity (T, U, V fields + grid%area_t)", lambda: D.psy.invoke_continuity(*CF, 0.5, stream=s), 72)
+del CF
 timed("copy_field (whole field)", lambda: D.copy_field(a, b, stream=s), 16)
 timed("set_field (fill)", lambda: D.set_field(b, 1.0, stream=s), 8)
 timed("hash_init", lambda: D.psy.hash_init(b, 7, stream=s), 8)

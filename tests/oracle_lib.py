@@ -95,6 +95,8 @@ def lib():
     L.orc_jacobi5_omp.argtypes = [_dp, _dp] + [C.c_int] * 6
     _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
     L.orc_stencil9.argtypes = [_dp, _dp, _dp] + [C.c_int] * 5
+    L.orc_continuity.argtypes = [C.c_double] + [C.c_int] * 5 + [_dp] * 9
+    L.orc_continuity.restype = None
     L.orc_jacobi5_masked.argtypes = [_dp, _dp, _ip] + [C.c_int] * 5
     L.orc_tmask_fill.argtypes = [C.c_void_p] + [C.c_int] * 7 + [_ip]
     L.orc_sw_step.argtypes = [C.POINTER(SwParams)] + [C.c_int] * 5 + [_dp] * 13
@@ -272,6 +274,10 @@ def periodic_halos(internal, bcx, bcy):
 def apply_periodic_halos(f, ld, internal, bcx, bcy):
     it = Region(0, 0, *internal)
     lib().orc_apply_periodic_halos(f, ld, C.byref(it), bcx, bcy)
+
+
+def continuity(rdt, ld, box, sshn_t, sshn_u, sshn_v, hu, hv, un, vn, area_t, ssha):
+    lib().orc_continuity(rdt, ld, *box, sshn_t, sshn_u, sshn_v, hu, hv, un, vn, area_t, ssha)
 
 
 def stencil9(inp, out, coef, ld, xs, xe, ys, ye):

@@ -757,6 +757,64 @@ def test_stencil9_distributed_step_loopback(D, nx, ny, alignment, corner_weights
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
+# --------------------------------------------------------------------------- continuity kernel (grid%area_t)
+def _continuity_fields(D, g):
+    pts = [D.GO_T_POINTS, D.GO_T_POINTS, D.GO_U_POINTS, D.GO_V_POINTS, D.GO_U_POINTS, D.GO_V_POINTS, D.GO_U_POINTS,
+           D.GO_V_POINTS]
+    F = [D.r2d_field(g, p) for p in pts]                # ssha, sshn_t, sshn_u, sshn_v, hu, hv, un, vn
+    for k, f in enumerate(F[1:]):
+        D.psy.hash_init(f, SEED + 80 + k)
+        f.data.add_(-0.3)
+    return F
+
+
+@pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (64, 48, 8), (300, 70, 64), (257, 129, None), (1, 1, 2),
+                                             (129, 3, 2), (1000, 37, 64), (4100, 9, 64)])
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_continuity_matches_oracle(D, nx, ny, alignment, kernel):
+    """dlesm_continuity_f64 (wave-tile form and one-cell-per-thread form) against orc_continuity, bit for
+    bit; the kernel's grid property is the grid's own area_t mirror; cells outside the box untouched"""
+    import torch
+    _set_tuning(D, cont_kernel=kernel)
+    g = _grid(D, nx, ny, alignment)
+    F = _continuity_fields(D, g)
+    D.set_field(F[0], -3.0)
+    g.area_t_device.copy_(torch.from_numpy(np.random.default_rng(nx).random((g.ny, g.nx)) + 0.5))   # a non-uniform grid
+    H = [f.get_data() for f in F]
+    area = g.area_t_device.cpu().numpy()
+    it = F[0].internal
+    D.psy.invoke_continuity(*F, 0.37)
+    O.continuity(0.37, g.nx, it.box(), *H[1:], area, H[0])
+    torch.cuda.synchronize()
+    assert np.array_equal(F[0].get_data(), H[0])
+    _set_tuning(D, cont_kernel=0)
+
+
+def test_continuity_full_size_properties(D):
+    """8192^2: no flow leaves the surface where it was, exactly; sampled rows against oracle slabs bit for bit"""
+    import torch
+    n = 8192
+    g = _grid(D, n, n, 64)
+    F = _continuity_fields(D, g)
+    it = F[0].internal
+    D.set_field(F[0], -1.0)
+    assert float(g.area_t_device[5, 5]) == g.dx * g.dy
+    zero_u, zero_v = D.r2d_field(g, D.GO_U_POINTS), D.r2d_field(g, D.GO_V_POINTS)
+    D.psy.invoke_continuity(F[0], F[1], F[2], F[3], F[4], F[5], zero_u, zero_v, 0.5)
+    inner = lambda f: f.data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop]      # noqa: E731
+    assert bool(torch.equal(inner(F[0]), inner(F[1])))
+    D.psy.invoke_continuity(*F, 0.5)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(6)
+    for jj in sorted(set([it.ystart, it.ystop] + [int(r) for r in rng.integers(it.ystart, it.ystop + 1, 8)])):
+        slabs = [f.data[jj - 2:jj, :].cpu().numpy() for f in F[1:]]               # rows jj-1 and jj (1-based)
+        area = g.area_t_device[jj - 2:jj, :].cpu().numpy()
+        want = np.full_like(slabs[0], -1.0)
+        O.continuity(0.5, g.nx, (it.xstart, it.xstop, 2, 2), *slabs, area, want)
+        assert np.array_equal(F[0].data[jj - 1, :].cpu().numpy(), want[1]), jj
+    assert bool((F[0].data[0, :] == -1.0).all()) and bool((F[0].data[:, 0] == -1.0).all())
+
+
 # --------------------------------------------------------------------------- hipGraph capture
 def test_time_loop_captured_into_a_graph(D):
     """two ping-pong Jacobi steps + two 9-point steps captured into one hipGraph on a side stream and

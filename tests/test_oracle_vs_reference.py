@@ -421,6 +421,34 @@ def test_periodic_sw_model_conserves_mass_and_is_translation_invariant():
         assert np.array_equal(np.roll(fa[1:n + 1, 1:n + 1], (5, 3), axis=(0, 1)), fb[1:n + 1, 1:n + 1])
 
 
+# --------------------------------------------------------------------------- continuity kernel
+def test_continuity_against_numpy():
+    """PARITY UNPINNED by the reference (it holds no such kernel).  orc_continuity (per-point GOcean
+    kernel form) against a whole-array numpy evaluation of DESIGN.md section 5.10, bit for bit; no flow
+    leaves the surface where it was; a uniform flow over a flat bed too"""
+    rng = np.random.default_rng(10)
+    for n, m, ld in [(37, 23, 44), (64, 48, 67), (5, 3, 8), (1, 1, 3)]:
+        st, su, sv, hu, hv, un, vn = (rng.random((m + 3, ld)) - 0.3 for _ in range(7))
+        area = rng.random((m + 3, ld)) + 0.5
+        out = np.full((m + 3, ld), -7.0)
+        O.continuity(0.37, ld, (2, n + 1, 2, m + 1), st, su, sv, hu, hv, un, vn, area, out)
+        V = lambda a, dj, di: a[1 + dj:m + 1 + dj, 1 + di:n + 1 + di]          # noqa: E731
+        r1 = (V(su, 0, 0) + V(hu, 0, 0)) * V(un, 0, 0)
+        r2 = (V(su, 0, -1) + V(hu, 0, -1)) * V(un, 0, -1)
+        r3 = (V(sv, 0, 0) + V(hv, 0, 0)) * V(vn, 0, 0)
+        r4 = (V(sv, -1, 0) + V(hv, -1, 0)) * V(vn, -1, 0)
+        want = V(st, 0, 0) + (((r2 - r1) + r4) - r3) * 0.37 / V(area, 0, 0)
+        assert np.array_equal(out[1:m + 1, 1:n + 1], want)
+        out[1:m + 1, 1:n + 1] = -7.0
+        assert np.all(out == -7.0)
+        zero = np.zeros_like(un)
+        O.continuity(0.37, ld, (2, n + 1, 2, m + 1), st, su, sv, hu, hv, zero, zero, area, out)
+        assert np.array_equal(out[1:m + 1, 1:n + 1], st[1:m + 1, 1:n + 1])
+        one, two = np.ones_like(un), np.full_like(un, 2.0)
+        O.continuity(0.37, ld, (2, n + 1, 2, m + 1), st, zero, zero, two, two, one, one, area, out)
+        assert np.array_equal(out[1:m + 1, 1:n + 1], st[1:m + 1, 1:n + 1])          # (2 - 2 + 2 - 2) = 0
+
+
 # --------------------------------------------------------------------------- general 9-point stencil
 def test_stencil9_against_numpy():
     """PARITY UNPINNED by the reference (it has no stencil).  orc_stencil9 (per-point GOcean kernel
