@@ -663,8 +663,9 @@ def main():
         stream.synchronize()
         planned = True
     # the kernel the planning call settled on (rows per tile is part of the plan), for the roofline object
-    shape = D.psy.planned_shape_jacobi5(b) if planned and world == 1 else (0, 0, 0)
-    j5_kernel = f"jacobi5_tile<2,{shape[2] or 2}>" if world == 1 else "jacobi5_tile_framed<2,2>"
+    shape = D.psy.planned_shape_jacobi5(b)
+    nt = 2 if shape[3] else 0
+    j5_kernel = f"jacobi5_tile<2,{shape[2] or 2},{nt}>" if world == 1 else f"jacobi5_tile_framed<2,2,{nt}>"
     fused = args.fused
     if fused != 1:
         if world > 1 or not 2 <= fused <= 8 or args.steps % fused:
@@ -753,7 +754,7 @@ def main():
                    "halo_exchange": "rccl send/recv of the four edges, overlapped; time-loop form (device-side join)"
                    if world > 1 else "none (1 tile)",
                    "launch_shape": "planned (dlesm_stencil5_autotune_f64, before the warm-up)" if planned else "rule",
-                   "planned_waves_tiles_rows": list(shape)},
+                   "planned_waves_tiles_rows_ntstores": list(shape)},
         "hbm_gbs_per_gpu": round(achieved, 1),
         "checksum": checksum, "dm_step_equals_stencil_plus_exchange": selfcheck,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -108,7 +108,7 @@ PROTOTYPES = {
     "dlesm_write_to_device": (None, [_vp, _vp, _i, _i, _i, _i, C.c_bool]),
     "dlesm_transfer_sync": (_i, []),
     "dlesm_stencil5_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "dlesm_stencil5_planned_shape": (_i, [_i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "dlesm_stencil5_planned_shape": (_i, [_i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "dlesm_continuity_f64": (_i, [_d, _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_stencil9_f64": (_i, [_vp, _vp, C.POINTER(_d), _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_stencil9_step_dm": (_i, [_vp, _vp, _vp, C.POINTER(_d), _i, _i, _i, _i, _i, _i, _vp]),

@@ -79,6 +79,9 @@ struct FramePack {
 };
 int launch_stencil5_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop,
                           int ystart, int ystop, hipStream_t s, const FramePack *pack = nullptr);
+// non-temporal stores for a sweep over rows y0..y1 of arrays of leading dimension ld? (dlesm_kernels.hip)
+int nt_stores_for(int ld, int y0, int y1);
+
 // general 3x3 weighted stencil (dlesm_stencil9.hip): the sweep over a box, and the one-cell frame of a
 // box in one launch (its west/east columns also written into the send buffer)
 int launch_stencil9(const double *in, double *out, const double *coef, int ld, int ny, int xstart, int xstop,

@@ -223,7 +223,9 @@ __global__ __launch_bounds__(256) void jacobi5_march(const double *__restrict__ 
 // Per-XCD row bands and an XCD-affine column-major tile order were built, measured
 // (70 %, 69-70 % against 75-78 %; profiles/r01_sweep_tile_group.txt) and removed.
 // ===========================================================================
-template <int VEC, int R, bool NT>
+// NT: cache policy -- bit 0: non-temporal loads, bit 1: non-temporal stores.  Loads never pay (the rows are
+// re-read by the tile below); stores do once the two arrays no longer fit the Infinity Cache -- see launch_tile.
+template <int VEC, int R, int NT>
 __device__ __forceinline__ void jacobi5_tile_body(const double *__restrict__ in, double *__restrict__ out,
                                                   int ld, int x0, int x1, int y0, int y1, int c_first,
                                                   int nxw, int flags, unsigned block)
@@ -267,7 +269,7 @@ __device__ __forceinline__ void jacobi5_tile_body(const double *__restrict__ in,
     for (int u = 0; u < R + 2; u++) {
         int jj = jb - 1 + u;
         if (jj > je + 1) jj = je + 1;
-        r[u] = load_chunk<VEC, NT>(pin + (size_t)jj * ld);
+        r[u] = load_chunk<VEC, (NT & 1) != 0>(pin + (size_t)jj * ld);
         e[u] = ecol >= 0 ? in[(size_t)jj * ld + ecol] : 0.0;
     }
 #pragma unroll
@@ -275,12 +277,12 @@ __device__ __forceinline__ void jacobi5_tile_body(const double *__restrict__ in,
         if (jb + u <= je) {
             double o[VEC];
             jacobi_row<VEC>(r[u], r[u + 1], r[u + 2], e[u + 1], lane, o);
-            store_chunk<VEC, NT>(pout + (size_t)(jb + u) * ld, o, m0, m1);
+            store_chunk<VEC, (NT & 2) != 0>(pout + (size_t)(jb + u) * ld, o, m0, m1);
         }
     }
 }
 
-template <int VEC, int R, bool NT>
+template <int VEC, int R, int NT>
 __global__ __launch_bounds__(1024) void jacobi5_tile(const double *__restrict__ in,
                                                     double *__restrict__ out, int ld, int x0, int x1,
                                                     int y0, int y1, int c_first, int nxw, int flags)
@@ -337,7 +339,7 @@ __device__ __forceinline__ void frame_cell(long t, const double *__restrict__ in
 // then); all other workgroups are the ordinary linear tile sweep over the interior (x0:x1, y0:y1).
 // No frame launch and no event record between frame and interior on the caller's stream: measured,
 // those cost it ~5 us of a 180 us step (scripts/syncbench.hip, profiles/r02_syncbench.txt).
-template <int VEC, int R, bool NT>
+template <int VEC, int R, int NT>
 __global__ __launch_bounds__(1024) void jacobi5_tile_framed(const double *__restrict__ in,
                                                            double *__restrict__ out, int ld, int x0, int x1,
                                                            int y0, int y1, int c_first, int nxw, int flags,
@@ -497,6 +499,15 @@ static std::mutex g_shape_mu;
 static std::map<ShapeKey, Shape> g_shape_cache;
 static Shape g_shape_override = {0, 0, 0};              // set only while the autotuner is measuring
 
+// Store policy of the two-to-three-stream sweeps (Jacobi, 3x3, masked, whole-field copy): non-temporal once
+// an array of the box's height no longer shares the 256 MB Infinity Cache with its partner (measured, see
+// launch_tile); j5_nt_stores = 1 / 0 forces it on / off.
+int nt_stores_for(int ld, int y0, int y1)
+{
+    const int t = tuning("j5_nt_stores", -1);
+    return t >= 0 ? (t != 0) : (size_t)ld * (size_t)(y1 - y0 + 3) * sizeof(double) >= ((size_t)400 << 20);
+}
+
 template <int VEC, bool NT>
 static void launch_tile(const double *in, double *out, int ld, int x0, int x1, int y0, int y1, int R,
                         int flags, hipStream_t s, FrameJob *fj = nullptr)
@@ -526,6 +537,11 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
     }
     const int strips = (y1 - y0 + R) / R;
     const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
+    // Non-temporal stores of `out` (j5_nt_stores: 1 on, 0 off, -1 = by size).  Measured, same process, planned
+    // shapes: 16384^2 0.787-0.793 of peak against 0.760-0.780, 8192^2 0.782 against 0.758-0.773, but 4096^2
+    // 0.729 against 0.747-0.761 -- two 134 MB arrays ping-pong through the 256 MB Infinity Cache, and a store
+    // that bypasses it takes the next step's input away.  So: on from 400 MB per array.
+    const int nts = nt_stores_for(ld, y0, y1);
     if (fj) {
         // frame workgroups first (they are dispatched first): a multiple of 8 of them, so that the tile
         // workgroups keep the XCD each would have had in the plain launch (round-robin dealing)
@@ -533,15 +549,30 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
             const long cells = 2L * (fj->fx1 - fj->fx0 + 1) + 2L * (fj->fy1 - fj->fy0 + 1);
             long nb = ((cells + 64 * tpb - 1) / (64 * tpb) + 7) & ~7L;
             fj->nblocks = (int)(nb < 8 ? 8 : nb > 256 ? 256 : nb);
-            hipLaunchKernelGGL((jacobi5_tile_framed<2, 2, false>), dim3(grid + fj->nblocks), dim3(64 * tpb), 0, s, in,
-                               out, ld, x0, x1, y0, y1, c_first, nxw, flags, *fj);
+            if (nts)
+                hipLaunchKernelGGL((jacobi5_tile_framed<2, 2, 2>), dim3(grid + fj->nblocks), dim3(64 * tpb), 0, s, in,
+                                   out, ld, x0, x1, y0, y1, c_first, nxw, flags, *fj);
+            else
+                hipLaunchKernelGGL((jacobi5_tile_framed<2, 2, 0>), dim3(grid + fj->nblocks), dim3(64 * tpb), 0, s, in,
+                                   out, ld, x0, x1, y0, y1, c_first, nxw, flags, *fj);
         }
         return;
     }
     // (capping the resident waves with unused LDS -- 32 down to 16 waves per CU -- changes nothing
     // until 16, where it costs 2 %: the band of rows in flight is not a lever)
+    if constexpr (VEC == 2 && !NT) {
+        if (nts && (R == 2 || R == 3)) {                 // the two heights the planner chooses from
+            if (R == 2)
+                hipLaunchKernelGGL((jacobi5_tile<2, 2, 2>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, x0, x1, y0, y1,
+                                   c_first, nxw, flags);
+            else
+                hipLaunchKernelGGL((jacobi5_tile<2, 3, 2>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, x0, x1, y0, y1,
+                                   c_first, nxw, flags);
+            return;
+        }
+    }
 #define DLESM_TILE(RR)                                                                               \
-    hipLaunchKernelGGL((jacobi5_tile<VEC, RR, NT>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, x0, x1, \
+    hipLaunchKernelGGL((jacobi5_tile<VEC, RR, (NT ? 3 : 0)>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, x0, x1, \
                        y0, y1, c_first, nxw, flags)
     switch (R) {
     case 1: DLESM_TILE(1); break;
@@ -893,11 +924,14 @@ __global__ void copy_patch_k(const double *__restrict__ src, double *__restrict_
 
 // whole rows of a field are one contiguous block: the linear copy that sets the measured ceiling
 // (scripts/membench.hip), one 16-byte element per thread, workgroups sweeping memory front to back
+template <bool NTS>
 __global__ __launch_bounds__(256) void copy_linear_k(const double *__restrict__ src, double *__restrict__ dst, size_t n2)
 {
     typedef double d2 __attribute__((ext_vector_type(2)));
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n2) ((d2 *)dst)[i] = ((const d2 *)src)[i];
+    if (i >= n2) return;
+    if (NTS) __builtin_nontemporal_store(((const d2 *)src)[i], (d2 *)dst + i);
+    else ((d2 *)dst)[i] = ((const d2 *)src)[i];
 }
 
 __global__ void fill_k(double *__restrict__ f, int ld, int x0, int y0, int nx, int ny, double value)
@@ -1089,10 +1123,11 @@ extern "C" int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld
 }
 
 extern "C" int dlesm_stencil5_planned_shape(int ld, int xstart, int xstop, int ystart, int ystop, int *waves_per_group,
-                                            int *tiles_per_row, int *rows_per_tile)
+                                            int *tiles_per_row, int *rows_per_tile, int *nt_stores)
 {
-    DLESM_REQUIRE(waves_per_group && tiles_per_row && rows_per_tile, "null pointer");
+    DLESM_REQUIRE(waves_per_group && tiles_per_row && rows_per_tile && nt_stores, "null pointer");
     *waves_per_group = *tiles_per_row = *rows_per_tile = 0;
+    *nt_stores = nt_stores_for(ld, ystart - 1, ystop - 1);
     std::lock_guard<std::mutex> lk(g_shape_mu);
     for (int vec : {2, 1}) {
         auto it = g_shape_cache.find(ShapeKey{ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, vec});
@@ -1173,8 +1208,12 @@ extern "C" int dlesm_copy_patch_f64(const double *src, double *dst, int ld, int 
     double *d0 = dst + lin(ld, dx0, dy0);
     if (nx == ld && n % 2 == 0 && (uintptr_t)s0 % 16 == 0 && (uintptr_t)d0 % 16 == 0 && n / 2 < ((size_t)1 << 31) * 256) {
         // whole rows (field_copy_code over a whole field, copy_field of a field): contiguous
-        hipLaunchKernelGGL(copy_linear_k, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s0, d0,
-                           n / 2);
+        if (nt_stores_for(ld, 0, ny - 1))
+            hipLaunchKernelGGL(copy_linear_k<true>, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               s0, d0, n / 2);
+        else
+            hipLaunchKernelGGL(copy_linear_k<false>, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               s0, d0, n / 2);
     } else {
         hipLaunchKernelGGL(copy_patch_k, grid2d(nx, ny), dim3(256), 0, (hipStream_t)stream, src, dst, ld,
                            sx0 - 1, sy0 - 1, dx0 - 1, dy0 - 1, nx, ny);

@@ -35,6 +35,7 @@ __device__ __forceinline__ double masked_point(double c, double w, double e, dou
 
 constexpr int R = 2;
 
+template <bool NTS>
 __global__ __launch_bounds__(1024) void jacobi5_masked_tile(const double *__restrict__ in,
                                                            double *__restrict__ out,
                                                            const int *__restrict__ tmask, int ld, int x0,
@@ -79,8 +80,10 @@ __global__ __launch_bounds__(1024) void jacobi5_masked_tile(const double *__rest
         const double o0 = masked_point(v[k].x, vw, v[k].y, v[k - 1].x, v[k + 1].x, m[k].x, mw, m[k].y, m[k - 1].x, m[k + 1].x);
         const double o1 = masked_point(v[k].y, v[k].x, ve, v[k - 1].y, v[k + 1].y, m[k].y, m[k].x, me, m[k - 1].y, m[k + 1].y);
         double *po = out + (size_t)(jb + k - 1) * ld + (size_t)c * 2;
-        if (m0 && m1) *(d2 *)po = d2{o0, o1};
-        else {
+        if (m0 && m1) {
+            if (NTS) __builtin_nontemporal_store(d2{o0, o1}, (d2 *)po);
+            else *(d2 *)po = d2{o0, o1};
+        } else {
             if (m0) po[0] = o0;
             if (m1) po[1] = o1;
         }
@@ -126,8 +129,12 @@ extern "C" int dlesm_stencil5_masked_f64(const double *in, double *out, const in
         choose_block_shape(&nxw, &tpb);
         const int strips = (y1 - y0 + R) / R;
         const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
-        hipLaunchKernelGGL(jacobi5_masked_tile, dim3(grid), dim3(64 * tpb), 0, s, in, out, tmask, ld, x0, x1, y0, y1,
-                           c_first, nxw);
+        if (nt_stores_for(ld, y0, y1))
+            hipLaunchKernelGGL(jacobi5_masked_tile<true>, dim3(grid), dim3(64 * tpb), 0, s, in, out, tmask, ld, x0, x1, y0,
+                               y1, c_first, nxw);
+        else
+            hipLaunchKernelGGL(jacobi5_masked_tile<false>, dim3(grid), dim3(64 * tpb), 0, s, in, out, tmask, ld, x0, x1, y0,
+                               y1, c_first, nxw);
     } else {
         const int h = y1 - y0 + 1;
         hipLaunchKernelGGL(jacobi5_masked_direct, dim3((x1 - x0 + 256) / 256, h > 4096 ? 4096 : h), dim3(256), 0, s, in,

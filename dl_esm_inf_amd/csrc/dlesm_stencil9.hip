@@ -37,6 +37,7 @@ __device__ __forceinline__ double point9(const Coef9 &k, double sw, double s, do
 
 constexpr int R = 2;
 
+template <bool NTS>
 __global__ __launch_bounds__(1024) void stencil9_tile(const double *__restrict__ in, double *__restrict__ out,
                                                      Coef9 k, int ld, int x0, int x1, int y0, int y1, int c_first,
                                                      int nxw)
@@ -81,8 +82,10 @@ __global__ __launch_bounds__(1024) void stencil9_tile(const double *__restrict__
         const double o0 = point9(k, vw[r - 1], v[r - 1].x, v[r - 1].y, vw[r], v[r].x, v[r].y, vw[r + 1], v[r + 1].x, v[r + 1].y);
         const double o1 = point9(k, v[r - 1].x, v[r - 1].y, ve[r - 1], v[r].x, v[r].y, ve[r], v[r + 1].x, v[r + 1].y, ve[r + 1]);
         double *po = out + (size_t)(jb + r - 1) * ld + (size_t)c * 2;
-        if (m0 && m1) *(d2 *)po = d2{o0, o1};
-        else {
+        if (m0 && m1) {
+            if (NTS) __builtin_nontemporal_store(d2{o0, o1}, (d2 *)po);
+            else *(d2 *)po = d2{o0, o1};
+        } else {
             if (m0) po[0] = o0;
             if (m1) po[1] = o1;
         }
@@ -155,7 +158,10 @@ int launch_stencil9(const double *in, double *out, const double *coef, int ld, i
         choose_block_shape(&nxw, &tpb);
         const int strips = (y1 - y0 + R) / R;
         const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
-        hipLaunchKernelGGL(stencil9_tile, dim3(grid), dim3(64 * tpb), 0, s, in, out, k, ld, x0, x1, y0, y1, c_first, nxw);
+        if (nt_stores_for(ld, y0, y1))
+            hipLaunchKernelGGL(stencil9_tile<true>, dim3(grid), dim3(64 * tpb), 0, s, in, out, k, ld, x0, x1, y0, y1, c_first, nxw);
+        else
+            hipLaunchKernelGGL(stencil9_tile<false>, dim3(grid), dim3(64 * tpb), 0, s, in, out, k, ld, x0, x1, y0, y1, c_first, nxw);
     } else {
         const int h = y1 - y0 + 1;
         hipLaunchKernelGGL(stencil9_direct, dim3((x1 - x0 + 256) / 256, h > 4096 ? 4096 : h), dim3(256), 0, s, in, out, k,

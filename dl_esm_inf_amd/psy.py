@@ -68,12 +68,13 @@ def autotune_jacobi5(out_fld, in_fld, stream=None):
 
 
 def planned_shape_jacobi5(out_fld):
-    """(waves per workgroup, tiles per row, rows per tile) kept by autotune_jacobi5 for this geometry, or (0, 0, 0)"""
+    """(waves per workgroup, tiles per row, rows per tile, non-temporal stores) for this geometry; the first
+    three are 0 before autotune_jacobi5 has run for it"""
     g, it = out_fld.grid, out_fld.internal
-    a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    a, b, c, d = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
     check(_cabi.lib().dlesm_stencil5_planned_shape(g.nx, it.xstart, it.xstop, it.ystart, it.ystop, C.byref(a), C.byref(b),
-                                                   C.byref(c)))
-    return a.value, b.value, c.value
+                                                   C.byref(c), C.byref(d)))
+    return a.value, b.value, c.value, d.value
 
 
 def invoke_jacobi5_x2(out_fld, in_fld, ebox=None, stream=None):

@@ -210,9 +210,11 @@ int dlesm_stencil5_f64(const double *in, double *out, int ld, int ny,
 int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld, int ny,
                                 int xstart, int xstop, int ystart, int ystop, void *stream);
 /* What the planning call kept for this (ld, box): waves per workgroup, wave tiles per row, rows per
- * tile (all 0 when no planning call has been made for it).  Host only; for logs and profiles. */
+ * tile (all 0 when no planning call has been made for it), and whether `out` is stored non-temporally
+ * (by size: on once the arrays no longer fit the Infinity Cache).  Host only; for logs and profiles. */
 int dlesm_stencil5_planned_shape(int ld, int xstart, int xstop, int ystart, int ystop,
-                                 int *waves_per_group, int *tiles_per_row, int *rows_per_tile);
+                                 int *waves_per_group, int *tiles_per_row, int *rows_per_tile,
+                                 int *nt_stores);
 
 /* TWO Jacobi steps in one sweep (temporal blocking; SURVEY section 8 f.4 -- an extension,
  * the reference stops at MAX_HALO_DEPTH = 1, parallel_comms_mod.f90:48):
