@@ -89,7 +89,7 @@ swcounters)   # occupancy / VALU / L2 counters of shallow_tile, one counter per 
     python scripts/pmc_table.py $OUT/swcounters shallow_tile > $OUT/swcounters_table.txt 2>&1
     cat $OUT/swcounters_table.txt ;;
 pmcconfigs)   # fabric traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the other BASELINE Jacobi configurations
-    [ -f profiles/traffic.json ] && cp profiles/traffic.json $OUT/traffic.json
+    [ -f $OUT/traffic.json ] || { [ -f profiles/traffic.json ] && cp profiles/traffic.json $OUT/traffic.json; }
     for cfg in "8192 64" "4096 64" "16384 1"; do
         set -- $cfg
         rm -rf $OUT/pmcc_fetch $OUT/pmcc_write
