@@ -490,8 +490,9 @@ static int exchange_agg(dlesm_halo_plan *p, double *const *fields, int nf, unsig
     return DLESM_OK;
 }
 
-// The exchange of `nf` fields of the plan's shape in ONE grouped launch.  Between a pair of
-// ranks messages match in issue order: field-major, then ascending direction code, on both sides.
+// The exchange of one field in the Jacobi step's own form (rows sent and received in place, only the
+// strided strips packed; nf > 1 kept as the comparison point of exchange_agg, dm_aggregate = 0): between a
+// pair of ranks messages match in issue order, field-major, then ascending direction code, on both sides.
 // `prepacked`: the caller's kernel has already written the enabled strided strips of every field
 // into the send buffer (dlesm_jacobi5_step_dm's frame kernel does), so no pack launch is needed.
 static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsigned mask, hipStream_t s,
@@ -519,26 +520,24 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
     // diagnostics (profiling only, results are then wrong): price the parts of an exchange
     const int skip = tuning("dm_skip_parts", 0);         // bit0: no RCCL group, bit1: no unpack
     if (skip & 2) skip_unpack = true;
-    if (skip & 1) goto after_group;
-    {
-    DLESM_NCCL_TRY(ncclGroupStart());
-    ncclResult_t err = ncclSuccess;
-    for (int k = 0; k < nf; k++) {
-        double *f = fields[k];
-        for (const Msg &m : p->recvs) {
-            if (!dir_enabled(mask, m.dir)) continue;
-            double *dst = m.off >= 0 ? p->recvbuf + (size_t)k * p->recvbuf_len + m.off : f + (size_t)m.j0 * p->ld + m.i0;
-            DLESM_NCCL_IN_GROUP(err, ncclRecv(dst, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
+    if (!(skip & 1)) {
+        DLESM_NCCL_TRY(ncclGroupStart());
+        ncclResult_t err = ncclSuccess;
+        for (int k = 0; k < nf; k++) {
+            double *f = fields[k];
+            for (const Msg &m : p->recvs) {
+                if (!dir_enabled(mask, m.dir)) continue;
+                double *dst = m.off >= 0 ? p->recvbuf + (size_t)k * p->recvbuf_len + m.off : f + (size_t)m.j0 * p->ld + m.i0;
+                DLESM_NCCL_IN_GROUP(err, ncclRecv(dst, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
+            }
+            for (const Msg &m : p->sends) {
+                if (!dir_enabled(mask, m.dir)) continue;
+                const double *src = m.off >= 0 ? p->sendbuf + (size_t)k * p->sendbuf_len + m.off : f + (size_t)m.j0 * p->ld + m.i0;
+                DLESM_NCCL_IN_GROUP(err, ncclSend(src, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
+            }
         }
-        for (const Msg &m : p->sends) {
-            if (!dir_enabled(mask, m.dir)) continue;
-            const double *src = m.off >= 0 ? p->sendbuf + (size_t)k * p->sendbuf_len + m.off : f + (size_t)m.j0 * p->ld + m.i0;
-            DLESM_NCCL_IN_GROUP(err, ncclSend(src, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
-        }
+        if (int rc = group_end(err, "halo exchange (ncclSend/ncclRecv)")) return rc;
     }
-    if (int rc = group_end(err, "halo exchange (ncclSend/ncclRecv)")) return rc;
-    }
-after_group:
     if (any_rpack && !skip_unpack)
         for (int k = 0; k < nf; k++)
             hipLaunchKernelGGL(unpack_strips, dim3(gx, p->n_rpack), dim3(256), 0, s, fields[k], p->ld, p->d_rpack,
