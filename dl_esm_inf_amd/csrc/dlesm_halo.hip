@@ -682,6 +682,10 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
         p->pending_stream = s;
         return DLESM_OK;
     }
+    // joined form of the one-launch step: a one-wave kernel on the caller's stream that sleeps on the
+    // exchange's completion flag -- a kernel launch costs the stream ~2.5 us, an event wait 7-8
+    // (scripts/syncbench.hip); the halos were released at device scope when the exchange's last kernel ended
+    if (fused && tuning("dm_flag_join", 1)) return launch_frame_flag_wait(p->halo_flag, p->frame_seq, p->frame_timed_out, s);
     DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
     return DLESM_OK;
 }
@@ -889,6 +893,8 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
                 p->pending_field = nullptr;
                 return DLESM_OK;
             }
+            if (tuning("dm_flag_join", 1))               // as in the Jacobi step: a flag-wait kernel instead of an event wait
+                return launch_frame_flag_wait(p->halo_flag, job.seq, p->frame_timed_out, s);
             DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
             return DLESM_OK;
         }

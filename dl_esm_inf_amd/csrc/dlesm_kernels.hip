@@ -773,8 +773,13 @@ int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long se
 // with a 50 ms bound on the side stream, the releasing store on the caller's stream.
 bool streams_run_concurrently(hipStream_t callers)
 {
-    static int cached = -1;
-    if (cached >= 0) return cached != 0;
+    // per caller's stream: which hardware queue a stream lands on is the runtime's choice
+    static std::mutex mu;
+    static std::map<hipStream_t, int> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = seen.find(callers);
+    if (it != seen.end()) return it->second != 0;
+    int &cached = seen[callers];
     cached = 0;
     unsigned long long *flag = nullptr;
     int *timed_out = nullptr;
