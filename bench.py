@@ -161,6 +161,16 @@ def jacobi_config(D, torch, stream, tile, alignment, steps, warmup=10):
         for _ in range(warmup):
             D.psy.invoke_jacobi5(b, a, stream=stream)
             a, b = b, a
+        # a timed region of at least ~40 ms whatever the tile (a 4096^2 step takes 45 us: 100 of them are over
+        # before the clocks have settled): size it from a short estimate, at most 2000 launches
+        e0.record(stream)
+        for _ in range(20):
+            D.psy.invoke_jacobi5(b, a, stream=stream)
+            a, b = b, a
+        e1.record(stream)
+        stream.synchronize()
+        est = e0.elapsed_time(e1) / 20
+        steps = min(2000, max(steps, int(40.0 / max(est, 1e-3))))
         e0.record(stream)
         for _ in range(steps):
             D.psy.invoke_jacobi5(b, a, stream=stream)
