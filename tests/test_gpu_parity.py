@@ -815,6 +815,35 @@ def test_continuity_full_size_properties(D):
     assert bool((F[0].data[0, :] == -1.0).all()) and bool((F[0].data[:, 0] == -1.0).all())
 
 
+def test_planning_call_reports_its_shape_and_changes_no_bits(D):
+    """dlesm_stencil5_autotune_f64 / dlesm_stencil5_planned_shape: nothing planned before the call, a shape with
+    2 or 3 rows per tile after it, the non-temporal store policy by array size; the step computes the same bits
+    with the planned shape as with the rule's"""
+    import torch
+    g = _grid(D, 1500, 700, 64)
+    a, b, c = (D.r2d_field(g, D.GO_T_POINTS) for _ in range(3))
+    D.psy.hash_init(a, SEED + 91)
+    D.copy_field(a, b)
+    D.copy_field(a, c)
+    assert D.psy.planned_shape_jacobi5(b)[:3] == (0, 0, 0)
+    D.psy.invoke_jacobi5(b, a)                            # the rule's shape
+    D.psy.autotune_jacobi5(c, a)
+    waves, tiles, rows, nts = D.psy.planned_shape_jacobi5(c)
+    assert waves in (2, 4, 8, 16) and tiles >= (1500 // 128) and rows in (2, 3) and nts == 0     # 8.6 MB arrays: cached stores
+    D.psy.invoke_jacobi5(c, a)                            # the planned shape
+    torch.cuda.synchronize()
+    assert torch.equal(b.data, c.data)
+    for forced in (0, 1):                                 # the store policy is a tuning key too, and changes no bits
+        _set_tuning(D, j5_nt_stores=forced)
+        assert D.psy.planned_shape_jacobi5(c)[3] == forced
+        D.set_field(c, 0.0)
+        D.copy_field(a, c)
+        D.psy.invoke_jacobi5(c, a)
+        torch.cuda.synchronize()
+        assert torch.equal(b.data, c.data)
+    _set_tuning(D, j5_nt_stores=-1)
+
+
 # --------------------------------------------------------------------------- hipGraph capture
 def test_time_loop_captured_into_a_graph(D):
     """two ping-pong Jacobi steps + two 9-point steps captured into one hipGraph on a side stream and
