@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Table of per-kernel medians from a set of single-counter rocprofv3 --pmc runs.
 
-    python scripts/pmc_table.py <dir-with-one-subdir-per-run> <kernel substring> [<kernel substring> ...]
-Every sub-directory holds the output of one `rocprofv3 --pmc <COUNTER> -d <subdir>` run.
+    python scripts/pmc_table.py <dir-with-one-subdir-per-run> <kernel substring>[@<grid size>] [...]
+Every sub-directory holds the output of one `rocprofv3 --pmc <COUNTER> -d <subdir>` run.  `name@grid` keeps only
+the launches of that grid size (threads), i.e. one launch geometry of a kernel that a run launches at several.
 """
 import csv
 import glob
@@ -17,7 +18,8 @@ def main():
     for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             for sub in subs:
-                if sub in r.get("Kernel_Name", ""):
+                name, _, grid = sub.partition("@")
+                if name in r.get("Kernel_Name", "") and (not grid or r.get("Grid_Size") == grid):
                     table.setdefault((r["Counter_Name"], sub), []).append(
                         (float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
                          r["VGPR_Count"], r["Workgroup_Size"], r["Grid_Size"]))
