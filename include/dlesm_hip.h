@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DLESM_VERSION 100
+#define DLESM_VERSION 200   /* round 2: entries added (masks, pipelined steps, 3x3 stencil, continuity, graph capture), none changed */
 
 /* error codes */
 #define DLESM_OK 0
