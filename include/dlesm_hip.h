@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DLESM_VERSION 200   /* round 2: entries added (masks, pipelined steps, 3x3 stencil, continuity, graph capture), none changed */
+#define DLESM_VERSION 200   /* round 2: entries added (pipelined steps, 3x3 stencil, continuity, gather/scatter ...); no signature changed; dirs_mask 0 now exchanges nothing, as in the reference */
 
 /* error codes */
 #define DLESM_OK 0
