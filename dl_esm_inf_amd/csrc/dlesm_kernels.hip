@@ -500,12 +500,13 @@ static std::map<ShapeKey, Shape> g_shape_cache;
 static Shape g_shape_override = {0, 0, 0};              // set only while the autotuner is measuring
 
 // Store policy of the two-to-three-stream sweeps (Jacobi, 3x3, masked, whole-field copy): non-temporal once
-// an array of the box's height no longer shares the 256 MB Infinity Cache with its partner (measured, see
-// launch_tile); j5_nt_stores = 1 / 0 forces it on / off.
+// an array of the box's height no longer shares the 256 MB Infinity Cache with its partner -- from 150 MB
+// (measured: 134 MB arrays lose 3-4 % with non-temporal stores, 164 MB gain 0.6 %, 193-376 MB 2.5-4 %, see
+// launch_tile and DESIGN.md section 5.1); j5_nt_stores = 1 / 0 forces it on / off.
 int nt_stores_for(int ld, int y0, int y1)
 {
     const int t = tuning("j5_nt_stores", -1);
-    return t >= 0 ? (t != 0) : (size_t)ld * (size_t)(y1 - y0 + 3) * sizeof(double) >= ((size_t)400 << 20);
+    return t >= 0 ? (t != 0) : (size_t)ld * (size_t)(y1 - y0 + 3) * sizeof(double) >= ((size_t)150 << 20);
 }
 
 template <int VEC, bool NT>
@@ -540,7 +541,7 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
     // Non-temporal stores of `out` (j5_nt_stores: 1 on, 0 off, -1 = by size).  Measured, same process, planned
     // shapes: 16384^2 0.787-0.793 of peak against 0.760-0.780, 8192^2 0.782 against 0.758-0.773, but 4096^2
     // 0.729 against 0.747-0.761 -- two 134 MB arrays ping-pong through the 256 MB Infinity Cache, and a store
-    // that bypasses it takes the next step's input away.  So: on from 400 MB per array.
+    // that bypasses it takes the next step's input away.  So: on from 150 MB per array (nt_stores_for).
     const int nts = nt_stores_for(ld, y0, y1);
     if (fj) {
         // frame workgroups first (they are dispatched first): a multiple of 8 of them, so that the tile

@@ -211,7 +211,7 @@ int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld, int ny,
                                 int xstart, int xstop, int ystart, int ystop, void *stream);
 /* What the planning call kept for this (ld, box): waves per workgroup, wave tiles per row, rows per
  * tile (all 0 when no planning call has been made for it), and whether `out` is stored non-temporally
- * (by size: on once the arrays no longer fit the Infinity Cache).  Host only; for logs and profiles. */
+ * (by size: on from 150 MB per array, when a ping-pong pair no longer fits the 256 MB Infinity Cache).  Host only; for logs and profiles. */
 int dlesm_stencil5_planned_shape(int ld, int xstart, int xstop, int ystart, int ystop,
                                  int *waves_per_group, int *tiles_per_row, int *rows_per_tile,
                                  int *nt_stores);
