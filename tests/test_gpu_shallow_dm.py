@@ -156,3 +156,64 @@ def test_pipelined_shallow_time_loop(D, nx, ny, alignment, nsteps, chain):
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
     g._halo_plan = None
     L.dlesm_set_tuning(b"sw_dm_chain", 1)
+
+
+def test_shallow_dm_at_the_weak_scaling_tile(D):
+    """8192^2 (the per-GPU tile of BASELINE configs[4]) in loop-back: three leapfrog steps in the time-loop form
+    + one join equal three times (plain step, then grouped exchange) on the same device, every field and halo,
+    bit for bit; two sampled rows of the first step against an oracle slab"""
+    import torch
+    from dm_overhead import loopback_tables
+    L = D._cabi.lib()
+    n = 8192
+    os.environ["DL_ESM_ALIGNMENT"] = "64"
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    g.decompose(n, n)
+    D.grid_init(g, 1.0, 1.0)
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    A = {k: D.r2d_field(g, pts[k[0]]) for k in names}       # time-loop form
+    B = {k: D.r2d_field(g, pts[k[0]]) for k in names}       # step, then exchange
+    it = A["p"].internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    g._halo_plan = plan
+    for k, name in enumerate(names):
+        D.psy.hash_init(A[name], 300 + k)
+        A[name].data.mul_(0.01)
+        A[name].data.add_(1.0 if name[0] == "p" else -0.005)
+    D.psy.halo_exchange_multi([A[k] for k in names[:6]])
+    for name in names:
+        D.copy_field(A[name], B[name])
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 20.0)
+    # oracle slab of the first step: rows j0 .. j0+1 of the new fields
+    j0 = it.ystart + 4000
+    slab = [A[k].data[j0 - 2:j0 + 2, :].cpu().numpy() for k in names[:6]]
+    want = [np.zeros_like(slab[0]) for _ in range(3)]
+    O.sw_step(prm, g.nx, (it.xstart, it.xstop, 2, 3), *slab, *want)
+
+    def order(F, c, o, nw):
+        return [F[k] for k in c + o + nw]
+
+    cur, old, new = names[:3], names[3:6], names[6:]
+    for step in range(3):
+        D.psy.invoke_shallow_step_dm_pipelined(prm, *order(A, cur, old, new))
+        D.psy.invoke_shallow_step(prm, *order(B, cur, old, new))
+        D.psy.halo_exchange_multi([B[k] for k in new])
+        if step == 0:
+            D.psy.halo_join(g)
+            torch.cuda.synchronize()
+            for k, w in zip(new, want):
+                assert np.array_equal(A[k].data[j0 - 1:j0 + 1, it.xstart - 1:it.xstop].cpu().numpy(),
+                                      w[1:3, it.xstart - 1:it.xstop]), k
+        cur, old, new = new, cur, old
+    D.psy.halo_join(g)
+    torch.cuda.synchronize()
+    w = A["p"].whole
+    for k in names:
+        assert torch.equal(A[k].data[w.ystart - 1:w.ystop, w.xstart - 1:w.xstop],
+                           B[k].data[w.ystart - 1:w.ystop, w.xstart - 1:w.xstop]), k
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+    g._halo_plan = None
