@@ -358,7 +358,7 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_framed(const double *__rest
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             while (__hip_atomic_load(fj.halo_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fj.halo_seq) {
                 __builtin_amdgcn_s_sleep(32);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {   // ~20 s of the 100 MHz counter
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) {   // ~30 s of the 100 MHz counter
                     __hip_atomic_store(fj.timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
@@ -761,7 +761,7 @@ int launch_flag_set(unsigned long long *flag, unsigned long long seq, hipStream_
 
 int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(frame_flag_wait, dim3(1), dim3(64), 0, s, flag, seq, timed_out, 2000000000ull);   // ~20 s
+    hipLaunchKernelGGL(frame_flag_wait, dim3(1), dim3(64), 0, s, flag, seq, timed_out, 3000000000ull);   // ~30 s
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
