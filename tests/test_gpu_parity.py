@@ -516,6 +516,45 @@ def test_distributed_step_variants(D, corners, frame_pack):
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
+@pytest.mark.parametrize("flag_join,aggregate_single", [(0, 1), (1, 0), (0, 0)])
+def test_join_and_single_field_exchange_variants(D, flag_join, aggregate_single):
+    """the comparison points of two defaults stay alive: the joined step joining through an event instead of a
+    flag-wait kernel, and a lone field's exchange sending its rows in place instead of through the staging buffer"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dm_overhead import loopback_tables
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    _set_tuning(D, dm_flag_join=flag_join, dm_aggregate_single=aggregate_single)
+    g = _grid(D, 300, 41, 64)
+    x, y = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    it = x.internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    D.psy.hash_init(x, SEED + 13)
+    hx = x.get_data()
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+    assert O.exchange_all([hx], [g.nx], [oc]) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(x.get_data(), hx)
+    D.copy_field(x, y)
+    for _ in range(3):
+        hx = x.get_data()
+        want = y.get_data()
+        O.jacobi5(hx, want, g.nx, *it.box())
+        assert O.exchange_dirs([want], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+        D._cabi.check(L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(y.get_data(), want)
+        x, y = y, x
+    _set_tuning(D, dm_flag_join=1, dm_aggregate_single=1)
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
 @pytest.mark.parametrize("nx,ny,alignment,nsteps", [(300, 41, 64, 7), (64, 64, 2, 12), (1500, 700, 64, 9), (130, 5, 2, 4)])
 @pytest.mark.parametrize("chain,lazy", [(1, 1), (1, 0), (0, 1)])
 def test_pipelined_distributed_steps(D, nx, ny, alignment, nsteps, chain, lazy):
