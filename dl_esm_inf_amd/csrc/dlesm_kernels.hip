@@ -86,8 +86,15 @@ __device__ __forceinline__ void jacobi_row(const Vec<VEC> &south, const Vec<VEC>
                                            const Vec<VEC> &north, double edge, int lane,
                                            double (&o)[VEC])
 {
+#ifndef DLESM_J5_SHFL
+    // whole-wave shifts on the VALU (DPP) rather than ds_bpermute through the LDS crossbar; lanes 0 / 63 get 0
+    // from it and their real value from `edge` just below
+    double west = from_lower<true>(mid.v[VEC - 1]);
+    double east = from_upper<true>(mid.v[0]);
+#else
     double west = __shfl_up(mid.v[VEC - 1], 1);
     double east = __shfl_down(mid.v[0], 1);
+#endif
     if (lane == 0) west = edge;
     if (lane == 63) east = edge;
     if constexpr (VEC == 2) {
