@@ -414,7 +414,9 @@ int dlesm_jacobi5_step_dm(dlesm_halo_plan *plan, const double *in, double *out,
  * device (its frame workgroups, the only ones that read halos, sleep on a flag the side stream sets
  * once the messages have landed; bounded; the received west/east strips are read straight from the
  * receive buffer, not unpacked into the field); every other entry point that takes the plan joins it
- * first -- the join also runs the deferred unpack, so that `out` then holds valid edge halos.  Before
+ * first -- the join also runs the deferred unpack, so that `out` then holds valid edge halos (the
+ * outputs of EARLIER steps of the loop keep whatever west/east halos they had: only the joined
+ * output's are promised).  Before
  * anything ELSE reads the halo cells of `out` (a kernel of the host program, a copy on another
  * stream), call dlesm_halo_plan_join.  Same results as dlesm_jacobi5_step_dm, bit for bit. */
 int dlesm_jacobi5_step_dm_pipelined(dlesm_halo_plan *plan, const double *in, double *out,

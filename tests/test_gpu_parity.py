@@ -516,6 +516,56 @@ def test_distributed_step_variants(D, corners, frame_pack):
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
+def test_two_grids_on_two_streams_in_the_time_loop_form(D):
+    """two plans, two caller streams, ONE library side stream: time loops of the pipelined Jacobi step on two
+    grids of different shape issued alternately -- each plan's flags and buffers are its own, the exchanges
+    of both queue on the side stream -- then one join each; both equal the oracle's steps + edge exchanges"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dm_overhead import loopback_tables
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    runs = []
+    for nx, ny, al in ((900, 260, 64), (333, 777, 2)):
+        g = _grid(D, nx, ny, al)
+        x, y = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+        it = x.internal
+        t = loopback_tables(D, it)
+        plan = C.c_void_p()
+        D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+        oc = O.Comms()
+        C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+        D.psy.hash_init(x, SEED + nx)
+        D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+        D.copy_field(x, y)
+        torch.cuda.synchronize()
+        runs.append(dict(g=g, x=x, y=y, it=it, plan=plan, oc=oc, hx=x.get_data(), hy=y.get_data(),
+                         s=torch.cuda.Stream()))
+    nsteps = 7
+    for k in range(nsteps):
+        for r in runs:                                     # alternately: both loops are in flight at once
+            sp = C.c_void_p(r["s"].cuda_stream)
+            D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(r["plan"], r["x"].device_ptr, r["y"].device_ptr, r["g"].nx,
+                                                            r["g"].ny, *r["it"].box(), sp))
+            r["x"], r["y"] = r["y"], r["x"]
+    for r in runs:
+        D._cabi.check(L.dlesm_halo_plan_join(r["plan"], C.c_void_p(r["s"].cuda_stream)))
+        for k in range(nsteps):
+            O.jacobi5(r["hx"], r["hy"], r["g"].nx, *r["it"].box())
+            assert O.exchange_dirs([r["hy"]], [r["g"].nx], [r["oc"]], (1, 2, 3, 4), no_diagonals=True) == 0
+            r["hx"], r["hy"] = r["hy"], r["hx"]
+    torch.cuda.synchronize()
+    for r in runs:
+        it = r["it"]
+        inner = (slice(it.ystart - 1, it.ystop), slice(it.xstart - 1, it.xstop))
+        assert np.array_equal(r["x"].get_data(), r["hx"])                     # the last output: halos included
+        # the output before it: its west/east halos were never unpacked into the field (the next step read
+        # them from the receive buffer) -- the time-loop form promises valid halos for the joined output only
+        assert np.array_equal(r["y"].get_data()[inner], r["hy"][inner])
+        D._cabi.check(L.dlesm_halo_plan_destroy(r["plan"]))
+
+
 @pytest.mark.parametrize("flag_join,aggregate_single", [(0, 1), (1, 0), (0, 0)])
 def test_join_and_single_field_exchange_variants(D, flag_join, aggregate_single):
     """the comparison points of two defaults stay alive: the joined step joining through an event instead of a
