@@ -217,3 +217,63 @@ def test_shallow_dm_at_the_weak_scaling_tile(D):
                            B[k].data[w.ystart - 1:w.ystop, w.xstart - 1:w.xstop]), k
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
     g._halo_plan = None
+
+
+def test_time_loop_forms_of_both_steps_share_a_plan(D):
+    """a pipelined shallow-water step, then a pipelined Jacobi step on its pnew (chained on the device to the
+    shallow step's exchange), then a pipelined shallow step again (which must first join the Jacobi step's
+    un-unpacked exchange): one plan, one stream, every hand-over between the two kinds of step"""
+    import torch
+    from dm_overhead import loopback_tables
+    L = D._cabi.lib()
+    nx, ny = 257, 66
+    os.environ["DL_ESM_ALIGNMENT"] = "64"
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    g.decompose(nx, ny)
+    D.grid_init(g, 1.0, 1.0)
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    F = {n: D.r2d_field(g, pts[n[0]]) for n in names}
+    q = D.r2d_field(g, D.GO_T_POINTS)
+    it = F["p"].internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    g._halo_plan = plan
+    for k, n in enumerate(names[:6]):
+        D.psy.hash_init(F[n], 400 + k)
+        F[n].data.mul_(0.01)
+        F[n].data.add_(1.0 if n[0] == "p" else -0.005)
+    for n in names[6:]:
+        D.set_field(F[n], 9.0)
+    D.set_field(q, 5.0)
+    D.psy.halo_exchange_multi([F[n] for n in names[:6]])
+    torch.cuda.synchronize()
+    H = {n: F[n].get_data() for n in names}
+    hq = q.get_data()
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 20.0)
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+
+    def shallow(cur, old, new):
+        D.psy.invoke_shallow_step_dm_pipelined(prm, *[F[n] for n in cur + old + new])
+        O.sw_step(prm, g.nx, it.box(), *[H[n] for n in cur + old], *[H[n] for n in new])
+        for n in new:
+            assert O.exchange_all([H[n]], [g.nx], [oc]) == 0
+
+    cur, old, new = names[:3], names[3:6], names[6:]
+    shallow(cur, old, new)
+    # Jacobi on pnew: its frame workgroups wait on the device for the shallow step's exchange
+    D.psy.invoke_jacobi5_dm_pipelined(q, F["pnew"])
+    O.jacobi5(H["pnew"], hq, g.nx, *it.box())
+    assert O.exchange_dirs([hq], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+    # the next shallow step joins the Jacobi step's exchange (and its deferred unpack into q) first
+    shallow(new, cur, old)
+    D.psy.halo_join(g)
+    torch.cuda.synchronize()
+    for n in names:
+        assert np.array_equal(F[n].get_data(), H[n]), n
+    assert np.array_equal(q.get_data(), hq)
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+    g._halo_plan = None
