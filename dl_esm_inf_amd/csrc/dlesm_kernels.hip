@@ -1009,13 +1009,16 @@ __global__ __launch_bounds__(256) void abs_sum_rows(const double *__restrict__ f
                 if (tail) acc1 += fabs(r[nx - 1]);
             }
             int i = threadIdx.x;
-            for (; i + 256 < nvec; i += 512) {                // two 16-byte loads in flight per lane
-                const d2 a = rv[i], b = rv[i + 256];
+            for (; i + 768 < nvec; i += 1024) {               // four 16-byte loads in flight per lane, read once
+                const d2 a = __builtin_nontemporal_load(rv + i), b = __builtin_nontemporal_load(rv + i + 256);
+                const d2 c = __builtin_nontemporal_load(rv + i + 512), d = __builtin_nontemporal_load(rv + i + 768);
                 acc0 += fabs(a.x) + fabs(a.y);
                 acc1 += fabs(b.x) + fabs(b.y);
+                acc0 += fabs(c.x) + fabs(c.y);
+                acc1 += fabs(d.x) + fabs(d.y);
             }
-            if (i < nvec) {
-                const d2 a = rv[i];
+            for (; i < nvec; i += 256) {
+                const d2 a = __builtin_nontemporal_load(rv + i);
                 acc0 += fabs(a.x) + fabs(a.y);
             }
         } else {
