@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 4: GOcean shallow-water u/v/h update, 8192x8192 fp64, one MI355X.
 Times the fused step (72 B/cell algorithmic) for the register-tiled kernel (R = 1, 2) and the
-direct-load kernel, leapfrog buffer rotation between steps, and the CPU oracle on a bounded sample.
+direct-load kernel, leapfrog buffer rotation between steps.
 
     python scripts/shallow_bench.py [--tile 8192] [--steps 40]
 """
@@ -10,7 +10,6 @@ import ctypes as C
 import json
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,10 +21,9 @@ def main():
     ap.add_argument("--tile", type=int, default=8192)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--out", default="gpurun_out/shallow_bench.json")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="accepted and ignored (the CPU leg lives in bench.py)")
     ap.add_argument("--only-default", action="store_true", help="time the default kernel only (profiling runs)")
     args = ap.parse_args()
-    import numpy as np
     import torch
     import dl_esm_inf_amd as D
     L = D._cabi.lib()
@@ -122,22 +120,8 @@ def main():
                       f"({72.0 * cells / ms / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
             L.dlesm_set_tuning(b"sw_kernel", 0)
     out = {"tile": args.tile, "ld": g.nx, "steps": args.steps, "algorithmic_bytes_per_cell": 72, "gpu": res}
-    if not args.no_cpu:
-        import oracle_lib as O
-        n = min(args.tile, 4096)                              # bounded CPU sample: n x n cells
-        ld, ny = O.grid_extents(n + 2, n + 2, 64)
-        rng = np.random.default_rng(0)
-        H = [rng.random((ny, ld)) + (1.0 if k % 3 == 2 else -0.5) for k in range(6)]
-        scratch = [np.zeros((ny, ld)) for _ in range(7)]
-        op = O.SwParams(prm.fsdx, prm.fsdy, prm.tdts8, prm.tdtsdx, prm.tdtsdy)
-        O.lib().orc_sw_step(C.byref(op), ld, 2, n + 1, 2, n + 1, *H, *scratch)
-        t0, reps = time.perf_counter(), 0
-        while time.perf_counter() - t0 < 6.0:
-            O.lib().orc_sw_step(C.byref(op), ld, 2, n + 1, 2, n + 1, *H, *scratch)
-            reps += 1
-        dt = time.perf_counter() - t0
-        out["cpu_oracle_1core"] = {"mcells_per_s": n * n * reps / dt / 1e6, "sample": f"{reps} steps of {n}x{n}"}
-        print(f"CPU oracle (1 core, un-fused GOcean kernel sequence): {n * n * reps / dt / 1e6:.1f} Mcells/s", flush=True)
+    # (the CPU baseline of this configuration is bench.py's `shallow_water.cpu_baseline` leg: only tests/, smoke() and that leg
+    #  may use the oracle)
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
 
