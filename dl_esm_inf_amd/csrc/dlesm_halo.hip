@@ -733,6 +733,29 @@ extern "C" int dlesm_stencil9_step_dm(dlesm_halo_plan *p, const double *in, doub
     } else {
         fp.n = 0;
     }
+    // one launch (frame workgroups inside the interior sweep, device flag to the side stream), as the Jacobi step
+    DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
+                  "an earlier distributed step gave up waiting for a flag (frame or halo wait timed out)");
+    if (!capturing(s) && p->frame_flag && tuning("s9_dm_fused", 1) && streams_run_concurrently(s)) {
+        FrameJob job{};
+        job.pk = fp;
+        job.counter = p->frame_counter;
+        job.flag = p->frame_flag;
+        job.seq = p->frame_seq + 1;
+        job.timed_out = p->frame_timed_out;
+        bool fused = false;
+        if (int rc = launch_stencil9_framed(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, job, s, &fused)) return rc;
+        if (fused) {
+            p->frame_seq = job.seq;
+            if (int rc = launch_frame_flag_wait(p->frame_flag, job.seq, p->frame_timed_out, side)) return rc;
+            if (int rc = exchange_on(p, out, mask, side, prepacked)) return rc;
+            if (int rc = launch_flag_set(p->halo_flag, job.seq, side)) return rc;
+            DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
+            if (tuning("dm_flag_join", 1)) return launch_frame_flag_wait(p->halo_flag, job.seq, p->frame_timed_out, s);
+            DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
+            return DLESM_OK;
+        }
+    }
     if (int rc = launch_stencil9_frame(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, s, prepacked ? &fp : nullptr))
         return rc;
     DLESM_HIP_TRY(hipEventRecord(p->ev_frame, s));

@@ -89,6 +89,8 @@ int launch_stencil9(const double *in, double *out, const double *coef, int ld, i
 int launch_stencil9_frame(const double *in, double *out, const double *coef, int ld, int ny, int xstart, int xstop,
                           int ystart, int ystop, hipStream_t s, const FramePack *pack);
 
+// (declared after FrameJob, below) launch_stencil9_framed
+
 // the one-cell frame of the shallow-water step in ONE launch (one cell per thread).  Every frame cell
 // that a neighbour will receive (rows, columns and corners) is also written into the AGGREGATED send
 // buffer of the three new fields: one message per neighbour and direction carries all three strips,
@@ -136,6 +138,9 @@ struct FrameJob {
 // arrays do not qualify for the 16-byte-lane tile kernel: the caller then takes the two-launch path.
 int launch_stencil5_framed(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart,
                            int ystop, FrameJob job, hipStream_t s, bool *fused);
+// the same for the 3x3 weighted stencil (joined form only: no halo wait, no virtual halos)
+int launch_stencil9_framed(const double *in, double *out, const double *coef, int ld, int ny, int xstart, int xstop,
+                           int ystart, int ystop, FrameJob job, hipStream_t s, bool *fused);
 // park stream `s` (one sleeping wave) until *flag >= seq; bounded, see frame_flag_wait
 int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s);
 // true when kernels of two streams execute side by side in this process (probed once; false under

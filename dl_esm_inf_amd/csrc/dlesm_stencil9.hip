@@ -38,12 +38,12 @@ __device__ __forceinline__ double point9(const Coef9 &k, double sw, double s, do
 constexpr int R = 2;
 
 template <bool NTS>
-__global__ __launch_bounds__(1024) void stencil9_tile(const double *__restrict__ in, double *__restrict__ out,
-                                                     Coef9 k, int ld, int x0, int x1, int y0, int y1, int c_first,
-                                                     int nxw)
+__device__ __forceinline__ void stencil9_tile_body(const double *__restrict__ in, double *__restrict__ out, const Coef9 &k,
+                                                   int ld, int x0, int x1, int y0, int y1, int c_first, int nxw,
+                                                   unsigned block)
 {
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int w = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int xw = w % nxw, jb = y0 + (w / nxw) * R;
     if (jb > y1) return;
     const int je = jb + R - 1 > y1 ? y1 : jb + R - 1;
@@ -88,6 +88,52 @@ __global__ __launch_bounds__(1024) void stencil9_tile(const double *__restrict__
         } else {
             if (m0) po[0] = o0;
             if (m1) po[1] = o1;
+        }
+    }
+}
+
+template <bool NTS>
+__global__ __launch_bounds__(1024) void stencil9_tile(const double *__restrict__ in, double *__restrict__ out,
+                                                     Coef9 k, int ld, int x0, int x1, int y0, int y1, int c_first,
+                                                     int nxw)
+{
+    stencil9_tile_body<NTS>(in, out, k, ld, x0, x1, y0, y1, c_first, nxw, blockIdx.x);
+}
+
+// The distributed step in ONE launch (the construction of jacobi5_tile_framed): the first fj.nblocks
+// workgroups compute the one-cell frame of the box (fj.fx0:fx1, fj.fy0:fy1) from memory, store it write-through
+// at device scope -- into `out` and, for the west/east columns, into the send buffer -- and the last of them
+// publishes fj.seq in the flag the side stream's waiter sleeps on; all other workgroups are the ordinary tile
+// sweep over the interior (x0:x1, y0:y1).  Joined form only: `in` holds valid halos when the launch starts.
+template <bool NTS>
+__global__ __launch_bounds__(1024) void stencil9_tile_framed(const double *__restrict__ in, double *__restrict__ out,
+                                                            Coef9 k, int ld, int x0, int x1, int y0, int y1, int c_first,
+                                                            int nxw, FrameJob fj)
+{
+    if (blockIdx.x >= (unsigned)fj.nblocks) {
+        stencil9_tile_body<NTS>(in, out, k, ld, x0, x1, y0, y1, c_first, nxw, blockIdx.x - fj.nblocks);
+        return;
+    }
+    auto put = [](double *ptr, double val) { __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const long total = frame_cells(fj.fx1 - fj.fx0 + 1, fj.fy1 - fj.fy0 + 1);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)fj.nblocks * blockDim.x) {
+        int i, j;
+        frame_index(t, fj.fx0, fj.fx1, fj.fy0, fj.fy1, i, j);
+        const size_t o = (size_t)j * ld + i;
+        const double r = point9(k, in[o - ld - 1], in[o - ld], in[o - ld + 1], in[o - 1], in[o], in[o + 1],
+                                in[o + ld - 1], in[o + ld], in[o + ld + 1]);
+        put(out + o, r);
+        for (int q = 0; q < fj.pk.n; q++)
+            if (i == fj.pk.s[q].i && j >= fj.pk.s[q].j0 && j < fj.pk.s[q].j0 + fj.pk.s[q].nj)
+                put(fj.pk.buf + fj.pk.s[q].off + (j - fj.pk.s[q].j0), r);
+    }
+    __builtin_amdgcn_s_waitcnt(0);        // this wave's stores have been acknowledged ...
+    __syncthreads();                      // ... and those of every wave of the group ...
+    if (threadIdx.x == 0) {               // ... before the group is counted as done
+        const unsigned done = __hip_atomic_fetch_add(fj.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (unsigned)fj.nblocks - 1) {
+            __hip_atomic_store(fj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fj.flag, fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -140,6 +186,39 @@ int launch_stencil9_frame(const double *in, double *out, const double *coef, int
     hipLaunchKernelGGL(stencil9_frame_k, dim3(blocks), dim3(256), 0, s, in, out, k, ld, xstart - 1, xstop - 1, ystart - 1,
                        ystop - 1, pk);
     DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+// Frame of the box + interior sweep in ONE launch; *fused = false (nothing launched) when the arrays do not
+// qualify for the 16-byte-lane tile kernel or the box has no interior: the caller then takes the two-launch path.
+int launch_stencil9_framed(const double *in, double *out, const double *coef, int ld, int ny, int xstart, int xstop,
+                           int ystart, int ystop, FrameJob job, hipStream_t s, bool *fused)
+{
+    *fused = false;
+    if (xstop - xstart < 2 || ystop - ystart < 2) return DLESM_OK;
+    if (int rc = check_box("dlesm_stencil9_step_dm", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    DLESM_REQUIRE(in != nullptr && out != nullptr && coef != nullptr && in != out, "stencil9: null or aliased arrays");
+    DLESM_REQUIRE(job.counter != nullptr && job.flag != nullptr, "stencil9 framed: no signal words");
+    if (!(ld % 2 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0 && tuning("s9_kernel", 0) == 0)) return DLESM_OK;
+    const Coef9 k{coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[7], coef[8]};
+    job.fx0 = xstart - 1, job.fx1 = xstop - 1, job.fy0 = ystart - 1, job.fy1 = ystop - 1;
+    const int x0 = xstart, x1 = xstop - 2, y0 = ystart, y1 = ystop - 2;      // the interior, 0-based
+    const int c_first = (x0 / 2) & ~7, c_last = x1 / 2;
+    int nxw = (c_last - c_first + 64) / 64, tpb = 4;
+    choose_block_shape(&nxw, &tpb);
+    const int strips = (y1 - y0 + R) / R;
+    const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
+    const long cells = 2L * (job.fx1 - job.fx0 + 1) + 2L * (job.fy1 - job.fy0 + 1);
+    long nb = ((cells + 64 * tpb - 1) / (64 * tpb) + 7) & ~7L;               // a multiple of 8: tile groups keep their XCD
+    job.nblocks = (int)(nb < 8 ? 8 : nb > 256 ? 256 : nb);
+    if (nt_stores_for(ld, y0, y1))
+        hipLaunchKernelGGL(stencil9_tile_framed<true>, dim3(grid + job.nblocks), dim3(64 * tpb), 0, s, in, out, k, ld, x0, x1,
+                           y0, y1, c_first, nxw, job);
+    else
+        hipLaunchKernelGGL(stencil9_tile_framed<false>, dim3(grid + job.nblocks), dim3(64 * tpb), 0, s, in, out, k, ld, x0, x1,
+                           y0, y1, c_first, nxw, job);
+    DLESM_HIP_TRY(hipGetLastError());
+    *fused = true;
     return DLESM_OK;
 }
 

@@ -810,9 +810,11 @@ def test_stencil9_full_size_properties(D):
 
 @pytest.mark.parametrize("nx,ny,alignment", [(300, 41, 64), (37, 23, 8), (130, 5, None), (1500, 700, 64)])
 @pytest.mark.parametrize("corner_weights", [True, False])
-def test_stencil9_distributed_step_loopback(D, nx, ny, alignment, corner_weights):
+@pytest.mark.parametrize("one_launch", [1, 0])
+def test_stencil9_distributed_step_loopback(D, nx, ny, alignment, corner_weights, one_launch):
     """dlesm_stencil9_step_dm = stencil9 + the exchange its weights need (eight directions with
-    corner weights, the four edges without), bit for bit over several steps; loop-back tables"""
+    corner weights, the four edges without), bit for bit over several steps; loop-back tables.
+    one_launch: frame workgroups inside the interior launch + device flags (default) / frame kernel + events"""
     import sys
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
@@ -831,6 +833,7 @@ def test_stencil9_distributed_step_loopback(D, nx, ny, alignment, corner_weights
     if not corner_weights:
         coef[[0, 2, 6, 8]] = 0.0
     cp = coef.ctypes.data_as(C.POINTER(C.c_double))
+    _set_tuning(D, s9_dm_fused=one_launch)
     D.psy.hash_init(x, SEED + 61)
     D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
     D.copy_field(x, y)
@@ -843,6 +846,7 @@ def test_stencil9_distributed_step_loopback(D, nx, ny, alignment, corner_weights
         torch.cuda.synchronize()
         assert np.array_equal(y.get_data(), want)
         x, y = y, x
+    _set_tuning(D, s9_dm_fused=1)
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
