@@ -118,14 +118,24 @@ PROTOTYPES = {
     "dlesm_stencil5_multi_f64": (_i, [_vp, _vp] + [_i] * 15 + [_vp]),
     "dlesm_shallow_step_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_shallow_autotune_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
+    "dlesm_compute_cu_f64": (_i, [_i] * 7 + [_vp] * 3 + [_vp]),
+    "dlesm_compute_cv_f64": (_i, [_i] * 7 + [_vp] * 3 + [_vp]),
+    "dlesm_compute_z_f64": (_i, [_i] * 7 + [_d, _d] + [_vp] * 4 + [_vp]),
+    "dlesm_compute_h_f64": (_i, [_i] * 7 + [_vp] * 4 + [_vp]),
+    "dlesm_compute_unew_f64": (_i, [_i] * 7 + [_d, _d] + [_vp] * 5 + [_vp]),
+    "dlesm_compute_vnew_f64": (_i, [_i] * 7 + [_d, _d] + [_vp] * 5 + [_vp]),
+    "dlesm_compute_pnew_f64": (_i, [_i] * 7 + [_d, _d] + [_vp] * 4 + [_vp]),
+    "dlesm_time_smooth_f64": (_i, [_i] * 6 + [_d] + [_vp] * 3 + [_vp]),
     "dlesm_periodic_halos": (_i, [C.POINTER(Region), _i, _i, C.POINTER(Region), C.POINTER(Region), C.POINTER(_i)]),
     "dlesm_periodic_halos_apply_f64": (_i, [_vp, _i, _i, C.POINTER(Region), _i, _i, _vp]),
     "dlesm_periodic_halos_apply_multi_f64": (_i, [C.POINTER(_vp), _i, _i, _i, C.POINTER(Region), _i, _i, _vp]),
     "dlesm_shallow_step_sw_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
+    "dlesm_shallow_step_sw_periodic_f64": (_i, [C.POINTER(SwParams), _i, _i, C.POINTER(Region), _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_copy_patch_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_fill_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, _d, _vp]),
     "dlesm_checksum_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_d), _vp]),
     "dlesm_hash_init_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.c_uint64, C.c_int64, C.c_int64, _vp]),
+    "dlesm_stream_copy_f64": (_i, [_i, _i, C.POINTER(_vp), C.POINTER(_vp), C.c_size_t, _i, _vp]),
     "dlesm_set_tuning": (_i, [C.c_char_p, _i]),
     "dlesm_comm_unique_id": (_i, [_vp]),
     "dlesm_comm_init": (_i, [_vp, _i, _i]),

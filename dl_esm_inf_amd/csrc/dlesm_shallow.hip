@@ -50,6 +50,14 @@ template <bool DPP> __device__ __forceinline__ V2 east_of(const V2 &a) { return 
 template <bool DPP> __device__ __forceinline__ V2 west_of(const V2 &a) { return V2{from_lower<DPP>(a.y), a.x}; }
 
 #define EW(expr_x, expr_y) V2{(expr_x), (expr_y)}
+// the value unchanged, through a CONVERGENT operation (a DPP move with the identity lane pattern quad_perm:[0,1,2,3]):
+// code motion may not make a convergent operation control-dependent on a lane-varying condition
+__device__ __forceinline__ double pin_here(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), 0xE4, 0xf, 0xf, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(x), 0xE4, 0xf, 0xf, true));
+}
+__device__ __forceinline__ V2 pin_here(const V2 &a) { return V2{pin_here(a.x), pin_here(a.y)}; }
 // new time level stored non-temporally by default: +1.2 % at 8192^2 (profiles/r02_shallow_variants.txt)
 #define SW_NT_DEFAULT 2
 
@@ -61,13 +69,23 @@ __device__ __forceinline__ void shallow_tile_body(
     const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
     const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
-    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, unsigned block)
+    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, unsigned block, int stack = 1)
 {
     auto east = [](const V2 &a) { return east_of<DPP>(a); };
     auto west = [](const V2 &a) { return west_of<DPP>(a); };
     const int lane = threadIdx.x & 63;
-    const int w = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int xw = w % nxw, strip = w / nxw;
+    int xw, strip;
+    if (stack <= 1) {
+        const int w = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        xw = w % nxw, strip = w / nxw;
+    } else {
+        // `stack` vertically adjacent tiles per workgroup (experiment, sw_stack): the halo rows two tiles of a
+        // group share are then requested by one CU at about the same time
+        const int wv = threadIdx.x >> 6, sx = (blockDim.x >> 6) / stack, nbx = (nxw + sx - 1) / sx;
+        xw = (int)(block % nbx) * sx + wv % sx;
+        strip = (int)(block / nbx) * stack + wv / sx;
+        if (xw >= nxw) return;
+    }
     const int jb = y0 + strip * R;
     if (jb > y1) return;
     int je = jb + R - 1;
@@ -83,6 +101,17 @@ __device__ __forceinline__ void shallow_tile_body(
     const size_t col = (size_t)cl * 2;
     // rows jb-1 .. jb+R of u, v, p ; rows jb .. jb+R-1 of the old fields (clamped past je+1 / je)
     V2 U[R + 2], Vv[R + 2], P[R + 2], UO[R], VO[R], PO[R];
+    if constexpr ((NTM & 4) != 0) {     // experiment: the once-read old level requested first
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            int jj = jb + k;
+            if (jj > je) jj = je;
+            const size_t o = (size_t)jj * ld + col;
+            UO[k] = ld2<(NTM & 1) != 0>(uold + o);
+            VO[k] = ld2<(NTM & 1) != 0>(vold + o);
+            PO[k] = ld2<(NTM & 1) != 0>(pold + o);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < R + 2; k++) {
         int jj = jb - 1 + k;
@@ -92,15 +121,20 @@ __device__ __forceinline__ void shallow_tile_body(
         Vv[k] = ld2(v + o);
         P[k] = ld2(p + o);
     }
+    if constexpr ((NTM & 4) == 0) {
 #pragma unroll
-    for (int k = 0; k < R; k++) {
-        int jj = jb + k;
-        if (jj > je) jj = je;
-        const size_t o = (size_t)jj * ld + col;
-        UO[k] = ld2<(NTM & 1) != 0>(uold + o);
-        VO[k] = ld2<(NTM & 1) != 0>(vold + o);
-        PO[k] = ld2<(NTM & 1) != 0>(pold + o);
+        for (int k = 0; k < R; k++) {
+            int jj = jb + k;
+            if (jj > je) jj = je;
+            const size_t o = (size_t)jj * ld + col;
+            UO[k] = ld2<(NTM & 1) != 0>(uold + o);
+            VO[k] = ld2<(NTM & 1) != 0>(vold + o);
+            PO[k] = ld2<(NTM & 1) != 0>(pold + o);
+        }
     }
+
+    // straight-line form: no instruction moves across this point, i.e. every load above is issued before the first use
+    if constexpr ((NTM & 8) != 0) __builtin_amdgcn_sched_barrier(0);
 
     // raw neighbours
     V2 Pe[R + 2], Ve[R + 1], Uw[R + 2];
@@ -143,22 +177,32 @@ __device__ __forceinline__ void shallow_tile_body(
 #pragma unroll
     for (int k = 1; k <= R; k++) {
         const int jj = jb - 1 + k;
-        if (jj > je) break;
-        const V2 un = EW(UO[k - 1].x + q.tdts8 * (Z[k].x + Z[k - 1].x) *
+        constexpr bool STRAIGHT = (NTM & 8) != 0;
+        if constexpr (!STRAIGHT) {
+            if (jj > je) break;
+        }
+        V2 un = EW(UO[k - 1].x + q.tdts8 * (Z[k].x + Z[k - 1].x) *
                                            (CVe[k].x + CV[k].x + CV[k - 1].x + CVe[k - 1].x) -
                              q.tdtsdx * (He[k].x - H[k].x),
                          UO[k - 1].y + q.tdts8 * (Z[k].y + Z[k - 1].y) *
                                            (CVe[k].y + CV[k].y + CV[k - 1].y + CVe[k - 1].y) -
                              q.tdtsdx * (He[k].y - H[k].y));
-        const V2 vn = EW(VO[k - 1].x - q.tdts8 * (Z[k].x + Zw[k].x) *
+        V2 vn = EW(VO[k - 1].x - q.tdts8 * (Z[k].x + Zw[k].x) *
                                            (CU[k + 1].x + CUw[k + 1].x + CUw[k].x + CU[k].x) -
                              q.tdtsdy * (H[k + 1].x - H[k].x),
                          VO[k - 1].y - q.tdts8 * (Z[k].y + Zw[k].y) *
                                            (CU[k + 1].y + CUw[k + 1].y + CUw[k].y + CU[k].y) -
                              q.tdtsdy * (H[k + 1].y - H[k].y));
-        const V2 pn = EW(PO[k - 1].x - q.tdtsdx * (CU[k].x - CUw[k].x) - q.tdtsdy * (CV[k].x - CV[k - 1].x),
+        V2 pn = EW(PO[k - 1].x - q.tdtsdx * (CU[k].x - CUw[k].x) - q.tdtsdy * (CV[k].x - CV[k - 1].x),
                          PO[k - 1].y - q.tdtsdx * (CU[k].y - CUw[k].y) - q.tdtsdy * (CV[k].y - CV[k - 1].y));
         const size_t o = (size_t)jj * ld + (size_t)c * 2;
+        if constexpr (STRAIGHT) {
+            // Every value stored goes through a convergent identity first, so that neither the arithmetic nor the
+            // loads of the old time level can be sunk into the (lane-dependent) store branches: all 18 row loads
+            // of the wave tile are then in flight together instead of in two dependent groups.
+            un = pin_here(un); vn = pin_here(vn); pn = pin_here(pn);
+            if (jj > je) continue;
+        }
         if (m0 && m1) {
             st2<(NTM & 2) != 0>(unew + o, un);
             st2<(NTM & 2) != 0>(vnew + o, vn);
@@ -176,9 +220,9 @@ __global__ __launch_bounds__(512) void shallow_tile(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
     const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
-    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew)
+    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, int stack)
 {
-    shallow_tile_body<R, DPP, NTM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, blockIdx.x);
+    shallow_tile_body<R, DPP, NTM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, blockIdx.x, stack);
 }
 
 // The distributed shallow-water step in ONE launch on the caller's stream (as jacobi5_tile_framed): the
@@ -251,12 +295,18 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
 // shallow_tile -- cu, cv, z look WEST/SOUTH, h looks EAST/NORTH -- with its own expression trees
 // (the four-term sums associate differently from the mirrored NE ones, so this is not the NE
 // kernel run backwards).  Row index k = row jb-1+k, as above.
+// wrap (bit 0: x, bit 1: y): the box is the internal region of periodic fields, and every cell stored on its
+// first / last column or row is ALSO stored into the halo cell it is the periodic image of -- the copies of
+// init_periodic_bc_halos (field_mod.f90:1394-1464: east halo column <- first internal column, west halo column <-
+// last internal column over the internal rows; then north halo row <- first internal row, south halo row <- last
+// internal row over the columns widened by the two halo columns, which is what makes the corner halos the doubly
+// wrapped cells) without the two extra launches.
 template <int R, bool DPP, int NTM>
 __global__ __launch_bounds__(512) void shallow_tile_sw(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
     const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
-    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew)
+    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, int wrap)
 {
     auto east = [](const V2 &a) { return east_of<DPP>(a); };
     auto west = [](const V2 &a) { return west_of<DPP>(a); };
@@ -334,35 +384,59 @@ __global__ __launch_bounds__(512) void shallow_tile_sw(
 #pragma unroll
     for (int k = 1; k < R + 1; k++) Hw[k] = west(H[k]);
 
+    if constexpr ((NTM & 8) != 0) __builtin_amdgcn_sched_barrier(0);   // (see shallow_tile_body) nothing sinks below the loads
 #pragma unroll
     for (int k = 1; k <= R; k++) {
         const int jj = jb - 1 + k;
-        if (jj > je) break;
+        constexpr bool STRAIGHT = (NTM & 8) != 0;
+        if constexpr (!STRAIGHT) {
+            if (jj > je) break;
+        }
         // unew = uold + tdts8*(z(i,j+1)+z(i,j))*(cv(i,j+1)+cv(i-1,j+1)+cv(i-1,j)+cv(i,j)) - tdtsdx*(h(i,j)-h(i-1,j))
-        const V2 un = EW(UO[k - 1].x + q.tdts8 * (Z[k + 1].x + Z[k].x) *
+        V2 un = EW(UO[k - 1].x + q.tdts8 * (Z[k + 1].x + Z[k].x) *
                                            (CV[k + 1].x + CVw[k + 1].x + CVw[k].x + CV[k].x) -
                              q.tdtsdx * (H[k].x - Hw[k].x),
                          UO[k - 1].y + q.tdts8 * (Z[k + 1].y + Z[k].y) *
                                            (CV[k + 1].y + CVw[k + 1].y + CVw[k].y + CV[k].y) -
                              q.tdtsdx * (H[k].y - Hw[k].y));
         // vnew = vold - tdts8*(z(i+1,j)+z(i,j))*(cu(i+1,j)+cu(i,j)+cu(i,j-1)+cu(i+1,j-1)) - tdtsdy*(h(i,j)-h(i,j-1))
-        const V2 vn = EW(VO[k - 1].x - q.tdts8 * (Ze[k].x + Z[k].x) *
+        V2 vn = EW(VO[k - 1].x - q.tdts8 * (Ze[k].x + Z[k].x) *
                                            (CUe[k].x + CU[k].x + CU[k - 1].x + CUe[k - 1].x) -
                              q.tdtsdy * (H[k].x - H[k - 1].x),
                          VO[k - 1].y - q.tdts8 * (Ze[k].y + Z[k].y) *
                                            (CUe[k].y + CU[k].y + CU[k - 1].y + CUe[k - 1].y) -
                              q.tdtsdy * (H[k].y - H[k - 1].y));
         // pnew = pold - tdtsdx*(cu(i+1,j)-cu(i,j)) - tdtsdy*(cv(i,j+1)-cv(i,j))
-        const V2 pn = EW(PO[k - 1].x - q.tdtsdx * (CUe[k].x - CU[k].x) - q.tdtsdy * (CV[k + 1].x - CV[k].x),
+        V2 pn = EW(PO[k - 1].x - q.tdtsdx * (CUe[k].x - CU[k].x) - q.tdtsdy * (CV[k + 1].x - CV[k].x),
                          PO[k - 1].y - q.tdtsdx * (CUe[k].y - CU[k].y) - q.tdtsdy * (CV[k + 1].y - CV[k].y));
-        const size_t o = (size_t)jj * ld + (size_t)c * 2;
-        if (m0 && m1) {
-            st2<(NTM & 2) != 0>(unew + o, un);
-            st2<(NTM & 2) != 0>(vnew + o, vn);
-            st2<(NTM & 2) != 0>(pnew + o, pn);
-        } else {
-            if (m0) { unew[o] = un.x; vnew[o] = vn.x; pnew[o] = pn.x; }
-            if (m1) { unew[o + 1] = un.y; vnew[o + 1] = vn.y; pnew[o + 1] = pn.y; }
+        if constexpr (STRAIGHT) {
+            un = pin_here(un); vn = pin_here(vn); pn = pin_here(pn);
+            if (jj > je) continue;
+        }
+        // this row, and the halo row(s) it is the periodic image of
+        int rows[3], nrows = 1;
+        rows[0] = jj;
+        if (wrap & 2) {
+            if (jj == y0) rows[nrows++] = y1 + 1;
+            if (jj == y1) rows[nrows++] = y0 - 1;
+        }
+        for (int r = 0; r < nrows; r++) {
+            const size_t row = (size_t)rows[r] * ld, o = row + (size_t)c * 2;
+            if (m0 && m1) {
+                st2<(NTM & 2) != 0>(unew + o, un);
+                st2<(NTM & 2) != 0>(vnew + o, vn);
+                st2<(NTM & 2) != 0>(pnew + o, pn);
+            } else {
+                if (m0) { unew[o] = un.x; vnew[o] = vn.x; pnew[o] = pn.x; }
+                if (m1) { unew[o + 1] = un.y; vnew[o + 1] = vn.y; pnew[o + 1] = pn.y; }
+            }
+            if (wrap & 1) {     // the first / last internal column also goes to the opposite halo column
+                const int i0 = 2 * c, i1 = 2 * c + 1;
+                if (m0 && i0 == x0) { unew[row + x1 + 1] = un.x; vnew[row + x1 + 1] = vn.x; pnew[row + x1 + 1] = pn.x; }
+                if (m1 && i1 == x0) { unew[row + x1 + 1] = un.y; vnew[row + x1 + 1] = vn.y; pnew[row + x1 + 1] = pn.y; }
+                if (m0 && i0 == x1) { unew[row + x0 - 1] = un.x; vnew[row + x0 - 1] = vn.x; pnew[row + x0 - 1] = pn.x; }
+                if (m1 && i1 == x1) { unew[row + x0 - 1] = un.y; vnew[row + x0 - 1] = vn.y; pnew[row + x0 - 1] = pn.y; }
+            }
         }
     }
 }
@@ -420,10 +494,10 @@ static void sw_rule_shape(int ld, int x0, int x1, int *nxw_out, int *tpb_out)
 void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,
                          const double *u, const double *v, const double *p, const double *uold,
                          const double *vold, const double *pold, double *unew, double *vnew,
-                         double *pnew, hipStream_t s, bool sw_offset, SwFrameJob *fj)
+                         double *pnew, hipStream_t s, bool sw_offset, SwFrameJob *fj, int wrap)
 {
     const int cb = sw_first_chunk(x0);
-    int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & 3;
+    int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & 15;
     {
         std::lock_guard<std::mutex> lk(g_sw_mu);
         auto it = g_sw_cache.find(SwKey{ld, x0, x1, y0, y1});
@@ -436,8 +510,16 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     if (R != 1 && R != 3) R = 2;
     const int h = y1 - y0 + 1, strips = (h + R - 1) / R;
     const long tiles = (long)nxw * strips;
-    const unsigned grid = (unsigned)((tiles + tpb - 1) / tpb);
+    unsigned grid = (unsigned)((tiles + tpb - 1) / tpb);
     const bool dpp = tuning("sw_dpp", 1);
+    // experiments (NE offset, R = 2, DPP): sw_stack = vertically adjacent tiles per workgroup; sw_nt bit 2 = the old
+    // level requested before u, v, p
+    int stack = (!fj && !sw_offset && R == 2 && dpp) ? tuning("sw_stack", 1) : 1;
+    if (stack != 2 && stack != 4) stack = 1;
+    if (stack > tpb) stack = 1;
+    if (stack > 1) grid = (unsigned)(((nxw + tpb / stack - 1) / (tpb / stack)) * (long)((strips + stack - 1) / stack));
+    if ((ntm & 4) && (fj || sw_offset || R != 2 || !dpp)) ntm &= 11;      // old-level-first: NE only
+    if ((ntm & 8) && (fj || R != 2 || !dpp)) ntm &= 3;                     // straight-line: both staggerings, R = 2, DPP
     if (fj) {   // NE offset, R = 2, the default wave shifts: the one form the distributed step uses
         const long cells = 2L * (fj->fx1 - fj->fx0 + 1) + 2L * (fj->fy1 - fj->fy0 + 1);
         long nb = ((cells + 64 * tpb - 1) / (64 * tpb) + 7) & ~7L;    // a multiple of 8: tile groups keep their XCD
@@ -455,10 +537,10 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     do {                                                                                                       \
         if (sw_offset)                                                                                         \
             hipLaunchKernelGGL((shallow_tile_sw<RR, DD, NN>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
-                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew);                      \
+                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, wrap);                \
         else                                                                                                   \
             hipLaunchKernelGGL((shallow_tile<RR, DD, NN>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
-                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew);                      \
+                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, stack);               \
     } while (0)
 #define DLESM_SW2(RR, DD)                                                                                      \
     do {                                                                                                       \
@@ -474,7 +556,21 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
         if (dpp) DLESM_SW2(RR, true);                                                                          \
         else DLESM_SW2(RR, false);                                                                             \
     } while (0)
-    if (R == 1) DLESM_SW(1);
+    if (ntm & 12) {     // only reached for the NE offset, R = 2, DPP
+        switch (ntm) {
+        case 5: DLESM_SW3(2, true, 5); break;
+        case 6: DLESM_SW3(2, true, 6); break;
+        case 7: DLESM_SW3(2, true, 7); break;
+        case 8: DLESM_SW3(2, true, 8); break;
+        case 9: DLESM_SW3(2, true, 9); break;
+        case 10: DLESM_SW3(2, true, 10); break;
+        case 11: DLESM_SW3(2, true, 11); break;
+        case 14: DLESM_SW3(2, true, 14); break;
+        case 15: DLESM_SW3(2, true, 15); break;
+        default: DLESM_SW3(2, true, 4); break;
+        }
+    }
+    else if (R == 1) DLESM_SW(1);
     else if (R == 3) DLESM_SW(3);
     else DLESM_SW(2);
 #undef DLESM_SW2
@@ -579,6 +675,41 @@ extern "C" int dlesm_shallow_step_sw_f64(const dlesm_sw_params *q, int ld, int n
                        pold, unew, vnew, pnew);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
+}
+
+// The SW-offset step over the internal region of periodic fields WITH the periodic copies of the new level inside
+// the launch (shallow_tile_sw's `wrap`): what dlesm_shallow_step_sw_f64 + dlesm_periodic_halos_apply_multi_f64 leave
+// behind, in one launch instead of three.  Arrays that do not qualify for the wave-tile kernel take those three.
+extern "C" int dlesm_shallow_step_sw_periodic_f64(const dlesm_sw_params *q, int ld, int ny, const dlesm_region *internal,
+                                                  int bc_x, int bc_y, const double *u, const double *v, const double *p,
+                                                  const double *uold, const double *vold, const double *pold, double *unew,
+                                                  double *vnew, double *pnew, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(q && internal && u && v && p && uold && vold && pold && unew && vnew && pnew, "null pointer");
+    const int xstart = internal->xstart, xstop = internal->xstop, ystart = internal->ystart, ystop = internal->ystop;
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("dlesm_shallow_step_sw_periodic_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    DLESM_REQUIRE(unew != u && unew != v && unew != p && vnew != u && vnew != v && vnew != p &&
+                      pnew != u && pnew != v && pnew != p && unew != vnew && unew != pnew && vnew != pnew,
+                  "shallow step: outputs alias the 3x3-read inputs or each other");
+    const int wrap = (bc_x == DLESM_BC_PERIODIC ? 1 : 0) | (bc_y == DLESM_BC_PERIODIC ? 2 : 0);
+    bool aligned = ld % 2 == 0 || (xstop - 1) + 1 <= 2 * (ld / 2) - 1;
+    for (const double *f : {u, v, p, uold, vold, pold, (const double *)unew, (const double *)vnew,
+                            (const double *)pnew})
+        aligned = aligned && ((uintptr_t)f % 16 == 0);
+    if (aligned && tuning("sw_kernel", 0) == 0 && tuning("sw_wrap_fused", 1)) {
+        launch_shallow_tile(*q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold, unew,
+                            vnew, pnew, (hipStream_t)stream, true, nullptr, wrap);
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
+    if (int rc = dlesm_shallow_step_sw_f64(q, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, unew, vnew,
+                                           pnew, stream))
+        return rc;
+    if (!wrap) return DLESM_OK;
+    double *fields[3] = {unew, vnew, pnew};
+    return dlesm_periodic_halos_apply_multi_f64(fields, 3, ld, ny, internal, bc_x, bc_y, stream);
 }
 
 // Up to 16 fields x 2 independent patch copies in one launch: grid.y = field * 2 + copy.

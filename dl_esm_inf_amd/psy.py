@@ -155,6 +155,109 @@ def invoke_shallow_step_sw(params, u, v, p, uold, vold, pold, unew, vnew, pnew, 
                                                 pnew.device_ptr, _stream_ptr(stream)))
 
 
+# ---- the GOcean `shallow` kernels one by one: what an unmodified generated PSy layer calls ----------------
+def _kernel_box(out_fld, box):
+    """the loop bounds of the nest: the written field's internal region (ITERATES_OVER = GO_INTERNAL_PTS,
+    kernel_mod.f90:28-50) unless the caller's PSy layer runs the kernel over another box"""
+    return tuple(box) if box is not None else out_fld.internal.box()
+
+
+def invoke_compute_cu(cu, p, u, box=None, stream=None):
+    """`call compute_cu_code(ji, jj, cu%data, p%data, u%data)` over cu%internal"""
+    g = cu.grid
+    check(_cabi.lib().dlesm_compute_cu_f64(g.offset, g.nx, g.ny, *_kernel_box(cu, box), cu.device_ptr, p.device_ptr,
+                                           u.device_ptr, _stream_ptr(stream)))
+
+
+def invoke_compute_cv(cv, p, v, box=None, stream=None):
+    g = cv.grid
+    check(_cabi.lib().dlesm_compute_cv_f64(g.offset, g.nx, g.ny, *_kernel_box(cv, box), cv.device_ptr, p.device_ptr,
+                                           v.device_ptr, _stream_ptr(stream)))
+
+
+def invoke_compute_z(z, p, u, v, box=None, stream=None):
+    """fsdx = 4/dx, fsdy = 4/dy from the grid (the kernel's GO_GRID_DX_CONST / GO_GRID_DY_CONST arguments)"""
+    g = z.grid
+    check(_cabi.lib().dlesm_compute_z_f64(g.offset, g.nx, g.ny, *_kernel_box(z, box), 4.0 / g.dx, 4.0 / g.dy,
+                                          z.device_ptr, p.device_ptr, u.device_ptr, v.device_ptr, _stream_ptr(stream)))
+
+
+def invoke_compute_h(h, p, u, v, box=None, stream=None):
+    g = h.grid
+    check(_cabi.lib().dlesm_compute_h_f64(g.offset, g.nx, g.ny, *_kernel_box(h, box), h.device_ptr, p.device_ptr,
+                                          u.device_ptr, v.device_ptr, _stream_ptr(stream)))
+
+
+def invoke_compute_unew(unew, uold, z, cv, h, tdt, box=None, stream=None):
+    """tdt = 2*dt in a leapfrog step; tdts8 = tdt/8, tdtsdx = tdt/dx"""
+    g = unew.grid
+    check(_cabi.lib().dlesm_compute_unew_f64(g.offset, g.nx, g.ny, *_kernel_box(unew, box), tdt / 8.0, tdt / g.dx,
+                                             unew.device_ptr, uold.device_ptr, z.device_ptr, cv.device_ptr,
+                                             h.device_ptr, _stream_ptr(stream)))
+
+
+def invoke_compute_vnew(vnew, vold, z, cu, h, tdt, box=None, stream=None):
+    g = vnew.grid
+    check(_cabi.lib().dlesm_compute_vnew_f64(g.offset, g.nx, g.ny, *_kernel_box(vnew, box), tdt / 8.0, tdt / g.dy,
+                                             vnew.device_ptr, vold.device_ptr, z.device_ptr, cu.device_ptr,
+                                             h.device_ptr, _stream_ptr(stream)))
+
+
+def invoke_compute_pnew(pnew, pold, cu, cv, tdt, box=None, stream=None):
+    g = pnew.grid
+    check(_cabi.lib().dlesm_compute_pnew_f64(g.offset, g.nx, g.ny, *_kernel_box(pnew, box), tdt / g.dx, tdt / g.dy,
+                                             pnew.device_ptr, pold.device_ptr, cu.device_ptr, cv.device_ptr,
+                                             _stream_ptr(stream)))
+
+
+def invoke_time_smooth(field, field_new, field_old, alpha, box=None, stream=None):
+    """field_old = field + alpha*(field_new - 2*field + field_old) over field_old%internal"""
+    g = field_old.grid
+    check(_cabi.lib().dlesm_time_smooth_f64(g.nx, g.ny, *_kernel_box(field_old, box), float(alpha), field.device_ptr,
+                                            field_new.device_ptr, field_old.device_ptr, _stream_ptr(stream)))
+
+
+def invoke_shallow_kernel_sequence(tdt, u, v, p, uold, vold, pold, cu, cv, z, h, unew, vnew, pnew, stream=None):
+    """One time step the way a generated PSy layer runs it: seven loop nests, every intermediate through HBM
+    (224 B/cell).  Non-periodic grids: cu, cv, z, h over the internal region grown towards their consumers (all
+    operands stay inside the boundary ring); periodic (SW-offset) grids: over the internal region, followed by
+    their periodic copies, as the benchmark does.  Bit-identical to invoke_shallow_step / invoke_shallow_step_sw."""
+    g = p.grid
+    xs, xe, ys, ye = p.internal.box()
+    periodic = GO_BC_PERIODIC_ in g.boundary_conditions[:2]
+    if periodic:
+        grown = dict(cu=None, cv=None, z=None, h=None)
+    elif g.offset == grid_mod.GO_OFFSET_NE:
+        grown = dict(cu=(xs - 1, xe, ys, ye + 1), cv=(xs, xe + 1, ys - 1, ye), z=(xs - 1, xe, ys - 1, ye),
+                     h=(xs, xe + 1, ys, ye + 1))
+    else:
+        grown = dict(cu=(xs, xe + 1, ys - 1, ye), cv=(xs - 1, xe, ys, ye + 1), z=(xs, xe + 1, ys, ye + 1),
+                     h=(xs - 1, xe, ys - 1, ye))
+    invoke_compute_cu(cu, p, u, grown["cu"], stream)
+    invoke_compute_cv(cv, p, v, grown["cv"], stream)
+    invoke_compute_z(z, p, u, v, grown["z"], stream)
+    invoke_compute_h(h, p, u, v, grown["h"], stream)
+    if periodic:
+        apply_periodic_halos_multi([cu, cv, z, h], stream)
+    invoke_compute_unew(unew, uold, z, cv, h, tdt, None, stream)
+    invoke_compute_vnew(vnew, vold, z, cu, h, tdt, None, stream)
+    invoke_compute_pnew(pnew, pold, cu, cv, tdt, None, stream)
+
+
+GO_BC_PERIODIC_ = grid_mod.GO_BC_PERIODIC
+
+
+def invoke_shallow_step_sw_periodic(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
+    """the SW-offset step over the internal region AND the periodic copies of the three new fields in one launch
+    (== invoke_shallow_step_sw + apply_periodic_halos_multi, bit for bit)"""
+    g = p.grid
+    check(_cabi.lib().dlesm_shallow_step_sw_periodic_f64(C.byref(params), g.nx, g.ny, C.byref(p.internal),
+                                                         g.boundary_conditions[0], g.boundary_conditions[1],
+                                                         u.device_ptr, v.device_ptr, p.device_ptr, uold.device_ptr,
+                                                         vold.device_ptr, pold.device_ptr, unew.device_ptr,
+                                                         vnew.device_ptr, pnew.device_ptr, _stream_ptr(stream)))
+
+
 def apply_periodic_halos(fld, stream=None):
     """the periodic-boundary copies of a field (field_mod.f90:1394-1464), on the device"""
     g = fld.grid

@@ -31,13 +31,14 @@
 #define DLESM_HIP_H
 
 #include <stdbool.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define DLESM_VERSION 200   /* round 2: entries added (pipelined steps, 3x3 stencil, continuity, gather/scatter ...); no signature changed; dirs_mask 0 now exchanges nothing, as in the reference */
+#define DLESM_VERSION 300   /* round 3: entries added (the GOcean shallow kernels one by one, time_smooth, fused periodic step, plan description ...); no signature changed */
 
 /* error codes */
 #define DLESM_OK 0
@@ -306,6 +307,54 @@ int dlesm_shallow_step_sw_f64(const dlesm_sw_params *params, int ld, int ny,
                               const double *uold, const double *vold, const double *pold,
                               double *unew, double *vnew, double *pnew, void *stream);
 
+/* The same step over the INTERNAL region of periodic fields, with the periodic copies of the new level done by
+ * the same launch: every cell stored on the first / last internal column or row is also stored into the halo cell
+ * that init_periodic_bc_halos (field_mod.f90:1394-1464) would copy it to, corner halos included.  Leaves unew,
+ * vnew, pnew exactly as dlesm_shallow_step_sw_f64 over `internal` followed by
+ * dlesm_periodic_halos_apply_multi_f64 does -- one launch instead of three.  bc_x, bc_y: the grid's
+ * boundary_conditions(1:2); a non-periodic direction gets no copies. */
+int dlesm_shallow_step_sw_periodic_f64(const dlesm_sw_params *params, int ld, int ny,
+                                       const dlesm_region *internal, int bc_x, int bc_y,
+                                       const double *u, const double *v, const double *p,
+                                       const double *uold, const double *vold, const double *pold,
+                                       double *unew, double *vnew, double *pnew, void *stream);
+
+/* The GOcean `shallow` kernel set as SEPARATE launch entries: one per PSy loop nest, which is what a
+ * PSyclone-generated PSy layer has -- `do jj / do ji / call compute_cu_code(ji, jj, cu%data, p%data,
+ * u%data)` becomes dlesm_compute_cu_f64 over the same index box (kernel form infrastructure_mod.f90:13-41,
+ * metadata argument_mod.f90:39-112, kernel_mod.f90:28-50).  Array arguments in the kernels' own order
+ * (the written field first).  `offset` is the kernel's index_offset, DLESM_OFFSET_NE or DLESM_OFFSET_SW;
+ * formulas frozen in DESIGN.md section 6 (NE), 6.2 (SW), 6.3 (time_smooth) -- the expression trees of the
+ * fused step, so that the seven launches
+ *     cu, cv, z, h  (each over the box grown towards its consumers, or over the internal region followed by
+ *     the periodic copies)  then  unew, vnew, pnew
+ * give bit for bit what dlesm_shallow_step_f64 / dlesm_shallow_step_sw_f64 give, at 224 B/cell of HBM
+ * traffic instead of 72.  The box plus the cells its stencil reads must lie inside the ld x ny arrays;
+ * the output may not alias an input (time_smooth updates field_old in place).
+ *   NE:  cu(i,j) = 0.5*(p(i+1,j)+p(i,j))*u(i,j)         SW:  cu(i,j) = 0.5*(p(i,j)+p(i-1,j))*u(i,j)   ... */
+int dlesm_compute_cu_f64(int offset, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                         double *cu, const double *p, const double *u, void *stream);
+int dlesm_compute_cv_f64(int offset, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                         double *cv, const double *p, const double *v, void *stream);
+int dlesm_compute_z_f64(int offset, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                        double fsdx, double fsdy, double *z, const double *p, const double *u,
+                        const double *v, void *stream);
+int dlesm_compute_h_f64(int offset, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                        double *h, const double *p, const double *u, const double *v, void *stream);
+int dlesm_compute_unew_f64(int offset, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                           double tdts8, double tdtsdx, double *unew, const double *uold,
+                           const double *z, const double *cv, const double *h, void *stream);
+int dlesm_compute_vnew_f64(int offset, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                           double tdts8, double tdtsdy, double *vnew, const double *vold,
+                           const double *z, const double *cu, const double *h, void *stream);
+int dlesm_compute_pnew_f64(int offset, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                           double tdtsdx, double tdtsdy, double *pnew, const double *pold,
+                           const double *cu, const double *cv, void *stream);
+/* time_smooth (the Asselin filter of the `shallow` leapfrog; any offset; pointwise):
+ *   field_old(i,j) = field(i,j) + alpha*(field_new(i,j) - 2.0*field(i,j) + field_old(i,j)) */
+int dlesm_time_smooth_f64(int ld, int ny, int xstart, int xstop, int ystart, int ystop, double alpha,
+                          const double *field, const double *field_new, double *field_old, void *stream);
+
 /* All periodic-boundary copies of one field (dlesm_periodic_halos' regions, applied in order with
  * the patch copy below), enqueued on `stream`: what the PSy layer of a periodic model does after
  * every kernel that writes the field. */
@@ -332,6 +381,14 @@ int dlesm_checksum_f64(const double *f, int ld, int ny, int xstart, int xstop,
  * on the box, gi = gx0+i-1, gj = gy0+j-1; cells outside the box are left alone. */
 int dlesm_hash_init_f64(double *f, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                         uint64_t seed, int64_t gx0, int64_t gy0, void *stream);
+
+/* Diagnostic (no reference counterpart): a linear sweep that reads `nread` arrays once and writes `nwrite`
+ * arrays once, n doubles each, one 16-byte element per thread per array -- the ceiling a kernel with that many
+ * concurrent HBM streams is measured against in the same process (bench.py's copy_ceiling).  Combinations:
+ * 1+1, 2+1, 3+1, 4+1, 6+3, 8+1.  nt bit 0: the second half of the read arrays loaded non-temporally; bit 1:
+ * non-temporal stores.  dst_k = (sum of the read arrays) + src_(k mod nread)   (1+1: a plain copy). */
+int dlesm_stream_copy_f64(int nread, int nwrite, const double *const *src, double *const *dst, size_t n,
+                          int nt, void *stream);
 
 /* kernel tuning knobs ("j5_rows", "j5_variant", ...) for benchmarking; returns previous value */
 int dlesm_set_tuning(const char *key, int value);

@@ -815,6 +815,50 @@ void orc_sw_step_sw(const orc_sw_params *q, int ld, int xs, int xe, int ys, int 
         for (i = xs; i <= xe; i++) compute_pnew_sw_code(i, j, pnew, pold, cu, cv, q->tdtsdx, q->tdtsdy, ld);
 }
 
+/* time_smooth of the GOcean `shallow` benchmark [external; not in /root/reference] -- the Asselin filter of
+ * the leapfrog scheme, pointwise, formula frozen in DESIGN.md section 6.3 */
+static inline void time_smooth_code(int i, int j, const double *field, const double *field_new, double *field_old,
+                                    double alpha, int ld)
+{
+    A(field_old, i, j) = A(field, i, j) + alpha * (A(field_new, i, j) - 2.0 * A(field, i, j) + A(field_old, i, j));
+}
+
+/* ONE kernel of the set over a 1-based inclusive box: the PSy loop nest `do j / do i / call kern_code(i, j, ...)`
+ * (form: infrastructure_mod.f90:32-41) -- the checker of the per-kernel launch entries dlesm_compute_*_f64.
+ * kernel: 0 cu(out; p, u)  1 cv(out; p, v)  2 z(out; p, u, v; s0 = fsdx, s1 = fsdy)  3 h(out; p, u, v)
+ *         4 unew(out; uold, z, cv, h; tdts8, tdtsdx)  5 vnew(out; vold, z, cu, h; tdts8, tdtsdy)
+ *         6 pnew(out; pold, cu, cv; tdtsdx, tdtsdy)   7 time_smooth(out = field_old; field, field_new, field_old; alpha)
+ * sw_offset: 0 = NE staggering, 1 = SW staggering.  Returns -1 for an unknown kernel. */
+int orc_sw_kernel(int kernel, int sw_offset, int ld, int xs, int xe, int ys, int ye, double s0, double s1,
+                  double *out, const double *a, const double *b, const double *c, const double *d)
+{
+    int i, j;
+    if (kernel < 0 || kernel > 7) return -1;
+    for (j = ys; j <= ye; j++)
+        for (i = xs; i <= xe; i++) {
+            if (!sw_offset) switch (kernel) {
+                case 0: compute_cu_code(i, j, out, a, b, ld); break;
+                case 1: compute_cv_code(i, j, out, a, b, ld); break;
+                case 2: compute_z_code(i, j, out, a, b, c, s0, s1, ld); break;
+                case 3: compute_h_code(i, j, out, a, b, c, ld); break;
+                case 4: compute_unew_code(i, j, out, a, b, c, d, s0, s1, ld); break;
+                case 5: compute_vnew_code(i, j, out, a, b, c, d, s0, s1, ld); break;
+                case 6: compute_pnew_code(i, j, out, a, b, c, s0, s1, ld); break;
+                default: time_smooth_code(i, j, a, b, out, s0, ld); break;
+            } else switch (kernel) {
+                case 0: compute_cu_sw_code(i, j, out, a, b, ld); break;
+                case 1: compute_cv_sw_code(i, j, out, a, b, ld); break;
+                case 2: compute_z_sw_code(i, j, out, a, b, c, s0, s1, ld); break;
+                case 3: compute_h_sw_code(i, j, out, a, b, c, ld); break;
+                case 4: compute_unew_sw_code(i, j, out, a, b, c, d, s0, s1, ld); break;
+                case 5: compute_vnew_sw_code(i, j, out, a, b, c, d, s0, s1, ld); break;
+                case 6: compute_pnew_sw_code(i, j, out, a, b, c, s0, s1, ld); break;
+                default: time_smooth_code(i, j, a, b, out, s0, ld); break;
+            }
+        }
+    return 0;
+}
+
 /* init_periodic_bc_halos, field_mod.f90:1394-1464: source/dest hold up to 4 regions each, in the
  * reference's order; returns their number.  bc: 0 = GO_BC_PERIODIC (grid_mod.f90:64-69). */
 int orc_periodic_halos(const orc_region *it, int bc_x, int bc_y, orc_region *source, orc_region *dest)

@@ -156,6 +156,9 @@ void orc_sw_step_sw(const orc_sw_params *q, int ld, int xs, int xe, int ys, int 
                     const double *uold, const double *vold, const double *pold,
                     double *cu, double *cv, double *z, double *h,
                     double *unew, double *vnew, double *pnew);
+/* one kernel of the GOcean shallow set as its own PSy loop nest (see dlesm_oracle.c); PARITY UNPINNED */
+int orc_sw_kernel(int kernel, int sw_offset, int ld, int xs, int xe, int ys, int ye, double s0, double s1,
+                  double *out, const double *a, const double *b, const double *c, const double *d);
 int orc_periodic_halos(const orc_region *it, int bc_x, int bc_y, orc_region *source, orc_region *dest);
 void orc_apply_periodic_halos(double *f, int ld, const orc_region *it, int bc_x, int bc_y);
 

@@ -101,6 +101,8 @@ def lib():
     L.orc_tmask_fill.argtypes = [C.c_void_p] + [C.c_int] * 7 + [_ip]
     L.orc_sw_step.argtypes = [C.POINTER(SwParams)] + [C.c_int] * 5 + [_dp] * 13
     L.orc_sw_step_sw.argtypes = [C.POINTER(SwParams)] + [C.c_int] * 5 + [_dp] * 13
+    L.orc_sw_kernel.argtypes = [C.c_int] * 7 + [C.c_double] * 2 + [C.c_void_p] * 5
+    L.orc_sw_kernel.restype = C.c_int
     L.orc_periodic_halos.argtypes = [C.POINTER(Region), C.c_int, C.c_int, C.POINTER(Region), C.POINTER(Region)]
     L.orc_periodic_halos.restype = C.c_int
     L.orc_apply_periodic_halos.argtypes = [_dp, C.c_int, C.POINTER(Region), C.c_int, C.c_int]
@@ -283,3 +285,18 @@ def continuity(rdt, ld, box, sshn_t, sshn_u, sshn_v, hu, hv, un, vn, area_t, ssh
 def stencil9(inp, out, coef, ld, xs, xe, ys, ye):
     c = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(9))
     lib().orc_stencil9(inp, out, c, ld, xs, xe, ys, ye)
+
+
+SW_KERNELS = ("cu", "cv", "z", "h", "unew", "vnew", "pnew", "time_smooth")
+
+
+def sw_kernel(name, sw_offset, ld, box, out, ins, s0=0.0, s1=0.0):
+    """ONE kernel of the GOcean shallow set as its own PSy loop nest over the 1-based inclusive box:
+    out <- kern(ins...), arrays in the kernel's argument order (see orc_sw_kernel); (ny, ld) arrays"""
+    ptr = [None] * 4
+    for k, a in enumerate(ins):
+        assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+        ptr[k] = a.ctypes.data
+    assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"]
+    rc = lib().orc_sw_kernel(SW_KERNELS.index(name), 1 if sw_offset else 0, ld, *box, s0, s1, out.ctypes.data, *ptr)
+    assert rc == 0, rc

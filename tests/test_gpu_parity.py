@@ -1078,10 +1078,15 @@ def test_shallow_cache_policies_and_planned_shapes_change_no_bit(D, nx, ny, alig
         for n, w in zip(names[6:], want):
             assert np.array_equal(F[n].get_data(), w), (tag, n)
 
-    for nt in (0, 1, 2, 3):
+    # bits 0/1: non-temporal loads / stores; bit 2: the old level requested first; bit 3: the straight-line form
+    for nt in (0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 14, 15):
         _set_tuning(D, sw_nt=nt)
         check(f"sw_nt={nt}")
-    _set_tuning(D, sw_nt=2)
+    _set_tuning(D, sw_nt=10)
+    for stack in (2, 4):                       # vertically adjacent tiles per workgroup
+        _set_tuning(D, sw_stack=stack)
+        check(f"sw_stack={stack}")
+    _set_tuning(D, sw_nt=2, sw_stack=1)
     D.psy.autotune_shallow(prm, *[F[n] for n in names])
     check("planned")
     _set_tuning(D, j5_use_tuned=0)
@@ -1091,15 +1096,19 @@ def test_shallow_cache_policies_and_planned_shapes_change_no_bit(D, nx, ny, alig
 
 @pytest.mark.parametrize("nx,ny,alignment,steps", [(10, 10, None, 5), (10, 10, 8, 5), (256, 256, None, 4), (256, 256, 64, 4),
                                                    (37, 5, 2, 3), (1000, 130, 64, 3), (2100, 7, 2, 2)])
-@pytest.mark.parametrize("sw_kernel,sw_rows", [(0, 2), (0, 3), (1, 2)])
-def test_periodic_sw_offset_shallow_model(D, nx, ny, alignment, steps, sw_kernel, sw_rows):
+@pytest.mark.parametrize("sw_kernel,sw_rows,sw_nt,fused_halos", [(0, 2, 2, False), (0, 3, 2, False), (1, 2, 2, False),
+                                                                  (0, 2, 2, True), (0, 2, 10, True), (0, 3, 0, True),
+                                                                  (1, 2, 2, True), (0, 2, 11, False)])
+def test_periodic_sw_offset_shallow_model(D, nx, ny, alignment, steps, sw_kernel, sw_rows, sw_nt, fused_halos):
     """the configuration section 8 f.2 was built for: SW offset, periodic in x and y (serial only in
     the reference, field_mod.f90:675-751): dlesm_shallow_step_sw_f64 + the device periodic-halo
     copies (the field's own halo list) + leapfrog rotation, `steps` times, every bit against the
     oracle running the same model (orc_sw_step_sw pinned by tests/sw_numpy.py, halo regions by the
     reference's)"""
     import torch
-    _set_tuning(D, sw_kernel=sw_kernel, sw_tile_rows=sw_rows)        # wave-tile kernel (R rows) / one cell per thread
+    # wave-tile kernel (R rows; sw_nt bit 3 = its straight-line form) / one cell per thread; fused_halos: the periodic
+    # copies of the new level written by the step's own launch (dlesm_shallow_step_sw_periodic_f64)
+    _set_tuning(D, sw_kernel=sw_kernel, sw_tile_rows=sw_rows, sw_nt=sw_nt)
     g = _grid(D, nx, ny, alignment, offset=D.GO_OFFSET_SW, bc=(0, 0, 2))
     names, F = _sw_fields(D, g)
     it = F["p"].internal
@@ -1124,17 +1133,30 @@ def test_periodic_sw_offset_shallow_model(D, nx, ny, alignment, steps, sw_kernel
     cur, old, new = [F[n] for n in "uvp"], [F[n + "old"] for n in "uvp"], [F[n + "new"] for n in "uvp"]
     hc, ho, hn = [H[n] for n in "uvp"], [H[n + "old"] for n in "uvp"], [H[n + "new"] for n in "uvp"]
     for _ in range(steps):
-        D.psy.invoke_shallow_step_sw(prm, *cur, *old, *new)
-        D.psy.apply_periodic_halos_multi(new)                    # all three new fields: two launches
+        if fused_halos:
+            for f in new:                                        # stale halos must be overwritten, not inherited
+                f.data[0, :] = -3.0
+                f.data[:, 0] = -3.0
+                f.data[it.ystop, :] = -3.0
+                f.data[:, it.xstop] = -3.0
+            D.psy.invoke_shallow_step_sw_periodic(prm, *cur, *old, *new)
+        else:
+            D.psy.invoke_shallow_step_sw(prm, *cur, *old, *new)
+            D.psy.apply_periodic_halos_multi(new)                # all three new fields: two launches
         O.sw_step_sw(prm, g.nx, it.box(), *hc, *ho, *hn)
         for f in hn:
             O.apply_periodic_halos(f, g.nx, it.box(), 0, 0)
         torch.cuda.synchronize()
         for f, w in zip(new, hn):
-            assert np.array_equal(f.get_data(), w)
+            got = f.get_data()
+            if fused_halos:                                      # the wrecked cells beyond the halo ring are not the model's
+                assert np.array_equal(got[:it.ystop + 1, :it.xstop + 1], w[:it.ystop + 1, :it.xstop + 1])
+                f.set_data(w)
+            else:
+                assert np.array_equal(got, w)
         old, cur, new = cur, new, old
         ho, hc, hn = hc, hn, ho
-    _set_tuning(D, sw_kernel=0, sw_tile_rows=2)
+    _set_tuning(D, sw_kernel=0, sw_tile_rows=2, sw_nt=2)
 
 
 def _sw_fields(D, g):

@@ -1,0 +1,240 @@
+"""GPU parity of the GOcean `shallow` kernel set as SEPARATE launch entries (dlesm_compute_{cu,cv,z,h,unew,vnew,
+pnew}_f64, dlesm_time_smooth_f64): what a PSyclone-generated PSy layer calls, one launch per
+loop nest.  Each kernel against the CPU checker's loop nest of the same kernel (orc_sw_kernel, itself pinned by the
+whole-array numpy evaluation in tests/sw_numpy.py), bit for bit; the seven launches against the fused step, bit for
+bit, up to BASELINE configs[3]'s 8192^2.  PARITY UNPINNED by the reference: it holds no stencil.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import sw_numpy as N
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20261004
+DX, DY, DT = 1.0e5, 0.9e5, 90.0
+
+
+@pytest.fixture(scope="module")
+def D():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    import dl_esm_inf_amd as d
+    torch.cuda.set_device(0)
+    d.parallel_init(0, 1)
+    return d
+
+
+def _grid(D, nx, ny, alignment, sw_offset):
+    if alignment is None:
+        os.environ.pop("DL_ESM_ALIGNMENT", None)
+    else:
+        os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    if sw_offset:       # the GOcean `shallow` configuration: SW offset, periodic in x and y (serial only in the reference)
+        g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_PERIODIC, D.GO_BC_PERIODIC, D.GO_BC_NONE), D.GO_OFFSET_SW)
+    else:
+        g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
+    g.decompose(nx, ny)
+    D.grid_init(g, DX, DY)
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+    return g
+
+
+def _launch(D, name, offset, ld, ny, box, out, ins, s0, s1):
+    """the C entry of kernel `name` on raw device pointers"""
+    L = D._cabi.lib()
+    ptr = [C.c_void_p(t.data_ptr()) for t in ins]
+    o = C.c_void_p(out.data_ptr())
+    if name == "time_smooth":
+        return L.dlesm_time_smooth_f64(ld, ny, *box, s0, ptr[0], ptr[1], o, None)
+    fn = getattr(L, f"dlesm_compute_{name}_f64")
+    if name in ("z", "unew", "vnew", "pnew"):
+        return fn(offset, ld, ny, *box, s0, s1, o, *ptr, None)
+    return fn(offset, ld, ny, *box, o, *ptr, None)
+
+
+@pytest.mark.parametrize("swk_kernel", [0, 1], ids=["tile", "direct"])
+@pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW"])
+@pytest.mark.parametrize("name", O.SW_KERNELS)
+def test_each_kernel_matches_its_oracle_loop_nest(D, name, sw_offset, swk_kernel):
+    """arbitrary input arrays (the intermediates are NOT derived from a state), even and odd leading dimensions,
+    boxes from one cell to the largest the kernel's stencil allows (touching the array edge on the sides it does
+    not read), ragged widths around the 62/63/64-lane tile boundaries; nothing outside the box is written"""
+    import torch
+    D._cabi.lib().dlesm_set_tuning(b"swk_kernel", swk_kernel)
+    prm = N.Params(DX, DY, DT)
+    s0, s1 = N.kernel_scalars(name, prm)
+    rw, re, rs, rn = N.KERNEL_RING[sw_offset][name]
+    offset = D.GO_OFFSET_SW if sw_offset else D.GO_OFFSET_NE
+    try:
+        for (ld, nyarr) in [(40, 31), (37, 12), (131, 9), (3, 3), (256, 7), (259, 6), (1030, 40), (4163, 5)]:
+            rng = np.random.default_rng(ld * 100 + nyarr + len(name))
+            host = [rng.random((nyarr, ld)) + 0.5 for _ in range(N.KERNEL_NIN[name])]
+            dev = [torch.from_numpy(h).cuda() for h in host]
+            tight = (1 + rw, ld - re, 1 + rs, nyarr - rn)
+            boxes = [tight, (2, ld - 1, 2, nyarr - 1), (3, ld - 2, 3, nyarr - 2), (tight[0], tight[0], tight[2], tight[3]),
+                     (tight[0], tight[1], tight[3], tight[3]), (5, 4, 2, 3), (ld // 2, ld // 2 + 1, 2, 2),
+                     (124, 127, 2, nyarr - 1), (125, 253, 2, nyarr - 1)]
+            for box in boxes:
+                if box[0] < tight[0] or box[1] > tight[1] or box[2] < tight[2] or box[3] > tight[3]:
+                    continue
+                if name == "time_smooth":
+                    want = host[2].copy()
+                    O.sw_kernel(name, sw_offset, ld, box, want, [host[0], host[1], want], s0, s1)
+                    out = dev[2].clone()
+                    rc = _launch(D, name, offset, ld, nyarr, box, out, [dev[0], dev[1], out], s0, s1)
+                else:
+                    want = np.full((nyarr, ld), 9.0)
+                    O.sw_kernel(name, sw_offset, ld, box, want, host, s0, s1)
+                    out = torch.full((nyarr, ld), 9.0, dtype=torch.float64, device="cuda")
+                    rc = _launch(D, name, offset, ld, nyarr, box, out, dev, s0, s1)
+                D._cabi.check(rc)
+                assert np.array_equal(out.cpu().numpy(), want), (name, sw_offset, ld, nyarr, box)
+    finally:
+        D._cabi.lib().dlesm_set_tuning(b"swk_kernel", 0)
+
+
+def test_kernel_entries_reject_what_a_loop_nest_could_not_run(D):
+    import torch
+    L = D._cabi.lib()
+    a, b, c = (torch.zeros((8, 16), dtype=torch.float64, device="cuda") for _ in range(3))
+    p = [C.c_void_p(t.data_ptr()) for t in (a, b, c)]
+    # cu (NE) reads p(i+1,j): the box may touch the west edge but not the east one
+    assert L.dlesm_compute_cu_f64(D.GO_OFFSET_NE, 16, 8, 1, 15, 1, 8, p[0], p[1], p[2], None) == 0
+    assert L.dlesm_compute_cu_f64(D.GO_OFFSET_NE, 16, 8, 1, 16, 1, 8, p[0], p[1], p[2], None) == D._cabi.EINVAL
+    assert L.dlesm_compute_cu_f64(D.GO_OFFSET_SW, 16, 8, 1, 16, 1, 8, p[0], p[1], p[2], None) == D._cabi.EINVAL
+    assert L.dlesm_compute_cu_f64(D.GO_OFFSET_SW, 16, 8, 2, 16, 1, 8, p[0], p[1], p[2], None) == 0
+    # only NE and SW staggerings exist
+    assert L.dlesm_compute_cu_f64(D.GO_OFFSET_SE, 16, 8, 2, 15, 2, 7, p[0], p[1], p[2], None) == D._cabi.EINVAL
+    # the written array may not be one that is read at a neighbouring point ...
+    assert L.dlesm_compute_cu_f64(D.GO_OFFSET_NE, 16, 8, 2, 15, 2, 7, p[0], p[0], p[2], None) == D._cabi.EINVAL
+    # ... time_smooth updates field_old in place (pointwise), and an empty box is a zero-trip loop
+    assert L.dlesm_time_smooth_f64(16, 8, 1, 16, 1, 8, 0.001, p[0], p[1], p[2], None) == 0
+    assert L.dlesm_compute_h_f64(D.GO_OFFSET_NE, 16, 8, 5, 4, 2, 3, p[0], p[1], p[2], p[2], None) == 0
+    assert L.dlesm_compute_h_f64(D.GO_OFFSET_NE, 16, 8, 2, 15, 2, 7, None, p[1], p[2], p[2], None) == D._cabi.EINVAL
+    torch.cuda.synchronize()
+
+
+def _state(D, g):
+    """u, v, p (+ old, new copies) and the four intermediates as fields of the grid; hash initial data"""
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    F = {n: D.r2d_field(g, pts[n[0]]) for n in names}
+    for n, pt in (("cu", D.GO_U_POINTS), ("cv", D.GO_V_POINTS), ("z", D.GO_F_POINTS), ("h", D.GO_T_POINTS)):
+        F[n] = D.r2d_field(g, pt)
+    periodic = g.boundary_conditions[0] == D.GO_BC_PERIODIC
+    for k, n in enumerate("uvp"):
+        D.psy.hash_init(F[n], SEED + 70 + k, box=F[n].internal if periodic else None)
+        F[n].data.add_(1.0 if n == "p" else -0.5)
+        if periodic:
+            D.psy.apply_periodic_halos(F[n])
+        D.psy.hash_init(F[n + "old"], SEED + 80 + k, box=F[n].internal)
+        F[n + "old"].data.add_(1.0 if n == "p" else -0.5)
+    return names, F
+
+
+SEQ_CASES = [(10, 10, None), (37, 5, 2), (64, 48, None), (256, 256, 64), (1000, 130, None), (1021, 33, 8),
+             (1500, 200, 64), (2100, 7, 2)]
+
+
+@pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW-periodic"])
+@pytest.mark.parametrize("nx,ny,alignment", SEQ_CASES)
+def test_seven_launches_equal_the_fused_step(D, nx, ny, alignment, sw_offset):
+    """the un-fused GOcean sequence (cu, cv, z, h [+ their periodic copies], unew, vnew, pnew -- seven launches, every
+    intermediate through HBM) == dlesm_shallow_step_f64 / dlesm_shallow_step_sw_f64 (one launch), every bit, on even
+    and odd leading dimensions; and both == the oracle's step"""
+    import torch
+    g = _grid(D, nx, ny, alignment, sw_offset)
+    names, F = _state(D, g)
+    tdt = DT + DT
+    prm = D.psy.shallow_params(g.dx, g.dy, DT)
+    fused = [D.r2d_field(g, F[n].defined_on) for n in ("u", "v", "p")]
+    for f in fused + [F[n] for n in ("unew", "vnew", "pnew")]:
+        D.set_field(f, 9.0)
+    step = D.psy.invoke_shallow_step_sw if sw_offset else D.psy.invoke_shallow_step
+    step(prm, *[F[n] for n in names[:6]], *fused)
+    D.psy.invoke_shallow_kernel_sequence(tdt, *[F[n] for n in names[:6]], F["cu"], F["cv"], F["z"], F["h"],
+                                         F["unew"], F["vnew"], F["pnew"])
+    torch.cuda.synchronize()
+    it = F["p"].internal
+    H = {n: F[n].get_data() for n in names[:6]}
+    want = [np.full((g.ny, g.nx), 9.0) for _ in range(3)]
+    (O.sw_step_sw if sw_offset else O.sw_step)(prm, g.nx, it.box(), *[H[n] for n in names[:6]], *want)
+    for n, f, w in zip(("unew", "vnew", "pnew"), fused, want):
+        assert np.array_equal(F[n].get_data(), f.get_data()), (n, "sequence != fused")
+        assert np.array_equal(f.get_data(), w), (n, "fused != oracle")
+
+
+@pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW-periodic"])
+def test_seven_launches_equal_the_fused_step_at_8192(D, sw_offset):
+    """BASELINE configs[3]: 8192 x 8192, DL_ESM_ALIGNMENT = 64; compared on the device"""
+    import torch
+    g = _grid(D, 8192, 8192, 64, sw_offset)
+    names, F = _state(D, g)
+    prm = D.psy.shallow_params(g.dx, g.dy, DT)
+    fused = [D.r2d_field(g, F[n].defined_on) for n in ("u", "v", "p")]
+    for f in fused + [F[n] for n in ("unew", "vnew", "pnew")]:
+        D.set_field(f, 9.0)
+    step = D.psy.invoke_shallow_step_sw if sw_offset else D.psy.invoke_shallow_step
+    step(prm, *[F[n] for n in names[:6]], *fused)
+    D.psy.invoke_shallow_kernel_sequence(DT + DT, *[F[n] for n in names[:6]], F["cu"], F["cv"], F["z"], F["h"],
+                                         F["unew"], F["vnew"], F["pnew"])
+    torch.cuda.synchronize()
+    it = F["p"].internal
+    for n, f in zip(("unew", "vnew", "pnew"), fused):
+        assert bool(torch.equal(F[n].data, f.data)), n
+        inner = f.data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop]
+        assert bool(torch.isfinite(inner).all()) and not bool((inner == 9.0).any()), n
+
+
+@pytest.mark.parametrize("nx,ny,alignment", [(10, 10, None), (64, 48, 8), (300, 77, None)])
+def test_shallow_model_with_time_smoothing_against_the_oracle(D, nx, ny, alignment):
+    """the GOcean `shallow` time loop as the benchmark has it (SW offset, periodic): the seven kernels, the periodic
+    copies of the new level, time_smooth of the old level (Asselin filter), then u <- unew etc. by rotation -- four
+    steps, every field and halo, every bit, against the oracle running the same loop nest by loop nest"""
+    import torch
+    g = _grid(D, nx, ny, alignment, True)
+    names, F = _state(D, g)
+    for n in "uvp":                                    # the benchmark starts with old = current
+        D.copy_field(F[n], F[n + "old"])
+    tdt, alpha = DT + DT, 0.001
+    prm = N.Params(g.dx, g.dy, DT)
+    it = F["p"].internal.box()
+    xs, xe, ys, ye = it
+    torch.cuda.synchronize()
+    H = {n: F[n].get_data() for n in F}
+    cur, old, new = ["u", "v", "p"], ["uold", "vold", "pold"], ["unew", "vnew", "pnew"]
+    for step in range(4):
+        D.psy.invoke_shallow_kernel_sequence(tdt, *[F[n] for n in cur + old], F["cu"], F["cv"], F["z"], F["h"],
+                                             *[F[n] for n in new])
+        D.psy.apply_periodic_halos_multi([F[n] for n in new])
+        for c, nw, o in zip(cur, new, old):
+            D.psy.invoke_time_smooth(F[c], F[nw], F[o], alpha)
+        D.psy.apply_periodic_halos_multi([F[n] for n in old])
+        # the oracle, loop nest by loop nest
+        u, v, p = (H[n] for n in cur)
+        O.sw_kernel("cu", True, g.nx, it, H["cu"], [p, u])
+        O.sw_kernel("cv", True, g.nx, it, H["cv"], [p, v])
+        O.sw_kernel("z", True, g.nx, it, H["z"], [p, u, v], prm.fsdx, prm.fsdy)
+        O.sw_kernel("h", True, g.nx, it, H["h"], [p, u, v])
+        for n in ("cu", "cv", "z", "h"):
+            O.apply_periodic_halos(H[n], g.nx, it, 0, 0)
+        O.sw_kernel("unew", True, g.nx, it, H[new[0]], [H[old[0]], H["z"], H["cv"], H["h"]], prm.tdts8, prm.tdtsdx)
+        O.sw_kernel("vnew", True, g.nx, it, H[new[1]], [H[old[1]], H["z"], H["cu"], H["h"]], prm.tdts8, prm.tdtsdy)
+        O.sw_kernel("pnew", True, g.nx, it, H[new[2]], [H[old[2]], H["cu"], H["cv"]], prm.tdtsdx, prm.tdtsdy)
+        for n in new:
+            O.apply_periodic_halos(H[n], g.nx, it, 0, 0)
+        for c, nw, o in zip(cur, new, old):
+            O.sw_kernel("time_smooth", True, g.nx, it, H[o], [H[c], H[nw], H[o]], alpha)
+            O.apply_periodic_halos(H[o], g.nx, it, 0, 0)
+        torch.cuda.synchronize()
+        for n in new + old + ["cu", "cv", "z", "h"]:
+            got = F[n].get_data()
+            assert np.array_equal(got[:ye + 1, :xe + 1], H[n][:ye + 1, :xe + 1]), (step, n)
+        cur, old, new = new, old, cur                  # u <- unew; uold already holds the smoothed u; the former u buffers are free
+    assert np.all(np.isfinite(H[cur[2]][ys - 1:ye, xs - 1:xe]))

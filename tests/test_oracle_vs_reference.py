@@ -379,6 +379,73 @@ def test_sw_offset_step_against_independent_numpy(nx, ny, ld_extra):
         assert np.all(np.isfinite(got[0][ys - 1:ye, xs - 1:xe]))
 
 
+@pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW"])
+@pytest.mark.parametrize("name", O.SW_KERNELS)
+def test_each_shallow_kernel_against_independent_numpy(name, sw_offset):
+    """the GOcean shallow kernels ONE BY ONE (the per-kernel launch entries' checker, orc_sw_kernel: a PSy loop
+    nest around each compute_*_code) against the whole-array numpy expressions of tests/sw_numpy.py -- on
+    arbitrary input arrays (the intermediates a kernel takes are NOT derived from a state here), even and odd
+    leading dimensions, boxes that touch the array edge wherever the kernel's stencil allows it.  Bit for bit.
+    PARITY UNPINNED by the reference (no stencil there)."""
+    import sw_numpy as N
+    prm = N.Params(1.0e5, 0.7e5, 90.0)
+    s0, s1 = N.kernel_scalars(name, prm)
+    rw, re, rs, rn = N.KERNEL_RING[sw_offset][name]
+    for (ld, nyarr) in [(40, 31), (37, 12), (131, 9), (3, 3)]:
+        rng = np.random.default_rng(ld * 100 + nyarr + len(name))
+        ins = [rng.random((nyarr, ld)) + 0.5 for _ in range(N.KERNEL_NIN[name])]
+        tight = (1 + rw, ld - re, 1 + rs, nyarr - rn)                  # the largest box the stencil allows
+        boxes = [tight, (2, ld - 1, 2, nyarr - 1), (3, ld - 2, 3, nyarr - 2), (tight[0], tight[0], tight[2], tight[3]),
+                 (tight[0], tight[1], tight[3], tight[3]), (5, 4, 2, 3)]
+        for box in boxes:
+            if box[0] < tight[0] or box[1] > tight[1] or box[2] < tight[2] or box[3] > tight[3]:
+                continue
+            if name == "time_smooth":
+                got, want = ins[2].copy(), ins[2].copy()
+                O.sw_kernel(name, sw_offset, ld, box, got, [ins[0], ins[1], got], s0, s1)
+                N.kernel_numpy(name, sw_offset, prm, box, want, [ins[0], ins[1], want], alpha=s0)
+            else:
+                got, want = np.full((nyarr, ld), 9.0), np.full((nyarr, ld), 9.0)
+                O.sw_kernel(name, sw_offset, ld, box, got, ins, s0, s1)
+                N.kernel_numpy(name, sw_offset, prm, box, want, ins)
+            assert np.array_equal(got, want), (name, sw_offset, ld, nyarr, box)
+            xs, xe, ys, ye = box
+            if xe >= xs and ye >= ys and name != "time_smooth":
+                assert np.all(got[ys - 1:ye, xs - 1:xe] != 9.0)
+                got[ys - 1:ye, xs - 1:xe] = 9.0
+                assert np.all(got == 9.0)                               # nothing outside the box is written
+
+
+@pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW"])
+def test_kernel_sequence_equals_the_fused_oracle_step(sw_offset):
+    """the seven loop nests in the order a GOcean PSy layer runs them -- cu, cv, z, h over the box grown towards
+    their consumers, then unew, vnew, pnew over the box -- write what orc_sw_step / orc_sw_step_sw write"""
+    import sw_numpy as N
+    ld, nyarr, box = 45, 33, (2, 43, 2, 31)
+    xs, xe, ys, ye = box
+    rng = np.random.default_rng(7 + sw_offset)
+    prm = N.Params(1.0e5, 0.8e5, 90.0)
+    u, v, uold, vold = (rng.random((nyarr, ld)) - 0.5 for _ in range(4))
+    p, pold = (rng.random((nyarr, ld)) + 1.0 for _ in range(2))
+    want = [np.full((nyarr, ld), 9.0) for _ in range(3)]
+    (O.sw_step_sw if sw_offset else O.sw_step)(prm, ld, box, u, v, p, uold, vold, pold, *want)
+    cu, cv, z, h = (np.full((nyarr, ld), np.nan) for _ in range(4))
+    grown = {False: {"cu": (xs - 1, xe, ys, ye + 1), "cv": (xs, xe + 1, ys - 1, ye), "z": (xs - 1, xe, ys - 1, ye),
+                     "h": (xs, xe + 1, ys, ye + 1)},
+             True: {"cu": (xs, xe + 1, ys - 1, ye), "cv": (xs - 1, xe, ys, ye + 1), "z": (xs, xe + 1, ys, ye + 1),
+                    "h": (xs - 1, xe, ys - 1, ye)}}[sw_offset]
+    O.sw_kernel("cu", sw_offset, ld, grown["cu"], cu, [p, u])
+    O.sw_kernel("cv", sw_offset, ld, grown["cv"], cv, [p, v])
+    O.sw_kernel("z", sw_offset, ld, grown["z"], z, [p, u, v], prm.fsdx, prm.fsdy)
+    O.sw_kernel("h", sw_offset, ld, grown["h"], h, [p, u, v])
+    got = [np.full((nyarr, ld), 9.0) for _ in range(3)]
+    O.sw_kernel("unew", sw_offset, ld, box, got[0], [uold, z, cv, h], prm.tdts8, prm.tdtsdx)
+    O.sw_kernel("vnew", sw_offset, ld, box, got[1], [vold, z, cu, h], prm.tdts8, prm.tdtsdy)
+    O.sw_kernel("pnew", sw_offset, ld, box, got[2], [pold, cu, cv], prm.tdtsdx, prm.tdtsdy)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
 def test_periodic_sw_model_conserves_mass_and_is_translation_invariant():
     """properties of the periodic model (step + halo copies + rotation) that need no reference:
     (i) pnew - pold is a discrete divergence, so SUM(p) over the periodic domain returns to SUM(pold)
