@@ -112,6 +112,7 @@ def cpu_baseline(host_in, ld, box, budget_s):
 XT_ROWS = {2: 4, 3: 6, 4: 8, 5: 8, 6: 12, 7: 16, 8: 16}      # rows per wave tile the library picks per T
 TB_STEPS = 8                                                 # time steps per launch of the secondary legs
 SW_KERNEL = "shallow_tile<2,dpp,nt>"                            # what dlesm_shallow_step_f64 launches by default
+SW_DX, SW_DY, SW_DT = 1.0e5, 1.0e5, 90.0                      # frozen constants of the shallow-water legs
 WEAK_TILE = 8192                                             # the per-GPU tile BASELINE configs[4] names
 MIN_SECONDARY_LAUNCHES = 24                                  # every secondary leg times at least this many launches
 TRAFFIC_SOURCE = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with the "
@@ -192,6 +193,35 @@ def jacobi_config(D, torch, stream, tile, alignment, steps, warmup=10):
     return out
 
 
+def copy_ceiling(D, torch, stream, srcs, dsts, n_doubles, launches=MIN_SECONDARY_LAUNCHES):
+    """What a linear sweep with THIS many concurrent HBM streams reaches on THIS box, in THIS process: nread arrays
+    read once, nwrite arrays written once, nothing else (dlesm_stream_copy_f64: one 16-byte element per thread per
+    array, workgroups sweeping memory front to back), with default and with non-temporal stores.  The kernels'
+    `frac_of_copy_ceiling` is measured against the better of the two.  srcs / dsts: device tensors (clobbered: dsts)."""
+    L = D._cabi.lib()
+    nr, nw = len(srcs), len(dsts)
+    sp = (C.c_void_p * nr)(*[t.data_ptr() for t in srcs])
+    dp = (C.c_void_p * nw)(*[t.data_ptr() for t in dsts])
+    out = {"sweep": f"{nr} arrays read + {nw} written, {n_doubles * 8 / 1e6:.0f} MB each, linear, 16 B per thread per array",
+           "launches": launches}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for label, nt in (("default_stores", 0), ("nt_stores", 2)):
+        with torch.cuda.stream(stream):
+            for k in range(launches + 4):
+                if k == 4:
+                    e0.record(stream)
+                D._cabi.check(L.dlesm_stream_copy_f64(nr, nw, sp, dp, n_doubles, nt, C.c_void_p(stream.cuda_stream)))
+            e1.record(stream)
+        stream.synchronize()
+        ms = e0.elapsed_time(e1) / launches
+        gbs = 8.0 * (nr + nw) * n_doubles / (ms * 1e-3) / 1e9
+        out[label] = {"ms": round(ms, 5), "gbs": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        best = max(best, gbs)
+    out["best_gbs"] = round(best, 1)
+    return out
+
+
 def temporal_blocking(D, torch, grid, a, stream, steps, tile, T=TB_STEPS):
     """Secondary figure (never `value`): the same time steps advanced T per sweep by the fused
     kernel (dlesm_stencil5_multi_f64).  First T single steps and one fused launch from the same
@@ -236,7 +266,10 @@ def shallow_water(D, torch, stream, alignment, tile=8192, steps=40, cpu_seconds=
     GOcean kernel sequence (orc_sw_step, 1 core) on a 256-row slab of the same initial state, whose
     result rows must equal the GPU's bit for bit."""
     steps = max(steps, MIN_SECONDARY_LAUNCHES)
-    g = make_grid(D, tile, tile, alignment)
+    os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
+    g.decompose(tile, tile)
+    D.grid_init(g, SW_DX, SW_DY)            # the kernels' GO_GRID_DX_CONST / DY_CONST arguments come from the grid
     pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
     names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
     F = {}
@@ -245,7 +278,7 @@ def shallow_water(D, torch, stream, alignment, tile=8192, steps=40, cpu_seconds=
             F[name] = D.r2d_field(g, pts[name[0]])
             D.psy.hash_init(F[name], SEED + k, stream=stream)
             F[name].data.add_(1.0 if name[0] == "p" else -0.5)     # p in [1,2), u, v in [-0.5,0.5)
-    prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
+    prm = D.psy.shallow_params(SW_DX, SW_DY, SW_DT)
     it = F["p"].internal
     cur, old, new = [F["u"], F["v"], F["p"]], [F["uold"], F["vold"], F["pold"]], [F["unew"], F["vnew"], F["pnew"]]
     # slab kept for the CPU leg: inputs rows j0-1 .. j0+h, first-step outputs rows j0 .. j0+h-1 (1-based j0)
@@ -303,6 +336,17 @@ def shallow_water(D, torch, stream, alignment, tile=8192, steps=40, cpu_seconds=
                                          f"h, unew, vnew, pnew) on a {it.nx}x{h} slab of the same initial state: {n} "
                                          f"steps in {dt:.1f}s on 1 core",
                                "gpu_first_step_equals_oracle_on_slab": bool(same)}
+    # the ceiling of THIS stream count on this box, same arrays, same process: six arrays read + three written
+    try:
+        cc = copy_ceiling(D, torch, stream, [f.data for f in cur + old], [f.data for f in new], g.nx * g.ny)
+        out["copy_ceiling"] = cc
+        out["roofline"]["frac_of_copy_ceiling"] = round(gbs / cc["best_gbs"], 4)
+    except Exception as e:                                   # noqa: BLE001
+        out["copy_ceiling"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        out["unfused"] = shallow_water_unfused(D, torch, stream, g, F, prm, tile, steps, ms)
+    except Exception as e:                                   # noqa: BLE001
+        out["unfused"] = {"error": f"{type(e).__name__}: {e}"}
     del F, cur, old, new
     torch.cuda.empty_cache()
     try:
@@ -312,10 +356,99 @@ def shallow_water(D, torch, stream, alignment, tile=8192, steps=40, cpu_seconds=
     return out
 
 
+SW_KERNEL_BYTES = {"cu": 24, "cv": 24, "z": 32, "h": 32, "unew": 40, "vnew": 40, "pnew": 32}   # 8 B x (arrays read + 1)
+
+
+def shallow_water_unfused(D, torch, stream, g, F, prm, tile, steps, fused_ms):
+    """What an UNMODIFIED generated PSy layer gets: the same time step as seven launches, one per GOcean kernel
+    (compute_cu, cv, z, h, unew, vnew, pnew -- dlesm_compute_*_f64), every intermediate through HBM: 224 B/cell
+    algorithmic against 72 for the fused step.  The sequence must reproduce the fused step bit
+    for bit from the same state; then each kernel is timed on its own and the sequence as a whole."""
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    tdt = SW_DT + SW_DT
+    with torch.cuda.stream(stream):
+        for k, n in enumerate(names[:6]):                            # a sane state again (the ceiling sweeps wrote sums)
+            D.psy.hash_init(F[n], SEED + k, stream=stream)
+            F[n].data.add_(1.0 if n[0] == "p" else -0.5)
+        for n, pt in (("cu", D.GO_U_POINTS), ("cv", D.GO_V_POINTS), ("z", D.GO_F_POINTS), ("h", D.GO_T_POINTS)):
+            F[n] = D.r2d_field(g, pt)
+        chk = [D.r2d_field(g, F[n].defined_on) for n in ("u", "v", "p")]
+        for f in chk + [F[n] for n in names[6:]]:
+            D.set_field(f, 0.0, stream=stream)
+        D.psy.invoke_shallow_step(prm, *[F[n] for n in names[:6]], *chk, stream=stream)
+        D.psy.invoke_shallow_kernel_sequence(tdt, *[F[n] for n in names[:6]], F["cu"], F["cv"], F["z"], F["h"],
+                                             *[F[n] for n in names[6:]], stream=stream)
+    stream.synchronize()
+    same = all(bool(torch.equal(F[n].data, c.data)) for n, c in zip(names[6:], chk))
+    del chk
+    torch.cuda.empty_cache()
+    cells = tile * tile
+    xs, xe, ys, ye = F["p"].internal.box()
+    grown = {"cu": (xs - 1, xe, ys, ye + 1), "cv": (xs, xe + 1, ys - 1, ye), "z": (xs - 1, xe, ys - 1, ye),
+             "h": (xs, xe + 1, ys, ye + 1)}
+    P = D.psy
+    calls = {
+        "cu": lambda: P.invoke_compute_cu(F["cu"], F["p"], F["u"], grown["cu"], stream),
+        "cv": lambda: P.invoke_compute_cv(F["cv"], F["p"], F["v"], grown["cv"], stream),
+        "z": lambda: P.invoke_compute_z(F["z"], F["p"], F["u"], F["v"], grown["z"], stream),
+        "h": lambda: P.invoke_compute_h(F["h"], F["p"], F["u"], F["v"], grown["h"], stream),
+        "unew": lambda: P.invoke_compute_unew(F["unew"], F["uold"], F["z"], F["cv"], F["h"], tdt, None, stream),
+        "vnew": lambda: P.invoke_compute_vnew(F["vnew"], F["vold"], F["z"], F["cu"], F["h"], tdt, None, stream),
+        "pnew": lambda: P.invoke_compute_pnew(F["pnew"], F["pold"], F["cu"], F["cv"], tdt, None, stream),
+    }
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    per = {}
+    reps = max(10, steps // 2)
+    for name, fn in calls.items():
+        with torch.cuda.stream(stream):
+            for k in range(reps + 3):
+                if k == 3:
+                    e0.record(stream)
+                fn()
+            e1.record(stream)
+        stream.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gbs = SW_KERNEL_BYTES[name] * cells / (ms * 1e-3) / 1e9
+        per[name] = {"ms": round(ms, 5), "bytes_per_cell": SW_KERNEL_BYTES[name], "gbs": round(gbs, 1),
+                     "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    with torch.cuda.stream(stream):
+        for k in range(steps + 2):
+            if k == 2:
+                e0.record(stream)
+            P.invoke_shallow_kernel_sequence(tdt, *[F[n] for n in names[:6]], F["cu"], F["cv"], F["z"], F["h"],
+                                             *[F[n] for n in names[6:]], stream=stream)
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    gbs = 224 * cells / (ms * 1e-3) / 1e9
+    # time_smooth (the Asselin filter of the GOcean leapfrog, one launch per prognostic field): 3 read + 1 written
+    with torch.cuda.stream(stream):
+        for k in range(reps + 3):
+            if k == 3:
+                e0.record(stream)
+            P.invoke_time_smooth(F["u"], F["unew"], F["uold"], 0.001, None, stream)
+        e1.record(stream)
+    stream.synchronize()
+    ts = e0.elapsed_time(e1) / reps
+    return {"workload": f"the same step as SEVEN launches, one per GOcean kernel (what an unmodified generated PSy layer "
+                        f"runs), {tile}x{tile} fp64", "steps": steps,
+            "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),
+            "bit_identical_to_fused_step": same,
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_cell": 224,
+                         "algorithmic_bytes_per_launch_sequence": 224 * cells,
+                         "kernel": "swk_tile<compute_{cu,cv,z,h,unew,vnew,pnew}>"},
+            "per_kernel": per,
+            "time_smooth": {"ms": round(ts, 5), "bytes_per_cell": 32, "gbs": round(32 * cells / (ts * 1e-3) / 1e9, 1),
+                            "frac": round(32 * cells / (ts * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "fusion_speedup": round(ms / fused_ms, 3)}
+
+
 def shallow_water_periodic(D, torch, stream, alignment, tile, steps):
     """The same update in the configuration of the GOcean `shallow` benchmark: SW offset, periodic in
-    x and y (serial only in the reference).  A step = dlesm_shallow_step_sw_f64 + the periodic copies
-    of the three new fields (two launches) + leapfrog rotation."""
+    x and y (serial only in the reference).  A step = ONE launch, dlesm_shallow_step_sw_periodic_f64: the step
+    over the internal region whose edge tiles also write the periodic images of the three new fields (round 2:
+    the step + two copy launches), + leapfrog rotation."""
     os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
     g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_PERIODIC, D.GO_BC_PERIODIC, D.GO_BC_NONE), D.GO_OFFSET_SW)
     g.decompose(tile, tile)
@@ -336,10 +469,19 @@ def shallow_water_periodic(D, torch, stream, alignment, tile, steps):
 
     def step():
         nonlocal cur, old, new
-        D.psy.invoke_shallow_step_sw(prm, *cur, *old, *new, stream=stream)
-        D.psy.apply_periodic_halos_multi(new, stream=stream)
+        D.psy.invoke_shallow_step_sw_periodic(prm, *cur, *old, *new, stream=stream)
         old, cur, new = cur, new, old
 
+    # first: one step in the three-launch form must leave the same fields AND halos, bit for bit
+    chk = [D.r2d_field(g, f.defined_on) for f in new]
+    with torch.cuda.stream(stream):
+        D.psy.invoke_shallow_step_sw(prm, *cur, *old, *chk, stream=stream)
+        D.psy.apply_periodic_halos_multi(chk, stream=stream)
+        D.psy.invoke_shallow_step_sw_periodic(prm, *cur, *old, *new, stream=stream)
+    stream.synchronize()
+    same = all(bool(torch.equal(a.data[:tile + 2, :tile + 2], b.data[:tile + 2, :tile + 2])) for a, b in zip(new, chk))
+    del chk
+    torch.cuda.empty_cache()
     with torch.cuda.stream(stream):
         for _ in range(5):
             step()
@@ -357,7 +499,8 @@ def shallow_water_periodic(D, torch, stream, alignment, tile, steps):
            "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_cell": bpc,
-                        "kernel": "shallow_tile_sw<2,dpp,nt> + 2 x periodic_pair_k"},
+                        "kernel": "shallow_tile_sw<2,dpp,nt> with the periodic images stored by the edge tiles (one launch)"},
+           "one_launch_equals_step_plus_halo_copies": same,
            # pnew - pold is a discrete divergence: on the torus SUM(p) is conserved up to rounding
            "mass_drift_relative": abs(p1 - p0[(5 + steps) % 2]) / abs(p0[(5 + steps) % 2])}
     del F, cur, old, new
@@ -826,6 +969,15 @@ def main():
             bail(f"{type(e).__name__}: {e}", 4)              # the other ranks may be stuck in a collective
         dog.cancel()
     if world == 1 and secondary:
+        def headline_ceiling():
+            # one array read + one written, the headline's field shape, same process (two fresh arrays)
+            x, y = (torch.empty((grid.ny, grid.nx), dtype=torch.float64, device="cuda") for _ in range(2))
+            x.copy_(a.data)
+            cc = copy_ceiling(D, torch, stream, [x], [y], grid.nx * grid.ny)
+            out["roofline"]["frac_of_copy_ceiling"] = round(achieved / cc["best_gbs"], 4)
+            return cc
+        guarded("copy_ceiling", headline_ceiling)
+        torch.cuda.empty_cache()
         if not args.no_shallow:
             guarded("shallow_water", lambda: shallow_water(
                 D, torch, stream, args.alignment, tile=min(8192, args.tile), steps=min(40, args.steps),

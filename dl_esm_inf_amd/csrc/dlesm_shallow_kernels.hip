@@ -15,10 +15,12 @@
 //
 // Every kernel is one instance of the same wave-tile sweep the other kernels use: 64 lanes x 2
 // doubles (16-byte lanes, 1 KiB of a row per wave) x R rows, tiles numbered row-major so that
-// workgroups -- dispatched in index order -- sweep memory linearly.  A kernel that reads a west or
-// east neighbour gives up one lane on that side as a halo lane (it loads, feeds its neighbour through
-// a wave shift on the VALU, and stores nothing), so there are no scattered edge loads; south / north
-// operands come from the extra row loaded below / above the tile.  A kernel is written ONCE, as an
+// workgroups -- dispatched in index order -- sweep memory linearly.  West / east operands come from the
+// neighbouring lane through a wave shift on the VALU; the one column a wave cannot get from its own lanes
+// is fetched by lane 0 / lane 63 (one 8-byte load per row of the arrays that need it, an L1/L2 hit), so
+// that all 64 lanes store and every wave tile covers whole 128-byte lines -- measured against tiles that
+// give up a halo lane per side (62/63 output lanes, tile edges inside a line): cu 69.0 -> see DESIGN 6.3.
+// South / north operands come from the extra row loaded below / above the tile.  A kernel is written ONCE, as an
 // expression over an accessor `at<array, di, dj>()`: the tile sweep instantiates it on register rows
 // (two columns at a time), the one-cell-per-thread form for odd leading dimensions on memory.
 #include "dlesm_internal.h"
@@ -52,18 +54,21 @@ struct KArgs {
 struct CuNE {   // cu(i,j) = 0.5*(p(i+1,j)+p(i,j))*u(i,j)                     in: p, u
     static constexpr int NIN = 2;
     static constexpr bool W = false, E = true, S = false, N = false;
+    static constexpr int EW[4] = {2, 0, 0, 0};
     static constexpr int RS[4] = {0, 0, 0, 0}, RN[4] = {0, 0, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double, double) { return 0.5 * (AT(0, 1, 0) + AT(0, 0, 0)) * AT(1, 0, 0); }
 };
 struct CvNE {   // cv(i,j) = 0.5*(p(i,j+1)+p(i,j))*v(i,j)                     in: p, v
     static constexpr int NIN = 2;
     static constexpr bool W = false, E = false, S = false, N = true;
+    static constexpr int EW[4] = {0, 0, 0, 0};
     static constexpr int RS[4] = {0, 0, 0, 0}, RN[4] = {1, 0, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double, double) { return 0.5 * (AT(0, 0, 1) + AT(0, 0, 0)) * AT(1, 0, 0); }
 };
 struct ZNE {    // z(i,j) = (fsdx*(v(i+1,j)-v(i,j)) - fsdy*(u(i,j+1)-u(i,j))) / (p(i,j)+p(i+1,j)+p(i+1,j+1)+p(i,j+1))   in: p, u, v
     static constexpr int NIN = 3;
     static constexpr bool W = false, E = true, S = false, N = true;
+    static constexpr int EW[4] = {2, 0, 2, 0};
     static constexpr int RS[4] = {0, 0, 0, 0}, RN[4] = {1, 1, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double fsdx, double fsdy)
     {
@@ -74,6 +79,7 @@ struct ZNE {    // z(i,j) = (fsdx*(v(i+1,j)-v(i,j)) - fsdy*(u(i,j+1)-u(i,j))) / 
 struct HNE {    // h(i,j) = p(i,j) + 0.25*(u(i,j)^2 + u(i-1,j)^2 + v(i,j)^2 + v(i,j-1)^2)            in: p, u, v
     static constexpr int NIN = 3;
     static constexpr bool W = true, E = false, S = true, N = false;
+    static constexpr int EW[4] = {0, 1, 0, 0};
     static constexpr int RS[4] = {0, 0, 1, 0}, RN[4] = {0, 0, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double, double)
     {
@@ -84,6 +90,7 @@ struct HNE {    // h(i,j) = p(i,j) + 0.25*(u(i,j)^2 + u(i-1,j)^2 + v(i,j)^2 + v(
 struct UnewNE { // unew = uold + tdts8*(z(i,j)+z(i,j-1))*(cv(i+1,j)+cv(i,j)+cv(i,j-1)+cv(i+1,j-1)) - tdtsdx*(h(i+1,j)-h(i,j))   in: uold, z, cv, h
     static constexpr int NIN = 4;
     static constexpr bool W = false, E = true, S = true, N = false;
+    static constexpr int EW[4] = {0, 0, 2, 2};
     static constexpr int RS[4] = {0, 1, 1, 0}, RN[4] = {0, 0, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double tdts8, double tdtsdx)
     {
@@ -94,6 +101,7 @@ struct UnewNE { // unew = uold + tdts8*(z(i,j)+z(i,j-1))*(cv(i+1,j)+cv(i,j)+cv(i
 struct VnewNE { // vnew = vold - tdts8*(z(i,j)+z(i-1,j))*(cu(i,j+1)+cu(i-1,j+1)+cu(i-1,j)+cu(i,j)) - tdtsdy*(h(i,j+1)-h(i,j))   in: vold, z, cu, h
     static constexpr int NIN = 4;
     static constexpr bool W = true, E = false, S = false, N = true;
+    static constexpr int EW[4] = {0, 1, 1, 0};
     static constexpr int RS[4] = {0, 0, 0, 0}, RN[4] = {0, 0, 1, 1};
     template <class A> __device__ static auto eval(const A &t, double tdts8, double tdtsdy)
     {
@@ -104,6 +112,7 @@ struct VnewNE { // vnew = vold - tdts8*(z(i,j)+z(i-1,j))*(cu(i,j+1)+cu(i-1,j+1)+
 struct PnewNE { // pnew = pold - tdtsdx*(cu(i,j)-cu(i-1,j)) - tdtsdy*(cv(i,j)-cv(i,j-1))             in: pold, cu, cv
     static constexpr int NIN = 3;
     static constexpr bool W = true, E = false, S = true, N = false;
+    static constexpr int EW[4] = {0, 1, 0, 0};
     static constexpr int RS[4] = {0, 0, 1, 0}, RN[4] = {0, 0, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double tdtsdx, double tdtsdy)
     {
@@ -115,18 +124,21 @@ struct PnewNE { // pnew = pold - tdtsdx*(cu(i,j)-cu(i-1,j)) - tdtsdy*(cv(i,j)-cv
 struct CuSW {   // cu(i,j) = 0.5*(p(i,j)+p(i-1,j))*u(i,j)
     static constexpr int NIN = 2;
     static constexpr bool W = true, E = false, S = false, N = false;
+    static constexpr int EW[4] = {1, 0, 0, 0};
     static constexpr int RS[4] = {0, 0, 0, 0}, RN[4] = {0, 0, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double, double) { return 0.5 * (AT(0, 0, 0) + AT(0, -1, 0)) * AT(1, 0, 0); }
 };
 struct CvSW {   // cv(i,j) = 0.5*(p(i,j)+p(i,j-1))*v(i,j)
     static constexpr int NIN = 2;
     static constexpr bool W = false, E = false, S = true, N = false;
+    static constexpr int EW[4] = {0, 0, 0, 0};
     static constexpr int RS[4] = {1, 0, 0, 0}, RN[4] = {0, 0, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double, double) { return 0.5 * (AT(0, 0, 0) + AT(0, 0, -1)) * AT(1, 0, 0); }
 };
 struct ZSW {    // z(i,j) = (fsdx*(v(i,j)-v(i-1,j)) - fsdy*(u(i,j)-u(i,j-1))) / (p(i-1,j-1)+p(i,j-1)+p(i,j)+p(i-1,j))
     static constexpr int NIN = 3;
     static constexpr bool W = true, E = false, S = true, N = false;
+    static constexpr int EW[4] = {1, 0, 1, 0};
     static constexpr int RS[4] = {1, 1, 0, 0}, RN[4] = {0, 0, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double fsdx, double fsdy)
     {
@@ -137,6 +149,7 @@ struct ZSW {    // z(i,j) = (fsdx*(v(i,j)-v(i-1,j)) - fsdy*(u(i,j)-u(i,j-1))) / 
 struct HSW {    // h(i,j) = p(i,j) + 0.25*(u(i+1,j)^2 + u(i,j)^2 + v(i,j+1)^2 + v(i,j)^2)
     static constexpr int NIN = 3;
     static constexpr bool W = false, E = true, S = false, N = true;
+    static constexpr int EW[4] = {0, 2, 0, 0};
     static constexpr int RS[4] = {0, 0, 0, 0}, RN[4] = {0, 0, 1, 0};
     template <class A> __device__ static auto eval(const A &t, double, double)
     {
@@ -147,6 +160,7 @@ struct HSW {    // h(i,j) = p(i,j) + 0.25*(u(i+1,j)^2 + u(i,j)^2 + v(i,j+1)^2 + 
 struct UnewSW { // unew = uold + tdts8*(z(i,j+1)+z(i,j))*(cv(i,j+1)+cv(i-1,j+1)+cv(i-1,j)+cv(i,j)) - tdtsdx*(h(i,j)-h(i-1,j))
     static constexpr int NIN = 4;
     static constexpr bool W = true, E = false, S = false, N = true;
+    static constexpr int EW[4] = {0, 0, 1, 1};
     static constexpr int RS[4] = {0, 0, 0, 0}, RN[4] = {0, 1, 1, 0};
     template <class A> __device__ static auto eval(const A &t, double tdts8, double tdtsdx)
     {
@@ -157,6 +171,7 @@ struct UnewSW { // unew = uold + tdts8*(z(i,j+1)+z(i,j))*(cv(i,j+1)+cv(i-1,j+1)+
 struct VnewSW { // vnew = vold - tdts8*(z(i+1,j)+z(i,j))*(cu(i+1,j)+cu(i,j)+cu(i,j-1)+cu(i+1,j-1)) - tdtsdy*(h(i,j)-h(i,j-1))
     static constexpr int NIN = 4;
     static constexpr bool W = false, E = true, S = true, N = false;
+    static constexpr int EW[4] = {0, 2, 2, 0};
     static constexpr int RS[4] = {0, 0, 1, 1}, RN[4] = {0, 0, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double tdts8, double tdtsdy)
     {
@@ -167,6 +182,7 @@ struct VnewSW { // vnew = vold - tdts8*(z(i+1,j)+z(i,j))*(cu(i+1,j)+cu(i,j)+cu(i
 struct PnewSW { // pnew = pold - tdtsdx*(cu(i+1,j)-cu(i,j)) - tdtsdy*(cv(i,j+1)-cv(i,j))
     static constexpr int NIN = 3;
     static constexpr bool W = false, E = true, S = false, N = true;
+    static constexpr int EW[4] = {0, 2, 0, 0};
     static constexpr int RS[4] = {0, 0, 0, 0}, RN[4] = {0, 0, 1, 0};
     template <class A> __device__ static auto eval(const A &t, double tdtsdx, double tdtsdy)
     {
@@ -178,6 +194,7 @@ struct PnewSW { // pnew = pold - tdtsdx*(cu(i+1,j)-cu(i,j)) - tdtsdy*(cv(i,j+1)-
 struct TimeSmooth {
     static constexpr int NIN = 3;
     static constexpr bool W = false, E = false, S = false, N = false;
+    static constexpr int EW[4] = {0, 0, 0, 0};
     static constexpr int RS[4] = {0, 0, 0, 0}, RN[4] = {0, 0, 0, 0};
     template <class A> __device__ static auto eval(const A &t, double alpha, double)
     {
@@ -187,16 +204,24 @@ struct TimeSmooth {
 #undef AT
 
 // ---- accessor over the register rows of a wave tile: row index k = row jb-1+k -----------------------
+// edge[a][k]: the value of array a in row k one column WEST of lane 0's chunk (held by lane 0) or one column EAST
+// of lane 63's chunk (held by lane 63) -- what the wave shift cannot deliver to those two lanes
 template <int NIN, int R>
 struct TileAcc {
     const V2 (&rows)[NIN][R + 2];
-    int k;
+    const double (&edge)[NIN][R + 2];
+    int k, lane;
     template <int a, int di, int dj> __device__ __forceinline__ V2 at() const
     {
         const V2 &r = rows[a][k + dj];
         if constexpr (di == 0) return r;
-        else if constexpr (di > 0) return V2{r.y, from_upper<true>(r.x)};      // (i+1): own east column, the next lane's west one
-        else return V2{from_lower<true>(r.y), r.x};                            // (i-1)
+        else if constexpr (di > 0) {       // (i+1): own east column, the next lane's west one
+            const double up = from_upper<true>(r.x);
+            return V2{r.y, lane == 63 ? edge[a][k + dj] : up};
+        } else {                           // (i-1)
+            const double lo = from_lower<true>(r.y);
+            return V2{lane == 0 ? edge[a][k + dj] : lo, r.x};
+        }
     }
 };
 // ---- accessor over memory, one cell ----------------------------------------------------------------
@@ -210,7 +235,6 @@ struct CellAcc {
 template <class K, int R, bool NT>
 __global__ __launch_bounds__(512) void swk_tile(KArgs a, int ld, int x0, int x1, int y0, int y1, int cb, int nxw)
 {
-    constexpr int HW = K::W ? 1 : 0, HE = K::E ? 1 : 0, NOUT = 64 - HW - HE;
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int xw = w % nxw, strip = w / nxw;
@@ -218,16 +242,19 @@ __global__ __launch_bounds__(512) void swk_tile(KArgs a, int ld, int x0, int x1,
     if (jb > y1) return;
     int je = jb + R - 1;
     if (je > y1) je = y1;
-    const int c = cb + xw * NOUT - HW + lane;          // this lane's chunk (2 columns)
-    if (c - lane + HW > x1 / 2) return;                // idle padding tile
+    const int c = cb + xw * 64 + lane;                 // this lane's chunk (2 columns)
+    if (c - lane > x1 / 2) return;                     // idle padding tile
     const int c_ld = ld / 2 - 1;
-    const int cl = c < 0 ? 0 : (c > c_ld ? c_ld : c);  // halo / trailing lanes: any valid chunk
-    const bool out_lane = lane >= HW && lane <= 63 - HE && c <= c_ld;
-    const bool m0 = out_lane && 2 * c >= x0 && 2 * c <= x1;
-    const bool m1 = out_lane && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
+    const int cl = c > c_ld ? c_ld : c;                // trailing lanes: any valid chunk
+    const bool m0 = c <= c_ld && 2 * c >= x0 && 2 * c <= x1;
+    const bool m1 = c <= c_ld && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
     const size_t col = (size_t)cl * 2;
+    // the column outside the wave: west of lane 0 / east of lane 63 (clamped into the row; a clamped value is only
+    // ever combined into cells outside the box)
+    const int ecol = lane == 0 ? (2 * c - 1 < 0 ? 0 : 2 * c - 1) : (2 * c + 2 > ld - 1 ? ld - 1 : 2 * c + 2);
 
     V2 rows[K::NIN][R + 2];
+    double edge[K::NIN][R + 2];
 #pragma unroll
     for (int n = 0; n < K::NIN; n++) {
 #pragma unroll
@@ -236,13 +263,16 @@ __global__ __launch_bounds__(512) void swk_tile(KArgs a, int ld, int x0, int x1,
             if (jj > je + K::RN[n]) jj = je + K::RN[n];
             const d2 v = *(const d2 *)(a.in[n] + (size_t)jj * ld + col);
             rows[n][k] = V2{v.x, v.y};
+            edge[n][k] = 0.0;
+            if ((K::EW[n] & 1) && lane == 0) edge[n][k] = a.in[n][(size_t)jj * ld + ecol];
+            if ((K::EW[n] & 2) && lane == 63) edge[n][k] = a.in[n][(size_t)jj * ld + ecol];
         }
     }
 #pragma unroll
     for (int k = 1; k <= R; k++) {
         const int jj = jb - 1 + k;
         if (jj > je) break;
-        const V2 r = K::eval(TileAcc<K::NIN, R>{rows, k}, a.s0, a.s1);
+        const V2 r = K::eval(TileAcc<K::NIN, R>{rows, edge, k, lane}, a.s0, a.s1);
         double *po = a.out + (size_t)jj * ld + (size_t)c * 2;
         if (m0 && m1) {
             if constexpr (NT) __builtin_nontemporal_store(d2{r.x, r.y}, (d2 *)po);
@@ -292,14 +322,22 @@ int launch_kernel(const char *who, const KArgs &a, int ld, int ny, int xstart, i
     const int nx = x1 - x0 + 1, h = y1 - y0 + 1;
     const bool thin = nx <= tuning("sw_thin_box", 8) && h > 8;
     if (aligned && !thin && tuning("swk_kernel", 0) == 0) {
-        constexpr int R = 2, NOUT = 64 - (K::W ? 1 : 0) - (K::E ? 1 : 0);
+        constexpr int R = 2;
         const int cb = (x0 / 2) & ~7, c_last = x1 / 2;        // tiles anchored on 128-byte lines of the row
-        int nxw = (c_last - cb + NOUT) / NOUT, tpb = 4;
-        choose_block_shape(&nxw, &tpb);
+        int nxw = (c_last - cb + 64) / 64, tpb = 4;
+        // 4 waves per group, a quarter of a group past / short of a multiple of 8 groups per row: measured at 8192^2
+        // (scripts/shallow_r3_probe.py --what kernels,shapes: 65 tiles per row) every kernel of the set is fastest at
+        // 4 waves x 65 tiles (16.25 groups per row), 1-2 points above 8 waves x 66 tiles, the Jacobi rule's choice
+        choose_block_shape(&nxw, &tpb, 4);
         if (tpb > 8) tpb = 8;                                  // the kernel is bounded to 512 threads
         const int strips = (h + R - 1) / R;
         const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
-        if (nt_stores_for(ld, y0, y1))
+        // store policy: as the other sweeps, non-temporal once the arrays outgrow the Infinity Cache -- except for a
+        // kernel that updates an array in place (time_smooth): the line it writes is the line it has just read
+        bool in_place = false;
+        for (int n = 0; n < K::NIN; n++) in_place = in_place || (const double *)a.out == a.in[n];
+        const int key = tuning("swk_nt", -1);
+        if (key >= 0 ? key != 0 : (nt_stores_for(ld, y0, y1) && !in_place))
             hipLaunchKernelGGL((swk_tile<K, R, true>), dim3(grid), dim3(64 * tpb), 0, s, a, ld, x0, x1, y0, y1, cb, nxw);
         else
             hipLaunchKernelGGL((swk_tile<K, R, false>), dim3(grid), dim3(64 * tpb), 0, s, a, ld, x0, x1, y0, y1, cb, nxw);

@@ -155,18 +155,33 @@ def main():
             "time_smooth": (32, lambda: L.dlesm_time_smooth_f64(ld, ny, xs, xe, ys, ye, 0.001, P["u"], P["unew"], P["uold"], sp)),
         }
         with torch.cuda.stream(s):
+          for swk_nt in (0, 1, -1):
+            tune(swk_nt=swk_nt)
             total = 0.0
             for name, (bytes_per_cell, fn) in calls.items():
                 def go():
                     D._cabi.check(fn())
                 ms = timed(go, args.steps)
                 gbs = bytes_per_cell * cells / ms / 1e6
-                out[name] = {"ms": ms, "bytes_per_cell": bytes_per_cell, "gbs": gbs, "frac": gbs / 8000.0}
+                out[name + ("" if swk_nt < 0 else f" swk_nt={swk_nt}")] = {"ms": ms, "bytes_per_cell": bytes_per_cell, "gbs": gbs, "frac": gbs / 8000.0}
                 if name != "time_smooth":
                     total += ms
-                print(f"kernel {name:12s}: {ms:.4f} ms  {bytes_per_cell} B/cell  {gbs:7.0f} GB/s  {gbs / 80:.2f} %", flush=True)
+                print(f"kernel {name:12s} swk_nt={swk_nt:2d}: {ms:.4f} ms  {bytes_per_cell} B/cell  {gbs:7.0f} GB/s  {gbs / 80:.2f} %", flush=True)
 
-            def seq():
+            if "shapes" in what:      # launch-shape landscape of each kernel: waves per group x padding tiles per row
+                tune(j5_autoshape=0)
+                for name, (bytes_per_cell, fn) in calls.items():
+                    line = []
+                    for tpb in (4, 8):
+                        for pad in range(0, 6):
+                            tune(j5_tpb=tpb, j5_pad_tiles=pad)
+                            ms = timed(lambda: D._cabi.check(fn()), 10)
+                            line.append(f"{tpb}/{65 + pad}:{bytes_per_cell * cells / ms / 1e6 / 80:.1f}")
+                            out[f"shape {name} tpb={tpb} nxw={65 + pad}"] = ms
+                    print(f"shapes {name:12s} " + " ".join(line), flush=True)
+                tune(j5_autoshape=1, j5_tpb=0, j5_pad_tiles=0)
+
+            def seq():   # (default store policy: the last pass above)
                 D.psy.invoke_shallow_kernel_sequence(tdt, *[F[n] for n in names9[:6]], F["cu"], F["cv"], F["z"], F["h"],
                                                      F["unew"], F["vnew"], F["pnew"], stream=s)
             ms = timed(seq, max(4, args.steps // 4))

@@ -40,6 +40,13 @@ def test_bench_line_and_secondary_legs():
     sw = d["shallow_water"]
     assert "error" not in sw and sw["value"] > 0 and sw["roofline"]["algorithmic_bytes_per_cell"] == 72, sw
     assert sw["cpu_baseline"]["gpu_first_step_equals_oracle_on_slab"] is True and sw["cpu_baseline"]["cores"] == 1, sw
+    # round 3: the un-fused GOcean kernel sequence beside the fused step, the same-run copy ceilings, one-launch periodic step
+    un = sw["unfused"]
+    assert "error" not in un and un["bit_identical_to_fused_step"] is True and un["roofline"]["algorithmic_bytes_per_cell"] == 224, un
+    assert set(un["per_kernel"]) == {"cu", "cv", "z", "h", "unew", "vnew", "pnew"} and un["time_smooth"]["ms"] > 0, un
+    assert sw["copy_ceiling"]["best_gbs"] > 0 and 0 < sw["roofline"]["frac_of_copy_ceiling"] < 2, sw
+    assert sw["sw_offset_periodic"]["one_launch_equals_step_plus_halo_copies"] is True, sw["sw_offset_periodic"]
+    assert d["copy_ceiling"]["best_gbs"] > 0 and 0 < d["roofline"]["frac_of_copy_ceiling"] < 2, d["copy_ceiling"]
     tb = d["temporal_blocking"]
     assert tb["fused_steps"] == 8 and tb["bit_identical_to_single_steps"] is True and tb["value"] > 0
     assert tb["steps"] >= 24 * 8                       # secondary legs time >= 24 launches whatever --steps is
