@@ -118,6 +118,7 @@ PROTOTYPES = {
     "dlesm_stencil5_multi_f64": (_i, [_vp, _vp] + [_i] * 15 + [_vp]),
     "dlesm_shallow_step_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_shallow_autotune_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
+    "dlesm_shallow_autotune_sw_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_compute_cu_f64": (_i, [_i] * 7 + [_vp] * 3 + [_vp]),
     "dlesm_compute_cv_f64": (_i, [_i] * 7 + [_vp] * 3 + [_vp]),
     "dlesm_compute_z_f64": (_i, [_i] * 7 + [_d, _d] + [_vp] * 4 + [_vp]),

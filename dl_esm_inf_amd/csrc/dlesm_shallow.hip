@@ -447,8 +447,8 @@ __global__ __launch_bounds__(512) void shallow_tile_sw(
 // cache policy computes the same bits, so the fastest for a given (leading dimension, box) is
 // simply timed once and remembered.
 struct SwKey {
-    int ld, x0, x1, y0, y1;
-    bool operator<(const SwKey &o) const { return std::tie(ld, x0, x1, y0, y1) < std::tie(o.ld, o.x0, o.x1, o.y0, o.y1); }
+    int ld, x0, x1, y0, y1, sw;       // sw: 1 = the SW-offset kernel (its own landscape)
+    bool operator<(const SwKey &o) const { return std::tie(ld, x0, x1, y0, y1, sw) < std::tie(o.ld, o.x0, o.x1, o.y0, o.y1, o.sw); }
 };
 struct SwShape { int tpb, nxw, ntm; };
 static std::mutex g_sw_mu;
@@ -500,7 +500,7 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & 15;
     {
         std::lock_guard<std::mutex> lk(g_sw_mu);
-        auto it = g_sw_cache.find(SwKey{ld, x0, x1, y0, y1});
+        auto it = g_sw_cache.find(SwKey{ld, x0, x1, y0, y1, sw_offset ? 1 : 0});
         if (g_sw_override.tpb) { tpb = g_sw_override.tpb; nxw = g_sw_override.nxw; ntm = g_sw_override.ntm; }
         else if (it != g_sw_cache.end() && tuning("j5_use_tuned", 1)) { tpb = it->second.tpb; nxw = it->second.nxw; ntm = it->second.ntm; }
         else sw_rule_shape(ld, x0, x1, &nxw, &tpb);
@@ -773,16 +773,22 @@ extern "C" int dlesm_periodic_halos_apply_f64(double *field, int ld, int ny, con
     return dlesm_periodic_halos_apply_multi_f64(one, 1, ld, ny, internal, bc_x, bc_y, stream);
 }
 
-extern "C" int dlesm_shallow_autotune_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop,
-                                          int ystart, int ystop, const double *u, const double *v,
-                                          const double *p, const double *uold, const double *vold,
-                                          const double *pold, double *unew, double *vnew, double *pnew,
-                                          void *stream)
+static int shallow_autotune(bool sw_offset, const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop,
+                            int ystart, int ystop, const double *u, const double *v,
+                            const double *p, const double *uold, const double *vold,
+                            const double *pold, double *unew, double *vnew, double *pnew,
+                            void *stream)
 {
     // the step itself validates the arguments, warms the clocks, and tells whether the tile kernel applies
-    if (int rc = dlesm_shallow_step_f64(q, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, unew,
-                                        vnew, pnew, stream))
+    if (int rc = (sw_offset ? dlesm_shallow_step_sw_f64 : dlesm_shallow_step_f64)(q, ld, ny, xstart, xstop, ystart, ystop, u, v, p,
+                                                                                  uold, vold, pold, unew, vnew, pnew, stream))
         return rc;
+    {   // arrays the step sent to the one-cell-per-thread form have no shapes to choose from
+        bool aligned = ld % 2 == 0 || (xstop - 1) + 1 <= 2 * (ld / 2) - 1;
+        for (const double *f : {u, v, p, uold, vold, pold, (const double *)unew, (const double *)vnew, (const double *)pnew})
+            aligned = aligned && ((uintptr_t)f % 16 == 0);
+        if (!aligned) return DLESM_OK;
+    }
     if (xstop < xstart || ystop < ystart || tuning("sw_kernel", 0) != 0) return DLESM_OK;
     const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
     const int nxw0 = (x1 / 2 - sw_first_chunk(x0) + 62) / 62;
@@ -823,7 +829,7 @@ extern "C" int dlesm_shallow_autotune_f64(const dlesm_sw_params *q, int ld, int 
                 { std::lock_guard<std::mutex> lk(g_sw_mu); g_sw_override = c; }
                 (void)hipEventRecord(e0, s);
                 for (int rep = 0; rep < 3; rep++)
-                    launch_shallow_tile(*q, ld, x0, x1, y0, y1, u, v, p, uold, vold, pold, unew, vnew, pnew, s, false);
+                    launch_shallow_tile(*q, ld, x0, x1, y0, y1, u, v, p, uold, vold, pold, unew, vnew, pnew, s, sw_offset);
                 (void)hipEventRecord(e1, s);
                 { std::lock_guard<std::mutex> lk(g_sw_mu); g_sw_override = SwShape{0, 0, 0}; }
                 if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess)
@@ -854,6 +860,22 @@ extern "C" int dlesm_shallow_autotune_f64(const dlesm_sw_params *q, int ld, int 
     (void)hipEventDestroy(e1);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_sw_mu);
-    g_sw_cache[SwKey{ld, x0, x1, y0, y1}] = best;
+    g_sw_cache[SwKey{ld, x0, x1, y0, y1, sw_offset ? 1 : 0}] = best;
     return DLESM_OK;
+}
+
+extern "C" int dlesm_shallow_autotune_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop, int ystart,
+                                          int ystop, const double *u, const double *v, const double *p, const double *uold,
+                                          const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
+                                          void *stream)
+{
+    return shallow_autotune(false, q, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, unew, vnew, pnew, stream);
+}
+
+extern "C" int dlesm_shallow_autotune_sw_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop, int ystart,
+                                             int ystop, const double *u, const double *v, const double *p, const double *uold,
+                                             const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
+                                             void *stream)
+{
+    return shallow_autotune(true, q, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, unew, vnew, pnew, stream);
 }

@@ -206,6 +206,85 @@ module dlesm_hip_mod
        type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
        integer(c_int) :: rc
      end function
+     function dlesm_shallow_step_sw_periodic_f64(params, ld, ny, internal, bc_x, bc_y, u, v, p, &
+          uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_step_sw_periodic_f64") result(rc)
+       import :: c_int, c_ptr, c_sw_params, c_region
+       type(c_sw_params), intent(in) :: params
+       integer(c_int), value :: ld, ny, bc_x, bc_y
+       type(c_region), intent(in) :: internal
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_shallow_autotune_sw_f64(params, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
+          uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_autotune_sw_f64") result(rc)
+       import :: c_int, c_ptr, c_sw_params
+       type(c_sw_params), intent(in) :: params
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
+       integer(c_int) :: rc
+     end function
+     ! the GOcean `shallow` kernels one by one (one launch per PSy loop nest); arrays in the kernels' own order
+     function dlesm_compute_cu_f64(offset, ld, ny, xstart, xstop, ystart, ystop, cu, p, u, stream) &
+          bind(C, name="dlesm_compute_cu_f64") result(rc)
+       import :: c_int, c_ptr
+       integer(c_int), value :: offset, ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: cu, p, u, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_compute_cv_f64(offset, ld, ny, xstart, xstop, ystart, ystop, cv, p, v, stream) &
+          bind(C, name="dlesm_compute_cv_f64") result(rc)
+       import :: c_int, c_ptr
+       integer(c_int), value :: offset, ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: cv, p, v, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_compute_z_f64(offset, ld, ny, xstart, xstop, ystart, ystop, fsdx, fsdy, z, p, u, v, stream) &
+          bind(C, name="dlesm_compute_z_f64") result(rc)
+       import :: c_int, c_ptr, c_double
+       integer(c_int), value :: offset, ld, ny, xstart, xstop, ystart, ystop
+       real(c_double), value :: fsdx, fsdy
+       type(c_ptr), value :: z, p, u, v, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_compute_h_f64(offset, ld, ny, xstart, xstop, ystart, ystop, h, p, u, v, stream) &
+          bind(C, name="dlesm_compute_h_f64") result(rc)
+       import :: c_int, c_ptr
+       integer(c_int), value :: offset, ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: h, p, u, v, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_compute_unew_f64(offset, ld, ny, xstart, xstop, ystart, ystop, tdts8, tdtsdx, unew, uold, z, cv, &
+          h, stream) bind(C, name="dlesm_compute_unew_f64") result(rc)
+       import :: c_int, c_ptr, c_double
+       integer(c_int), value :: offset, ld, ny, xstart, xstop, ystart, ystop
+       real(c_double), value :: tdts8, tdtsdx
+       type(c_ptr), value :: unew, uold, z, cv, h, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_compute_vnew_f64(offset, ld, ny, xstart, xstop, ystart, ystop, tdts8, tdtsdy, vnew, vold, z, cu, &
+          h, stream) bind(C, name="dlesm_compute_vnew_f64") result(rc)
+       import :: c_int, c_ptr, c_double
+       integer(c_int), value :: offset, ld, ny, xstart, xstop, ystart, ystop
+       real(c_double), value :: tdts8, tdtsdy
+       type(c_ptr), value :: vnew, vold, z, cu, h, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_compute_pnew_f64(offset, ld, ny, xstart, xstop, ystart, ystop, tdtsdx, tdtsdy, pnew, pold, cu, cv, &
+          stream) bind(C, name="dlesm_compute_pnew_f64") result(rc)
+       import :: c_int, c_ptr, c_double
+       integer(c_int), value :: offset, ld, ny, xstart, xstop, ystart, ystop
+       real(c_double), value :: tdtsdx, tdtsdy
+       type(c_ptr), value :: pnew, pold, cu, cv, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_time_smooth_f64(ld, ny, xstart, xstop, ystart, ystop, alpha, field, field_new, field_old, stream) &
+          bind(C, name="dlesm_time_smooth_f64") result(rc)
+       import :: c_int, c_ptr, c_double
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       real(c_double), value :: alpha
+       type(c_ptr), value :: field, field_new, field_old, stream
+       integer(c_int) :: rc
+     end function
      function dlesm_periodic_halos_apply_f64(field, ld, ny, internal, bc_x, bc_y, stream) &
           bind(C, name="dlesm_periodic_halos_apply_f64") result(rc)
        import :: c_int, c_ptr, c_region

@@ -53,6 +53,9 @@ module dlesm_psy_mod
   public :: invoke_shallow_step_dm_pipelined, invoke_continuity
   public :: invoke_shallow_step_dm, halo_exchange_multi, invoke_jacobi5_multi, plan_jacobi5, plan_shallow_step
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
+  public :: invoke_compute_cu, invoke_compute_cv, invoke_compute_z, invoke_compute_h
+  public :: invoke_compute_unew, invoke_compute_vnew, invoke_compute_pnew, invoke_time_smooth
+  public :: invoke_shallow_step_sw_periodic, plan_shallow_step_sw
 
 contains
 
@@ -315,6 +318,176 @@ contains
                                    c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_shallow_step_sw: ' // dlesm_error_text())
   end subroutine invoke_shallow_step_sw
+
+  !> invoke_shallow_step_sw over the internal region AND the periodic copies of the three new fields, in ONE launch:
+  !! the step's edge tiles store the periodic images themselves (== invoke_shallow_step_sw followed by
+  !! invoke_periodic_halos of unew, vnew, pnew, bit for bit)
+  subroutine invoke_shallow_step_sw_periodic(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)
+    type(c_sw_params), intent(in) :: prm
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew
+    type(c_region) :: cint
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    associate (it => p%internal)
+      cint = c_region(it%nx, it%ny, it%xstart, it%xstop, it%ystart, it%ystop)
+    end associate
+    rc = dlesm_shallow_step_sw_periodic_f64(prm, int(p%grid%nx, c_int), int(p%grid%ny, c_int), cint, &
+                                            int(p%grid%boundary_conditions(1), c_int), &
+                                            int(p%grid%boundary_conditions(2), c_int), &
+                                            field_device_data(u), field_device_data(v), field_device_data(p), &
+                                            field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                            field_device_data(unew), field_device_data(vnew), field_device_data(pnew), &
+                                            c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_sw_periodic: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_sw_periodic
+
+  !> plan_shallow_step for the SW-offset step
+  subroutine plan_shallow_step_sw(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)
+    type(c_sw_params), intent(in) :: prm
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    rc = dlesm_shallow_autotune_sw_f64(prm, int(p%grid%nx, c_int), int(p%grid%ny, c_int), &
+                                       int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                                       int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                                       field_device_data(u), field_device_data(v), field_device_data(p), &
+                                       field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                       field_device_data(unew), field_device_data(vnew), field_device_data(pnew), &
+                                       c_null_ptr)
+    if (rc /= 0) call gocean_stop('plan_shallow_step_sw: ' // dlesm_error_text())
+  end subroutine plan_shallow_step_sw
+
+  ! ---- The GOcean `shallow` kernels ONE BY ONE: what replaces each generated loop nest
+  !        do jj = fld%internal%ystart, fld%internal%ystop
+  !           do ji = fld%internal%xstart, fld%internal%xstop
+  !              call compute_cu_code(ji, jj, cu%data, p%data, u%data)
+  !      of an unmodified PSy layer (kernel form: reference infrastructure_mod.f90:13-41; metadata
+  !      argument_mod.f90:39-112, kernel_mod.f90:28-50).  Loop bounds: the written field's internal region
+  !      (ITERATES_OVER = GO_INTERNAL_PTS) unless `box` = (/xstart, xstop, ystart, ystop/) is given; the kernel's
+  !      index_offset is the grid's; dx, dy (the kernels' GO_GRID_DX_CONST / GO_GRID_DY_CONST arguments) come from
+  !      the grid.  Formulas: DESIGN.md sections 6, 6.2, 6.3.
+
+  subroutine kernel_box(fld, box, b)
+    type(r2d_field), intent(in) :: fld
+    integer, intent(in), optional :: box(4)
+    integer(c_int), intent(out) :: b(4)
+    if (present(box)) then
+       b = int(box, c_int)
+    else
+       b = int((/ fld%internal%xstart, fld%internal%xstop, fld%internal%ystart, fld%internal%ystop /), c_int)
+    end if
+  end subroutine kernel_box
+
+  subroutine invoke_compute_cu(cu, p, u, box)
+    type(r2d_field), intent(inout), target :: cu, p, u
+    integer, intent(in), optional :: box(4)
+    integer(c_int) :: rc, b(4)
+    call need_device(cu);  call need_device(p);  call need_device(u)
+    call kernel_box(cu, box, b)
+    rc = dlesm_compute_cu_f64(int(cu%grid%offset, c_int), int(cu%grid%nx, c_int), int(cu%grid%ny, c_int), &
+                              b(1), b(2), b(3), b(4), field_device_data(cu), field_device_data(p), &
+                              field_device_data(u), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_compute_cu: ' // dlesm_error_text())
+  end subroutine invoke_compute_cu
+
+  subroutine invoke_compute_cv(cv, p, v, box)
+    type(r2d_field), intent(inout), target :: cv, p, v
+    integer, intent(in), optional :: box(4)
+    integer(c_int) :: rc, b(4)
+    call need_device(cv);  call need_device(p);  call need_device(v)
+    call kernel_box(cv, box, b)
+    rc = dlesm_compute_cv_f64(int(cv%grid%offset, c_int), int(cv%grid%nx, c_int), int(cv%grid%ny, c_int), &
+                              b(1), b(2), b(3), b(4), field_device_data(cv), field_device_data(p), &
+                              field_device_data(v), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_compute_cv: ' // dlesm_error_text())
+  end subroutine invoke_compute_cv
+
+  subroutine invoke_compute_z(z, p, u, v, box)
+    type(r2d_field), intent(inout), target :: z, p, u, v
+    integer, intent(in), optional :: box(4)
+    integer(c_int) :: rc, b(4)
+    call need_device(z);  call need_device(p);  call need_device(u);  call need_device(v)
+    call kernel_box(z, box, b)
+    rc = dlesm_compute_z_f64(int(z%grid%offset, c_int), int(z%grid%nx, c_int), int(z%grid%ny, c_int), &
+                             b(1), b(2), b(3), b(4), 4.0_go_wp / z%grid%dx, 4.0_go_wp / z%grid%dy, &
+                             field_device_data(z), field_device_data(p), field_device_data(u), field_device_data(v), &
+                             c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_compute_z: ' // dlesm_error_text())
+  end subroutine invoke_compute_z
+
+  subroutine invoke_compute_h(h, p, u, v, box)
+    type(r2d_field), intent(inout), target :: h, p, u, v
+    integer, intent(in), optional :: box(4)
+    integer(c_int) :: rc, b(4)
+    call need_device(h);  call need_device(p);  call need_device(u);  call need_device(v)
+    call kernel_box(h, box, b)
+    rc = dlesm_compute_h_f64(int(h%grid%offset, c_int), int(h%grid%nx, c_int), int(h%grid%ny, c_int), &
+                             b(1), b(2), b(3), b(4), field_device_data(h), field_device_data(p), &
+                             field_device_data(u), field_device_data(v), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_compute_h: ' // dlesm_error_text())
+  end subroutine invoke_compute_h
+
+  !> tdt = 2*dt in a leapfrog step (dt in the first, forward step)
+  subroutine invoke_compute_unew(unew, uold, z, cv, h, tdt, box)
+    type(r2d_field), intent(inout), target :: unew, uold, z, cv, h
+    real(go_wp), intent(in) :: tdt
+    integer, intent(in), optional :: box(4)
+    integer(c_int) :: rc, b(4)
+    call need_device(unew);  call need_device(uold);  call need_device(z);  call need_device(cv);  call need_device(h)
+    call kernel_box(unew, box, b)
+    rc = dlesm_compute_unew_f64(int(unew%grid%offset, c_int), int(unew%grid%nx, c_int), int(unew%grid%ny, c_int), &
+                                b(1), b(2), b(3), b(4), tdt / 8.0_go_wp, tdt / unew%grid%dx, &
+                                field_device_data(unew), field_device_data(uold), field_device_data(z), &
+                                field_device_data(cv), field_device_data(h), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_compute_unew: ' // dlesm_error_text())
+  end subroutine invoke_compute_unew
+
+  subroutine invoke_compute_vnew(vnew, vold, z, cu, h, tdt, box)
+    type(r2d_field), intent(inout), target :: vnew, vold, z, cu, h
+    real(go_wp), intent(in) :: tdt
+    integer, intent(in), optional :: box(4)
+    integer(c_int) :: rc, b(4)
+    call need_device(vnew);  call need_device(vold);  call need_device(z);  call need_device(cu);  call need_device(h)
+    call kernel_box(vnew, box, b)
+    rc = dlesm_compute_vnew_f64(int(vnew%grid%offset, c_int), int(vnew%grid%nx, c_int), int(vnew%grid%ny, c_int), &
+                                b(1), b(2), b(3), b(4), tdt / 8.0_go_wp, tdt / vnew%grid%dy, &
+                                field_device_data(vnew), field_device_data(vold), field_device_data(z), &
+                                field_device_data(cu), field_device_data(h), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_compute_vnew: ' // dlesm_error_text())
+  end subroutine invoke_compute_vnew
+
+  subroutine invoke_compute_pnew(pnew, pold, cu, cv, tdt, box)
+    type(r2d_field), intent(inout), target :: pnew, pold, cu, cv
+    real(go_wp), intent(in) :: tdt
+    integer, intent(in), optional :: box(4)
+    integer(c_int) :: rc, b(4)
+    call need_device(pnew);  call need_device(pold);  call need_device(cu);  call need_device(cv)
+    call kernel_box(pnew, box, b)
+    rc = dlesm_compute_pnew_f64(int(pnew%grid%offset, c_int), int(pnew%grid%nx, c_int), int(pnew%grid%ny, c_int), &
+                                b(1), b(2), b(3), b(4), tdt / pnew%grid%dx, tdt / pnew%grid%dy, &
+                                field_device_data(pnew), field_device_data(pold), field_device_data(cu), &
+                                field_device_data(cv), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_compute_pnew: ' // dlesm_error_text())
+  end subroutine invoke_compute_pnew
+
+  !> time_smooth (the Asselin filter of the leapfrog scheme), over field_old%internal:
+  !!   field_old = field + alpha*(field_new - 2*field + field_old)
+  subroutine invoke_time_smooth(field, field_new, field_old, alpha, box)
+    type(r2d_field), intent(inout), target :: field, field_new, field_old
+    real(go_wp), intent(in) :: alpha
+    integer, intent(in), optional :: box(4)
+    integer(c_int) :: rc, b(4)
+    call need_device(field);  call need_device(field_new);  call need_device(field_old)
+    call kernel_box(field_old, box, b)
+    rc = dlesm_time_smooth_f64(int(field_old%grid%nx, c_int), int(field_old%grid%ny, c_int), b(1), b(2), b(3), b(4), &
+                               alpha, field_device_data(field), field_device_data(field_new), &
+                               field_device_data(field_old), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_time_smooth: ' // dlesm_error_text())
+  end subroutine invoke_time_smooth
 
   !> The periodic-boundary copies of a field -- its halo(:) list (field_mod.f90:1394-1464), in order --
   !! on the device: what a periodic model's PSy layer does after every kernel that writes the field.

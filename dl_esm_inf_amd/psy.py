@@ -286,6 +286,16 @@ def autotune_shallow(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream
                                                  pnew.device_ptr, _stream_ptr(stream)))
 
 
+def autotune_shallow_sw(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
+    """the planning call of the SW-offset step (invoke_shallow_step_sw / invoke_shallow_step_sw_periodic)"""
+    g, it = p.grid, p.internal
+    check(_cabi.lib().dlesm_shallow_autotune_sw_f64(C.byref(params), g.nx, g.ny, it.xstart, it.xstop,
+                                                    it.ystart, it.ystop, u.device_ptr, v.device_ptr,
+                                                    p.device_ptr, uold.device_ptr, vold.device_ptr,
+                                                    pold.device_ptr, unew.device_ptr, vnew.device_ptr,
+                                                    pnew.device_ptr, _stream_ptr(stream)))
+
+
 def invoke_shallow_step_dm(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
     """distributed form: frame of the new fields, one grouped exchange of all three behind the
     interior; unew, vnew, pnew leave with valid halos"""

@@ -2,7 +2,8 @@
 !! the dl_esm_inf API (grid_type, r2d_field, halo_exchange, field_checksum), PSy layer =
 !! the HIP launch wrappers of dlesm_psy_mod.  5-point Jacobi ping-pong on a T field.
 !!
-!!   jacobi_app.exe [N] [NSTEPS]              (default 4096 100; DL_ESM_ALIGNMENT honoured)
+!!   jacobi_app.exe [N] [NSTEPS] [FUSE] [PLAN]  (default 4096 100 1 1; DL_ESM_ALIGNMENT honoured; PLAN = 0 skips the
+!!                                               optional planning call; ten untimed warm-up steps precede the timed loop)
 !! One process per GPU: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT in the environment (e.g.
 !!   for r in 0 1; do RANK=$r WORLD_SIZE=2 LOCAL_RANK=$r MASTER_PORT=29400 ./jacobi_app.exe & done).
 !! With more than one rank the global domain is (N*P) x (N*Q) so that every rank owns N x N.
@@ -45,7 +46,7 @@ program jacobi_app
   use dlesm_psy_mod
   implicit none
   character(len=32) :: arg
-  integer :: n, nsteps, i, p, q, nr, fuse, ncalls
+  integer :: n, nsteps, i, p, q, nr, fuse, ncalls, plan, i0
   integer(8) :: t0, t1, rate
   type(grid_type), target :: model_grid
   type(r2d_field), target :: a, b
@@ -62,6 +63,10 @@ program jacobi_app
   end if
   if (command_argument_count() >= 3) then
      call get_command_argument(3, arg);  read(arg, *) fuse
+  end if
+  plan = 1
+  if (command_argument_count() >= 4) then
+     call get_command_argument(4, arg);  read(arg, *) plan
   end if
   if (fuse < 1 .or. fuse > 8) stop 'jacobi_app: fuse must be 1..8'
   nsteps = (nsteps / fuse) * fuse
@@ -87,13 +92,18 @@ program jacobi_app
   call a%halo_exchange(1)
   call model_write_log("('initial checksum = ',E24.16)", field_checksum(a))
 
-  if (fuse == 1) then
+  if (fuse == 1 .and. plan /= 0) then
      call plan_jacobi5(b, a)            ! optional: the library times its launch shapes once
      call invoke_copy(b, a)
   end if
-  call device_sync()
-  call system_clock(t0, rate)
-  do i = 1, ncalls
+  ! ten untimed warm-up steps (an even number: a and b keep their roles), then the timed loop
+  do i0 = 0, 1
+  if (i0 == 1) then
+     call halo_join(model_grid)
+     call device_sync()
+     call system_clock(t0, rate)
+  end if
+  do i = 1, merge(10 / fuse + mod(10 / fuse, 2), ncalls, i0 == 0)
      if (fuse == 1) then
         if (mod(i, 2) == 1) then
            call invoke_jacobi5_dm_pipelined(b, a)   ! exchange of the result hidden behind the interior
@@ -107,6 +117,7 @@ program jacobi_app
            call invoke_jacobi5_multi(a, b, fuse)
         end if
      end if
+  end do
   end do
   call halo_join(model_grid)        ! the one join of the time loop (no-op on one rank)
   call device_sync()

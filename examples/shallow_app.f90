@@ -3,9 +3,16 @@
 !! configuration the reference supports, serially: field_mod.f90:675-751, grid_mod.f90:437-442).
 !! Algorithm layer = the usual sequence -- build grid and fields, initialise, time loop of
 !! [u/v/h update; periodic boundary copies of the new fields; leapfrog rotation], checksums --
-!! PSy layer = the launch wrappers of dlesm_psy_mod (invoke_shallow_step_sw, invoke_periodic_halos)
-!! instead of loop nests over compute_*_code.
-!!     shallow_app.exe N NSTEPS
+!! PSy layer = the launch wrappers of dlesm_psy_mod instead of loop nests over compute_*_code, in one of three
+!! forms (MODE, default 0):
+!!   0  fused     one launch per time step: invoke_shallow_step_sw_periodic (step + periodic images)
+!!   1  kernels   what an UNMODIFIED generated PSy layer does: one launch per GOcean kernel -- compute_cu, cv, z,
+!!                h, the periodic copies of the four intermediates, compute_unew, vnew, pnew, the periodic copies of
+!!                the new level -- seven kernel launches per step, every intermediate through HBM
+!!   2  kernels + time_smooth: mode 1 followed by the Asselin filter of the old level (alpha = 0.001), as the
+!!                benchmark's time loop has it; uold <- smoothed u, u <- unew by rotation
+!! Modes 0 and 1 print the same bits.
+!!     shallow_app.exe N NSTEPS [MODE]
 program shallow_app
   use iso_c_binding
   use kind_params_mod
@@ -16,9 +23,12 @@ program shallow_app
   use dlesm_psy_mod
   implicit none
   character(len=32) :: arg
-  integer :: n, nsteps, step, k, rate, t0, t1
+  integer :: n, nsteps, step, k, rate, t0, t1, mode
   type(grid_type), target :: model_grid
   type(r2d_field), target :: f(9)          ! u v p | uold vold pold | unew vnew pnew
+  type(r2d_field), target :: cu, cv, z, h  ! the intermediates of the per-kernel forms
+  real(go_wp), parameter :: dt = 90.0_go_wp, alpha = 0.001_go_wp
+  real(go_wp) :: tdt
   integer :: ptype(9), cur(3), old(3), new(3), tmp(3)
   real(go_wp), pointer :: d(:,:)
   real(go_wp) :: secs
@@ -30,6 +40,11 @@ program shallow_app
   if (command_argument_count() >= 2) then
      call get_command_argument(2, arg); read(arg, *) nsteps
   end if
+  mode = 0
+  if (command_argument_count() >= 3) then
+     call get_command_argument(3, arg); read(arg, *) mode
+  end if
+  tdt = dt + dt
   call gocean_initialise()
   model_grid = grid_type(GO_ARAKAWA_C, (/GO_BC_PERIODIC, GO_BC_PERIODIC, GO_BC_NONE/), GO_OFFSET_SW)
   call model_grid%decompose(n, n)
@@ -55,16 +70,45 @@ program shallow_app
      call invoke_copy(f(k + 6), f(k))
   end do
   cur = (/1, 2, 3/);  old = (/4, 5, 6/);  new = (/7, 8, 9/)
+  if (mode > 0) then
+     cu = r2d_field(model_grid, GO_U_POINTS);  cv = r2d_field(model_grid, GO_V_POINTS)
+     z = r2d_field(model_grid, GO_F_POINTS);   h = r2d_field(model_grid, GO_T_POINTS)
+  else
+     ! planning call (once, outside the time loop): the new level receives one valid step
+     call plan_shallow_step_sw(shallow_params(model_grid%dx, model_grid%dy, dt), &
+                               f(cur(1)), f(cur(2)), f(cur(3)), f(old(1)), f(old(2)), f(old(3)), &
+                               f(new(1)), f(new(2)), f(new(3)))
+  end if
   call device_sync()
   call system_clock(t0, rate)
   do step = 1, nsteps
-     call invoke_shallow_step_sw(shallow_params(1.0e5_go_wp, 1.0e5_go_wp, 90.0_go_wp), &
-                                 f(cur(1)), f(cur(2)), f(cur(3)), f(old(1)), f(old(2)), f(old(3)), &
-                                 f(new(1)), f(new(2)), f(new(3)))
-     do k = 1, 3
-        call invoke_periodic_halos(f(new(k)))
-     end do
-     tmp = old;  old = cur;  cur = new;  new = tmp        ! leapfrog rotation
+     if (mode == 0) then
+        call invoke_shallow_step_sw_periodic(shallow_params(model_grid%dx, model_grid%dy, dt), &
+                                             f(cur(1)), f(cur(2)), f(cur(3)), f(old(1)), f(old(2)), f(old(3)), &
+                                             f(new(1)), f(new(2)), f(new(3)))
+     else
+        call invoke_compute_cu(cu, f(cur(3)), f(cur(1)))
+        call invoke_compute_cv(cv, f(cur(3)), f(cur(2)))
+        call invoke_compute_z(z, f(cur(3)), f(cur(1)), f(cur(2)))
+        call invoke_compute_h(h, f(cur(3)), f(cur(1)), f(cur(2)))
+        call invoke_periodic_halos(cu);  call invoke_periodic_halos(cv)
+        call invoke_periodic_halos(z);   call invoke_periodic_halos(h)
+        call invoke_compute_unew(f(new(1)), f(old(1)), z, cv, h, tdt)
+        call invoke_compute_vnew(f(new(2)), f(old(2)), z, cu, h, tdt)
+        call invoke_compute_pnew(f(new(3)), f(old(3)), cu, cv, tdt)
+        do k = 1, 3
+           call invoke_periodic_halos(f(new(k)))
+        end do
+     end if
+     if (mode == 2) then
+        do k = 1, 3
+           call invoke_time_smooth(f(cur(k)), f(new(k)), f(old(k)), alpha)
+           call invoke_periodic_halos(f(old(k)))
+        end do
+        tmp = cur;  cur = new;  new = tmp                  ! u <- unew; uold holds the smoothed u already
+     else
+        tmp = old;  old = cur;  cur = new;  new = tmp      ! leapfrog rotation
+     end if
   end do
   call device_sync()
   call system_clock(t1)

@@ -307,6 +307,14 @@ int dlesm_shallow_step_sw_f64(const dlesm_sw_params *params, int ld, int ny,
                               const double *uold, const double *vold, const double *pold,
                               double *unew, double *vnew, double *pnew, void *stream);
 
+/* planning call for the SW-offset step (dlesm_shallow_step_sw_f64 and its periodic form), as
+ * dlesm_shallow_autotune_f64 is for the NE one; the new fields receive one valid step (no periodic copies) */
+int dlesm_shallow_autotune_sw_f64(const dlesm_sw_params *params, int ld, int ny,
+                                  int xstart, int xstop, int ystart, int ystop,
+                                  const double *u, const double *v, const double *p,
+                                  const double *uold, const double *vold, const double *pold,
+                                  double *unew, double *vnew, double *pnew, void *stream);
+
 /* The same step over the INTERNAL region of periodic fields, with the periodic copies of the new level done by
  * the same launch: every cell stored on the first / last internal column or row is also stored into the halo cell
  * that init_periodic_bc_halos (field_mod.f90:1394-1464) would copy it to, corner halos included.  Leaves unew,

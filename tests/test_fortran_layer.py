@@ -273,14 +273,17 @@ def test_fortran_device_io_and_jacobi_on_gpu(exe):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["fused", "seven-kernels", "seven-kernels+time_smooth"])
 @pytest.mark.parametrize("n,nsteps,alignment", [(10, 5, None), (256, 6, 64)])
-def test_fortran_periodic_shallow_app_on_gpu(exe, n, nsteps, alignment):
+def test_fortran_periodic_shallow_app_on_gpu(exe, n, nsteps, alignment, mode):
     """examples/shallow_app.f90 -- a GOcean-style SW-offset, doubly periodic shallow-water model written
-    against the reference's API (grid_type, r2d_field, halo lists) with the PSy layer of this library
-    -- against the oracle running the same model: checksums within 1e-12, sampled cells bit for bit"""
+    against the reference's API (grid_type, r2d_field, halo lists) with the PSy layer of this library: the fused
+    one-launch step, the seven GOcean kernels launched one by one (what an unmodified generated PSy layer does),
+    and the latter with the time_smooth kernel -- against the oracle running the same model: checksums within
+    1e-12, sampled cells bit for bit"""
     import sw_numpy as N
     env = {"DL_ESM_ALIGNMENT": str(alignment)} if alignment else None
-    _, g, _ = exe("shallow_app.exe", n, nsteps, env=env)
+    _, g, _ = exe("shallow_app.exe", n, nsteps, mode, env=env)
     ld, nyy, _ = ints(g["shape"][0])
     assert (ld, nyy) == O.grid_extents(n + 2, n + 2, alignment)
     it = (2, n + 1, 2, n + 1)
@@ -295,7 +298,13 @@ def test_fortran_periodic_shallow_app_on_gpu(exe, n, nsteps, alignment):
         O.sw_step_sw(prm, ld, it, *cur, *old, *new)
         for f in new:
             O.apply_periodic_halos(f, ld, it, 0, 0)
-        old, cur, new = cur, new, old
+        if mode == 2:
+            for c, nw, o in zip(cur, new, old):
+                O.sw_kernel("time_smooth", True, ld, it, o, [c, nw, o], 0.001)
+                O.apply_periodic_halos(o, ld, it, 0, 0)
+            cur, new = new, cur
+        else:
+            old, cur, new = cur, new, old
     for row, want in zip(g["cs"], cur):
         cs = O.lib().orc_checksum(want, ld, *it)
         assert abs(float(row[1]) - cs) <= 1e-12 * cs

@@ -1132,6 +1132,8 @@ def test_periodic_sw_offset_shallow_model(D, nx, ny, alignment, steps, sw_kernel
         assert np.array_equal(ref[:it.ystop + 1, :it.xstop + 1], H[n][:it.ystop + 1, :it.xstop + 1]), n
     cur, old, new = [F[n] for n in "uvp"], [F[n + "old"] for n in "uvp"], [F[n + "new"] for n in "uvp"]
     hc, ho, hn = [H[n] for n in "uvp"], [H[n + "old"] for n in "uvp"], [H[n + "new"] for n in "uvp"]
+    if sw_nt == 10:                                              # the planning call of the SW-offset step: no bit changes
+        D.psy.autotune_shallow_sw(prm, *cur, *old, *new)
     for _ in range(steps):
         if fused_halos:
             for f in new:                                        # stale halos must be overwritten, not inherited
