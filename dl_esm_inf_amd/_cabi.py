@@ -135,6 +135,7 @@ PROTOTYPES = {
     "dlesm_copy_patch_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_fill_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, _d, _vp]),
     "dlesm_checksum_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_d), _vp]),
+    "dlesm_checksum_async_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "dlesm_hash_init_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.c_uint64, C.c_int64, C.c_int64, _vp]),
     "dlesm_stream_copy_f64": (_i, [_i, _i, C.POINTER(_vp), C.POINTER(_vp), C.c_size_t, _i, _vp]),
     "dlesm_set_tuning": (_i, [C.c_char_p, _i]),

@@ -1032,6 +1032,65 @@ __global__ void pack_inner_k(const double *__restrict__ f, int ld, int x0, int y
 
 struct GBox { int x0, y0, w, h; };            // 0-based origin in the global array, extent
 
+// Round 3: both copies as ROW SEGMENTS (the shape of rowseg_write_k, dlesm_kernels.hip): one workgroup = 16 KB of one
+// row, four 16-byte pairs per thread anchored on the 16-byte boundaries of the DESTINATION row (the source is read
+// with 16-byte loads at whatever 8-byte alignment it has), work items numbered row-major, so that workgroups sweep
+// both arrays front to back.  The forms above (a workgroup per row, 8-byte lanes: 66 % of the HBM peak at 16384^2)
+// remain for unaligned base pointers.
+constexpr int SEG_PAIRS = 1024;
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef double d2v8 __attribute__((ext_vector_type(2), aligned(8)));
+
+// dst_row[0 .. n) <- src_row[0 .. n), segment sg of the row
+__device__ __forceinline__ void copy_row_segment(const double *__restrict__ src, double *__restrict__ dst, int n, int sg,
+                                                 int segs, bool nt)
+{
+    const int head = (int)(((uintptr_t)dst >> 3) & 1);
+    const int npairs = (n - head) / 2, tail = (n - head) & 1;
+    if (threadIdx.x == 0) {
+        if (sg == 0 && head && n > 0) dst[0] = src[0];
+        if (sg == segs - 1 && tail) dst[n - 1] = src[n - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = sg * SEG_PAIRS + threadIdx.x + 256 * k;
+        if (p < npairs) {
+            const d2v v = *(const d2v8 *)(src + head + 2 * p);
+            if (nt) __builtin_nontemporal_store(v, (d2v *)(dst + head + 2 * p));
+            else *(d2v *)(dst + head + 2 * p) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_inner_rowseg(const double *__restrict__ f, int ld, int x0, int y0, int nx, int h,
+                                                         int segs, long slot, double *__restrict__ send, bool nt)
+{
+    const long items = (long)segs * h;
+    if ((long)blockIdx.x < items) {
+        const int j = blockIdx.x / segs, sg = blockIdx.x - j * segs;
+        copy_row_segment(f + (size_t)(y0 + j) * ld + x0, send + (size_t)j * nx, nx, sg, segs, nt);
+        return;
+    }
+    // the rest of the slot (tiles are uneven): zeroed by the workgroups behind the copy
+    const long t = (long)nx * h + ((long)blockIdx.x - items) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (t + 256 * k < slot) send[t + 256 * k] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void unpack_gathered_rowseg(const double *__restrict__ recv, long slot,
+                                                              const GBox *__restrict__ boxes, int gnx, int segs,
+                                                              double *__restrict__ global, bool nt)
+{
+    const GBox b = boxes[blockIdx.y];
+    const int j = blockIdx.x / segs, sg = blockIdx.x - j * segs;
+    if (j >= b.h || sg * 2 * SEG_PAIRS >= b.w + 1) return;
+    const int bsegs = ((b.w + 1) / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? ((b.w + 1) / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
+    if (sg >= bsegs) return;
+    copy_row_segment(recv + (size_t)blockIdx.y * slot + (size_t)j * b.w, global + (size_t)(b.y0 + j) * gnx + b.x0, b.w, sg,
+                     bsegs, nt);
+}
+
 // grid.y = rank; j outer / i inner as field_mod.f90:1376-1386
 __global__ void unpack_gathered_k(const double *__restrict__ recv, long slot, const GBox *__restrict__ boxes,
                                   int gnx, double *__restrict__ global)
@@ -1055,6 +1114,17 @@ extern "C" int dlesm_pack_inner_f64(const double *field, int ld, int ny, int xst
     const long n = nx > 0 && h > 0 ? (long)nx * h : 0;
     DLESM_REQUIRE(slot >= n, "slot of %ld doubles for a %dx%d region", slot, nx, h);
     if (slot == 0) return DLESM_OK;
+    if ((uintptr_t)field % 8 == 0 && (uintptr_t)send % 16 == 0 && tuning("util_rowseg", 1)) {
+        const int segs = n > 0 ? (((nx + 1) / 2 + SEG_PAIRS - 1) / SEG_PAIRS) : 0;
+        const long items = (long)segs * (n > 0 ? h : 0), zero_blocks = (slot - n + 1023) / 1024;
+        if (items + zero_blocks < (1L << 31)) {
+            hipLaunchKernelGGL(pack_inner_rowseg, dim3((unsigned)(items + zero_blocks)), dim3(256), 0, (hipStream_t)stream, field,
+                               ld, xstart - 1, ystart - 1, n > 0 ? nx : 0, n > 0 ? h : 0, segs > 0 ? segs : 1, slot, send,
+                               nt_stores_for(nx, 0, h - 1) != 0);
+            DLESM_HIP_TRY(hipGetLastError());
+            return DLESM_OK;
+        }
+    }
     long blocks = n > 0 ? h : (slot + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
@@ -1090,10 +1160,18 @@ extern "C" int dlesm_unpack_gathered_f64(const double *recv, long slot, const dl
     DLESM_HIP_TRY(hipMalloc((void **)&dboxes, boxes.size() * sizeof(GBox)));
     hipError_t e = hipMemcpyAsync(dboxes, boxes.data(), boxes.size() * sizeof(GBox), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-        long gx = tallest;
-        if (gx > 2048) gx = 2048;
-        hipLaunchKernelGGL(unpack_gathered_k, dim3((unsigned)gx, (unsigned)nranks), dim3(256), 0, s, recv, slot, dboxes,
-                           d->global_nx, global);
+        int widest_w = 0;
+        for (const GBox &b : boxes) widest_w = b.w > widest_w ? b.w : widest_w;
+        const int segs = ((widest_w + 1) / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? ((widest_w + 1) / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
+        if ((uintptr_t)recv % 8 == 0 && (uintptr_t)global % 16 == 0 && (long)segs * tallest < (1L << 31) && tuning("util_rowseg", 1)) {
+            hipLaunchKernelGGL(unpack_gathered_rowseg, dim3((unsigned)((long)segs * tallest), (unsigned)nranks), dim3(256), 0, s, recv,
+                               slot, dboxes, d->global_nx, segs, global, nt_stores_for(d->global_nx, 0, d->global_ny - 1) != 0);
+        } else {
+            long gx = tallest;
+            if (gx > 2048) gx = 2048;
+            hipLaunchKernelGGL(unpack_gathered_k, dim3((unsigned)gx, (unsigned)nranks), dim3(256), 0, s, recv, slot, dboxes,
+                               d->global_nx, global);
+        }
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);      // the table is a stack-lifetime upload
@@ -1114,13 +1192,19 @@ extern "C" int dlesm_gather_inner_f64(const double *field, int ld, int ny, const
     const bool root = nranks == 1 || g_rank == 0;
     DLESM_REQUIRE(!root || global_host != nullptr, "null result array on the gathering rank");
     const size_t gbytes = (size_t)d->global_nx * d->global_ny * sizeof(double);
-    if (nranks == 1) {                                     // the copy-out of field_mod.f90:1332-1343
-        DLESM_REQUIRE(it->xstop - it->xstart + 1 == d->global_nx && it->ystop - it->ystart + 1 == d->global_ny,
-                      "one rank: internal region %dx%d is not the %dx%d domain", it->xstop - it->xstart + 1,
-                      it->ystop - it->ystart + 1, d->global_nx, d->global_ny);
+    if (nranks == 1) {
+        // the copy-out of field_mod.f90:1332-1343: WHATEVER internal region the field has goes to the top-left corner of
+        // global_data -- for SW-offset fields with external boundaries on U / V / F points (xstart + 1 / ystart + 1,
+        // field_mod.f90:724, 842, 1044, 1055) and for GO_ALL_POINTS fields that is not the whole domain; the rest of
+        // global_data keeps what the caller put there (the reference leaves it unset)
+        const int w = it->xstop - it->xstart + 1, h = it->ystop - it->ystart + 1;
+        if (w <= 0 || h <= 0) return DLESM_OK;
+        DLESM_REQUIRE(w <= d->global_nx && h <= d->global_ny, "one rank: internal region %dx%d is larger than the %dx%d domain", w,
+                      h, d->global_nx, d->global_ny);
+        if (int rc = check_box("dlesm_gather_inner_f64", ld, ny, it->xstart, it->xstop, it->ystart, it->ystop, 0)) return rc;
         DLESM_HIP_TRY(hipMemcpy2D(global_host, (size_t)d->global_nx * sizeof(double),
                                   field + lin(ld, it->xstart, it->ystart), (size_t)ld * sizeof(double),
-                                  (size_t)d->global_nx * sizeof(double), (size_t)d->global_ny, hipMemcpyDeviceToHost));
+                                  (size_t)w * sizeof(double), (size_t)h, hipMemcpyDeviceToHost));
         return DLESM_OK;
     }
     DLESM_REQUIRE(g_comm != nullptr && g_size == nranks, "gather over %d ranks, communicator has %d", nranks, g_size);

@@ -954,6 +954,45 @@ __global__ void fill_k(double *__restrict__ f, int ld, int x0, int y0, int nx, i
             f[(size_t)(y0 + j) * ld + x0 + i] = value;
 }
 
+// A box swept as ROW SEGMENTS (round 3; the forms above remain for unaligned base pointers): one workgroup = 16 KB of
+// one row of the box -- SEG_PAIRS 16-byte pairs, four per thread, anchored on the 16-byte boundaries of that row, the
+// unpaired element before / after them taken by thread 0 of the row's first / last segment -- numbered row-major,
+// so that workgroups, dispatched in index order and short-lived, sweep memory front to back like the linear copy that
+// sets the measured ceiling.  The earlier forms gave every workgroup whole rows (thousands of concurrent row fronts,
+// 8-byte lanes): 64-71 % of the HBM peak at 16384^2 (profiles/r02_aux_kernels.txt).
+constexpr int SEG_PAIRS = 1024;
+typedef double d2u __attribute__((ext_vector_type(2)));
+
+template <class GEN>   // GEN(i, j) -> value of element (0-based column i, row j)
+__global__ __launch_bounds__(256) void rowseg_write_k(double *__restrict__ f, int ld, int x0, int y0, int nx, int segs, bool nt,
+                                                      GEN gen)
+{
+    const int jr = blockIdx.x / segs, sg = blockIdx.x - jr * segs, j = y0 + jr;
+    const size_t row = (size_t)j * ld;
+    const int head = (int)((row + x0) & 1);
+    const int npairs = (nx - head) / 2, tail = (nx - head) & 1;
+    double *r = f + row + x0;
+    if (threadIdx.x == 0) {
+        if (sg == 0 && head) r[0] = gen(x0, j);
+        if (sg == segs - 1 && tail) r[nx - 1] = gen(x0 + nx - 1, j);
+    }
+    d2u *rv = (d2u *)(r + head);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = sg * SEG_PAIRS + threadIdx.x + 256 * k;
+        if (p < npairs) {
+            const int i = x0 + head + 2 * p;
+            const d2u v = d2u{gen(i, j), gen(i + 1, j)};
+            if (nt) __builtin_nontemporal_store(v, rv + p);
+            else rv[p] = v;
+        }
+    }
+}
+struct GenConst {
+    double v;
+    __device__ double operator()(int, int) const { return v; }
+};
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
     x += 0x9E3779B97F4A7C15ULL;
@@ -972,6 +1011,16 @@ __global__ void hash_init_k(double *__restrict__ f, int ld, int x0, int y0, int 
             f[(size_t)(y0 + j) * ld + x0 + i] = (double)(h >> 11) * 0x1.0p-53;
         }
 }
+
+struct GenHash {
+    uint64_t seed;
+    int64_t gx0, gy0;
+    __device__ double operator()(int i, int j) const
+    {
+        const uint64_t gi = (uint64_t)(gx0 + i), gj = (uint64_t)(gy0 + j);
+        return (double)(splitmix64(seed ^ (gi + (gj << 32))) >> 11) * 0x1.0p-53;
+    }
+};
 
 // SUM(ABS()) in a fixed tree order: lane strides -> wave shuffle tree -> LDS
 // across the 4 waves -> one partial per block -> second pass over the partials.
@@ -1027,6 +1076,47 @@ __global__ __launch_bounds__(256) void abs_sum_rows(const double *__restrict__ f
     }
     const double acc = block_sum_256(acc0 + acc1);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// the same sum as row segments (one partial per workgroup = per 16 KB of a row; see rowseg_write_k): the additions
+// happen in an order fixed by (ld, box) alone, so the result is deterministic run to run
+__global__ __launch_bounds__(256) void abs_sum_rowseg(const double *__restrict__ f, int ld, int x0, int y0, int nx, int segs,
+                                                      double *__restrict__ partial)
+{
+    const int jr = blockIdx.x / segs, sg = blockIdx.x - jr * segs;
+    const size_t row = (size_t)(y0 + jr) * ld;
+    const int head = (int)((row + x0) & 1);
+    const int npairs = (nx - head) / 2, tail = (nx - head) & 1;
+    const double *r = f + row + x0;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (threadIdx.x == 0) {
+        if (sg == 0 && head) acc0 += fabs(r[0]);
+        if (sg == segs - 1 && tail) acc1 += fabs(r[nx - 1]);
+    }
+    const d2u *rv = (const d2u *)(r + head);
+    d2u v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                        // four 16-byte loads in flight per lane, each read once
+        const int p = sg * SEG_PAIRS + threadIdx.x + 256 * k;
+        v[k] = p < npairs ? __builtin_nontemporal_load(rv + p) : d2u{0.0, 0.0};
+    }
+    acc0 += fabs(v[0].x) + fabs(v[0].y);
+    acc1 += fabs(v[1].x) + fabs(v[1].y);
+    acc0 += fabs(v[2].x) + fabs(v[2].y);
+    acc1 += fabs(v[3].x) + fabs(v[3].y);
+    const double acc = block_sum_256(acc0 + acc1);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// one level of the tree over the partials: workgroup b sums partial[b*chunk .. (b+1)*chunk)
+__global__ __launch_bounds__(256) void sum_partials_level(const double *__restrict__ partial, long n, int chunk,
+                                                          double *__restrict__ out)
+{
+    const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    double acc = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) acc += partial[i];
+    acc = block_sum_256(acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 
 __global__ __launch_bounds__(256) void sum_partials(const double *__restrict__ partial, int n,
@@ -1246,8 +1336,13 @@ extern "C" int dlesm_fill_f64(double *f, int ld, int ny, int xstart, int xstop, 
     if (xstop < xstart || ystop < ystart) return DLESM_OK;
     if (int rc = check_box("dlesm_fill_f64", ld, ny, xstart, xstop, ystart, ystop, 0)) return rc;
     const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
-    hipLaunchKernelGGL(fill_k, grid2d(nx, nyb), dim3(256), 0, (hipStream_t)stream, f, ld, xstart - 1,
-                       ystart - 1, nx, nyb, value);
+    const int segs = (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
+    if ((uintptr_t)f % 16 == 0 && (long)segs * nyb < (1L << 31) && tuning("util_rowseg", 1))
+        hipLaunchKernelGGL((rowseg_write_k<GenConst>), dim3((unsigned)((long)segs * nyb)), dim3(256), 0, (hipStream_t)stream, f, ld,
+                           xstart - 1, ystart - 1, nx, segs, nt_stores_for(ld, ystart - 1, ystop - 1) != 0, GenConst{value});
+    else
+        hipLaunchKernelGGL(fill_k, grid2d(nx, nyb), dim3(256), 0, (hipStream_t)stream, f, ld, xstart - 1,
+                           ystart - 1, nx, nyb, value);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -1260,11 +1355,48 @@ extern "C" int dlesm_hash_init_f64(double *f, int ld, int ny, int xstart, int xs
     if (xstop < xstart || ystop < ystart) return DLESM_OK;
     if (int rc = check_box("dlesm_hash_init_f64", ld, ny, xstart, xstop, ystart, ystop, 0)) return rc;
     const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
-    hipLaunchKernelGGL(hash_init_k, grid2d(nx, nyb), dim3(256), 0, (hipStream_t)stream, f, ld, xstart - 1,
-                       ystart - 1, nx, nyb, seed, gx0, gy0);
+    const int segs = (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
+    if ((uintptr_t)f % 16 == 0 && (long)segs * nyb < (1L << 31) && tuning("util_rowseg", 1))
+        hipLaunchKernelGGL((rowseg_write_k<GenHash>), dim3((unsigned)((long)segs * nyb)), dim3(256), 0, (hipStream_t)stream, f, ld,
+                           xstart - 1, ystart - 1, nx, segs, nt_stores_for(ld, ystart - 1, ystop - 1) != 0,
+                           GenHash{seed, gx0, gy0});
+    else
+        hipLaunchKernelGGL(hash_init_k, grid2d(nx, nyb), dim3(256), 0, (hipStream_t)stream, f, ld, xstart - 1,
+                           ystart - 1, nx, nyb, seed, gx0, gy0);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
+
+// SUM(ABS(box)) enqueued on `s`: partials (one per row segment) -> levels of 4096 -> *result_dev.  `scratch` holds
+// segs*rows + (segs*rows + 4095)/4096 doubles.
+static int enqueue_checksum(const double *f, int ld, int x0, int y0, int nx, int nyb, double *scratch, double *result_dev,
+                            hipStream_t s)
+{
+    const int segs = (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
+    const long n1 = (long)segs * nyb;
+    hipLaunchKernelGGL(abs_sum_rowseg, dim3((unsigned)n1), dim3(256), 0, s, f, ld, x0, y0, nx, segs, scratch);
+    const double *lvl = scratch;
+    long n = n1;
+    if (n > 4096) {
+        const long n2 = (n + 4095) / 4096;                       // <= 2^31 / 4096 row segments: fits one more level
+        hipLaunchKernelGGL(sum_partials_level, dim3((unsigned)n2), dim3(256), 0, s, lvl, n, 4096, scratch + n1);
+        lvl = scratch + n1;
+        n = n2;
+    }
+    DLESM_REQUIRE(n <= (1 << 20), "checksum: box too large");
+    hipLaunchKernelGGL(sum_partials, dim3(1), dim3(256), 0, s, lvl, (int)n, result_dev);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+static long checksum_scratch_doubles(int nx, int nyb)
+{
+    const int segs = (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
+    const long n1 = (long)segs * nyb;
+    return n1 + (n1 + 4095) / 4096 + 1;
+}
+
+static double *g_cs_scratch = nullptr;   // grows with the largest box seen (g_scratch_mu)
+static long g_cs_scratch_n = 0;
 
 extern "C" int dlesm_checksum_f64(const double *f, int ld, int ny, int xstart, int xstop, int ystart,
                                   int ystop, double *result, void *stream)
@@ -1277,10 +1409,23 @@ extern "C" int dlesm_checksum_f64(const double *f, int ld, int ny, int xstart, i
     }
     if (int rc = check_box("dlesm_checksum_f64", ld, ny, xstart, xstop, ystart, ystop, 0)) return rc;
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    if (!g_partials) DLESM_HIP_TRY(hipMalloc((void **)&g_partials, (kMaxPartials + 1) * sizeof(double)));
     const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
-    const int blocks = nyb < kMaxPartials ? nyb : kMaxPartials;
     hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)f % 16 == 0 && tuning("util_rowseg", 1)) {
+        const long need = checksum_scratch_doubles(nx, nyb);
+        if (need > g_cs_scratch_n) {
+            if (g_cs_scratch) DLESM_HIP_TRY(hipFree(g_cs_scratch));      // (synchronises: nothing of ours is in flight under the lock)
+            g_cs_scratch = nullptr, g_cs_scratch_n = 0;
+            DLESM_HIP_TRY(hipMalloc((void **)&g_cs_scratch, (size_t)need * sizeof(double)));
+            g_cs_scratch_n = need;
+        }
+        if (int rc = enqueue_checksum(f, ld, xstart - 1, ystart - 1, nx, nyb, g_cs_scratch, g_cs_scratch + need - 1, s)) return rc;
+        DLESM_HIP_TRY(hipMemcpyAsync(result, g_cs_scratch + need - 1, sizeof(double), hipMemcpyDeviceToHost, s));
+        DLESM_HIP_TRY(hipStreamSynchronize(s));
+        return DLESM_OK;
+    }
+    if (!g_partials) DLESM_HIP_TRY(hipMalloc((void **)&g_partials, (kMaxPartials + 1) * sizeof(double)));
+    const int blocks = nyb < kMaxPartials ? nyb : kMaxPartials;
     hipLaunchKernelGGL(abs_sum_rows, dim3(blocks), dim3(256), 0, s, f, ld, xstart - 1, ystart - 1, nx, nyb,
                        g_partials);
     hipLaunchKernelGGL(sum_partials, dim3(1), dim3(256), 0, s, g_partials, blocks, g_partials + kMaxPartials);
@@ -1288,4 +1433,28 @@ extern "C" int dlesm_checksum_f64(const double *f, int ld, int ny, int xstart, i
     DLESM_HIP_TRY(hipMemcpyAsync(result, g_partials + kMaxPartials, sizeof(double), hipMemcpyDeviceToHost, s));
     DLESM_HIP_TRY(hipStreamSynchronize(s));
     return DLESM_OK;
+}
+
+// The same sum WITHOUT a host synchronisation: *result_dev (device memory, or host memory the device can write:
+// hipHostMalloc) receives the value when `stream` gets there.  What a time loop that logs a checksum every few steps
+// wants: no pipeline drain per check; read the values after the loop's own synchronisation.  Deterministic, and equal
+// to dlesm_checksum_f64 bit for bit.  The scratch space is stream-ordered (hipMallocAsync / hipFreeAsync).
+extern "C" int dlesm_checksum_async_f64(const double *f, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                                        double *result_dev, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(f != nullptr && result_dev != nullptr, "null pointer");
+    DLESM_REQUIRE((uintptr_t)f % 16 == 0, "dlesm_checksum_async_f64: field not 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (xstop < xstart || ystop < ystart) {
+        DLESM_HIP_TRY(hipMemsetAsync(result_dev, 0, sizeof(double), s));
+        return DLESM_OK;
+    }
+    if (int rc = check_box("dlesm_checksum_async_f64", ld, ny, xstart, xstop, ystart, ystop, 0)) return rc;
+    const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
+    double *scratch = nullptr;
+    DLESM_HIP_TRY(hipMallocAsync((void **)&scratch, (size_t)checksum_scratch_doubles(nx, nyb) * sizeof(double), s));
+    const int rc = enqueue_checksum(f, ld, xstart - 1, ystart - 1, nx, nyb, scratch, result_dev, s);
+    DLESM_HIP_TRY(hipFreeAsync(scratch, s));
+    return rc;
 }

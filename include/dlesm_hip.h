@@ -385,6 +385,12 @@ int dlesm_fill_f64(double *f, int ld, int ny, int xstart, int xstop, int ystart,
  * Synchronous: returns the value in *result (host). Deterministic tree order. */
 int dlesm_checksum_f64(const double *f, int ld, int ny, int xstart, int xstop,
                        int ystart, int ystop, double *result, void *stream);
+/* The same sum with NO host synchronisation: *result_dev -- device memory, or host memory the device can write
+ * (hipHostMalloc) -- receives the value when `stream` gets there; bit-identical to dlesm_checksum_f64.  For time
+ * loops that record a checksum every few steps (field_checksum of field_mod.f90:1209-1219 costs the reference a
+ * full device-to-host copy of the field per call, :538); combine across ranks afterwards (dlesm_global_sum_f64). */
+int dlesm_checksum_async_f64(const double *f, int ld, int ny, int xstart, int xstop,
+                             int ystart, int ystop, double *result_dev, void *stream);
 /* synthetic initial condition of BASELINE.md: f(i,j) = u01(splitmix64(seed ^ (gi + gj<<32)))
  * on the box, gi = gx0+i-1, gj = gy0+j-1; cells outside the box are left alone. */
 int dlesm_hash_init_f64(double *f, int ld, int ny, int xstart, int xstop, int ystart, int ystop,

@@ -64,6 +64,9 @@ timed("set_field (fill)", lambda: D.set_field(b, 1.0, stream=s), 8)
 timed("hash_init", lambda: D.psy.hash_init(b, 7, stream=s), 8)
 timed("field_checksum (device part + 8 B to host)", lambda: L.dlesm_checksum_f64(
     a.device_ptr, g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop, C.byref(val), sp), 8, n=10)
+res_dev = torch.zeros(1, dtype=torch.float64, device="cuda")
+timed("field_checksum, no host synchronisation (async entry)", lambda: L.dlesm_checksum_async_f64(
+    a.device_ptr, g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop, C.c_void_p(res_dev.data_ptr()), sp), 8)
 timed("gather: pack_inner", lambda: L.dlesm_pack_inner_f64(
     a.device_ptr, g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop, C.c_void_p(send.data_ptr()), slot, sp), 16)
 timed("gather: unpack_gathered (1 rank)", lambda: L.dlesm_unpack_gathered_f64(

@@ -266,6 +266,42 @@ def test_checksum_matches_oracle(D, nx, ny, alignment):
     want = O.lib().orc_checksum(f.get_data(), g.nx, it.xstart, it.xstop, it.ystart, it.ystop)
     got = D.field_checksum(f)
     assert abs(got - want) <= 1e-12 * abs(want)
+    # the form without a host synchronisation leaves the SAME bits in device memory; so does the older whole-row form
+    import torch
+    L = D._cabi.lib()
+    r = torch.full((3,), -1.0, dtype=torch.float64, device="cuda")
+    for k, box in enumerate((it.box(), (it.xstart + 1, it.xstop - 1, it.ystart, it.ystart), (5, 4, 2, 3))):
+        D._cabi.check(L.dlesm_checksum_async_f64(f.device_ptr, g.nx, g.ny, *box, C.c_void_p(r.data_ptr() + 8 * k), None))
+    torch.cuda.synchronize()
+    assert float(r[0]) == got and float(r[2]) == 0.0
+    one_row = f.get_data()[it.ystart - 1, it.xstart:it.xstop - 1]
+    assert abs(float(r[1]) - float(np.abs(one_row).sum())) <= 1e-12 * max(1.0, float(np.abs(one_row).sum()))
+    _set_tuning(D, util_rowseg=0)
+    assert abs(D.field_checksum(f) - want) <= 1e-12 * abs(want)
+    _set_tuning(D, util_rowseg=1)
+
+
+@pytest.mark.parametrize("ld,ny,box", [(40, 31, (1, 40, 1, 31)), (37, 12, (2, 36, 3, 11)), (4163, 7, (2, 4162, 1, 7)),
+                                       (4163, 7, (3, 4100, 2, 6)), (6000, 5, (1, 6000, 2, 4)), (2051, 9, (2, 2050, 2, 8))])
+@pytest.mark.parametrize("rowseg", [1, 0])
+def test_fill_and_hash_init_on_ragged_boxes(D, ld, ny, box, rowseg):
+    """set_field / the synthetic initial condition restricted to a box (row segments of 16-byte pairs with the odd
+    element before / after them, and the older 8-byte form): exactly the box is written, with the right values, on odd
+    and even leading dimensions, boxes that start on odd and even elements and span several 16 KB segments"""
+    import torch
+    L = D._cabi.lib()
+    _set_tuning(D, util_rowseg=rowseg)
+    xs, xe, ys, ye = box
+    t = torch.full((ny, ld), -2.0, dtype=torch.float64, device="cuda")
+    D._cabi.check(L.dlesm_fill_f64(C.c_void_p(t.data_ptr()), ld, ny, xs, xe, ys, ye, 3.25, None))
+    want = np.full((ny, ld), -2.0)
+    want[ys - 1:ye, xs - 1:xe] = 3.25
+    assert np.array_equal(t.cpu().numpy(), want)
+    D._cabi.check(L.dlesm_hash_init_f64(C.c_void_p(t.data_ptr()), ld, ny, xs, xe, ys, ye, SEED + 3, 7, -2, None))
+    hf = O.hash_field(SEED + 3, ny, ld, 7, -2 % 2 ** 64, xs, xe, ys, ye)
+    want[ys - 1:ye, xs - 1:xe] = hf[ys - 1:ye, xs - 1:xe]
+    assert np.array_equal(t.cpu().numpy(), want)
+    _set_tuning(D, util_rowseg=1)
 
 
 def test_config1_plumbing_matches_reference_golden(D):
@@ -299,7 +335,31 @@ def test_scatter_gather_matches_reference_golden(D):
         assert list(back.shape[::-1]) == m["gather_shape"] and np.array_equal(back, glob)
 
 
-@pytest.mark.parametrize("nx,ny,nranks", [(10, 10, 4), (10, 10, 6), (37, 29, 6), (64, 48, 8), (13, 13, 9)])
+@pytest.mark.parametrize("alignment", [None, 8])
+def test_one_rank_gather_of_a_field_whose_internal_region_is_not_the_domain(D, alignment):
+    """gather_inner_data on one rank copies WHATEVER internal region the field has into the top-left corner of the
+    global array (field_mod.f90:1332-1343): an SW-offset U field with external boundaries starts one column further
+    east (xstart + 1, field_mod.f90:724-725), so its internal region is narrower than the domain; a GO_ALL_POINTS
+    field (larger than the domain: the reference would write out of bounds) is refused"""
+    g = _grid(D, 12, 9, alignment, offset=D.GO_OFFSET_SW, bc=(1, 1, 2))
+    u = D.r2d_field(g, D.GO_U_POINTS)
+    it = u.internal
+    assert (it.xstart, it.nx) == (g.subdomain.internal.xstart + 1, 11)
+    D.psy.hash_init(u, SEED + 5)
+    h = u.get_data()
+    want = np.zeros((9, 12))
+    want[:it.ny, :it.nx] = h[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop]
+    assert np.array_equal(u.gather_inner_data(), want)
+    t = D.r2d_field(g, D.GO_T_POINTS)                      # the whole-domain case still round-trips
+    D.psy.hash_init(t, SEED + 6)
+    ht = t.get_data()
+    assert np.array_equal(t.gather_inner_data(), ht[t.internal.ystart - 1:t.internal.ystop, t.internal.xstart - 1:t.internal.xstop])
+    a = D.r2d_field(g, D.GO_ALL_POINTS)
+    with pytest.raises(D.DlesmError):
+        a.gather_inner_data()
+
+
+@pytest.mark.parametrize("nx,ny,nranks", [(10, 10, 4), (10, 10, 6), (37, 29, 6), (64, 48, 8), (13, 13, 9), (4500, 40, 2)])
 def test_device_gather_pack_and_unpack_for_uneven_tiles(D, nx, ny, nranks):
     """gather_inner_data's device legs for 4-9 ranks on one GPU: every rank's internal region packed
     into its fixed-size slot (dlesm_pack_inner_f64, the slot is the LARGEST tile: tiles are uneven,
