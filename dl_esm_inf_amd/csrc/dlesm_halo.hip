@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "dlesm_internal.h"
+#include "dlesm_device.h"
 
 using namespace dlesm;
 
@@ -1032,43 +1033,46 @@ __global__ void pack_inner_k(const double *__restrict__ f, int ld, int x0, int y
 
 struct GBox { int x0, y0, w, h; };            // 0-based origin in the global array, extent
 
-// Round 3: both copies as ROW SEGMENTS (the shape of rowseg_write_k, dlesm_kernels.hip): one workgroup = 16 KB of one
-// row, four 16-byte pairs per thread anchored on the 16-byte boundaries of the DESTINATION row (the source is read
-// with 16-byte loads at whatever 8-byte alignment it has), work items numbered row-major, so that workgroups sweep
-// both arrays front to back.  The forms above (a workgroup per row, 8-byte lanes: 66 % of the HBM peak at 16384^2)
-// remain for unaligned base pointers.
-constexpr int SEG_PAIRS = 1024;
-typedef double d2v __attribute__((ext_vector_type(2)));
-typedef double d2v8 __attribute__((ext_vector_type(2), aligned(8)));
+// Round 3: both copies as ROW SEGMENTS (dlesm_device.h): pairs anchored on the 128-byte lines of the DESTINATION row (the
+// source is read with 16-byte loads at whatever 8-byte alignment it has), all four loads of a lane issued before its
+// first store, work items numbered row-major so that workgroups sweep both arrays front to back.  The forms above (a
+// workgroup per row, 8-byte lanes: 66 % of the HBM peak at 16384^2) remain for unaligned bases and tiny rows.
+// Segments of 256 pairs (one per thread) measured 72-73 % for both copies at 16384^2 against 68 % with 1024
+// (scripts/segp_probe.py); the read-only checksum is the other way round (81 % with 1024, 60 % with 256).
+typedef rs_d2 d2v;
 
-// dst_row[0 .. n) <- src_row[0 .. n), segment sg of the row
-__device__ __forceinline__ void copy_row_segment(const double *__restrict__ src, double *__restrict__ dst, int n, int sg,
-                                                 int segs, bool nt)
+// dst[d0 .. d0+n) <- src[s0 .. s0+n) (element offsets from the array bases), segment sg of that row; n >= ROWSEG_MIN_NX
+__device__ __forceinline__ void copy_row_segment(const double *__restrict__ src, long s0, double *__restrict__ dst, long d0,
+                                                 int n, int sg, int segp, bool nt)
 {
-    const int head = (int)(((uintptr_t)dst >> 3) & 1);
-    const int npairs = (n - head) / 2, tail = (n - head) & 1;
-    if (threadIdx.x == 0) {
-        if (sg == 0 && head && n > 0) dst[0] = src[0];
-        if (sg == segs - 1 && tail) dst[n - 1] = src[n - 1];
-    }
+    const long e0 = d0, e1 = d0 + n - 1, shift = s0 - d0;
+    const long safe = (e0 + 1) & ~1L;                    // a destination pair wholly inside the row
+    RowPair pr[4];
+    d2v v[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int p = sg * SEG_PAIRS + threadIdx.x + 256 * k;
-        if (p < npairs) {
-            const d2v v = *(const d2v8 *)(src + head + 2 * p);
-            if (nt) __builtin_nontemporal_store(v, (d2v *)(dst + head + 2 * p));
-            else *(d2v *)(dst + head + 2 * p) = v;
-        }
+        pr[k] = rowseg_pair(e0, e1, sg, segp, threadIdx.x, k);
+        v[k] = *(const rs_d2a8 *)(src + shift + (pr[k].full() ? pr[k].el : safe));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = d2v{pin_here(v[k].x), pin_here(v[k].y)};     // all four loads before the first store
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (pr[k].full()) {
+            if (nt) __builtin_nontemporal_store(v[k], (d2v *)(dst + pr[k].el));
+            else *(d2v *)(dst + pr[k].el) = v[k];
+        } else if (pr[k].m0) dst[pr[k].el] = src[shift + pr[k].el];
+        else if (pr[k].m1) dst[pr[k].el + 1] = src[shift + pr[k].el + 1];
     }
 }
 
 __global__ __launch_bounds__(256) void pack_inner_rowseg(const double *__restrict__ f, int ld, int x0, int y0, int nx, int h,
-                                                         int segs, long slot, double *__restrict__ send, bool nt)
+                                                         int segs, int segp, long slot, double *__restrict__ send, bool nt)
 {
     const long items = (long)segs * h;
     if ((long)blockIdx.x < items) {
         const int j = blockIdx.x / segs, sg = blockIdx.x - j * segs;
-        copy_row_segment(f + (size_t)(y0 + j) * ld + x0, send + (size_t)j * nx, nx, sg, segs, nt);
+        copy_row_segment(f, (long)(y0 + j) * ld + x0, send, (long)j * nx, nx, sg, segp, nt);
         return;
     }
     // the rest of the slot (tiles are uneven): zeroed by the workgroups behind the copy
@@ -1078,17 +1082,15 @@ __global__ __launch_bounds__(256) void pack_inner_rowseg(const double *__restric
         if (t + 256 * k < slot) send[t + 256 * k] = 0.0;
 }
 
+// grid.x = segments of the WIDEST box x rows of the tallest one, grid.y = rank: narrower / shorter boxes leave early
 __global__ __launch_bounds__(256) void unpack_gathered_rowseg(const double *__restrict__ recv, long slot,
-                                                              const GBox *__restrict__ boxes, int gnx, int segs,
+                                                              const GBox *__restrict__ boxes, int gnx, int segs, int segp,
                                                               double *__restrict__ global, bool nt)
 {
     const GBox b = boxes[blockIdx.y];
     const int j = blockIdx.x / segs, sg = blockIdx.x - j * segs;
-    if (j >= b.h || sg * 2 * SEG_PAIRS >= b.w + 1) return;
-    const int bsegs = ((b.w + 1) / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? ((b.w + 1) / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
-    if (sg >= bsegs) return;
-    copy_row_segment(recv + (size_t)blockIdx.y * slot + (size_t)j * b.w, global + (size_t)(b.y0 + j) * gnx + b.x0, b.w, sg,
-                     bsegs, nt);
+    if (j >= b.h || b.w < ROWSEG_MIN_NX) return;             // (boxes narrower than that: see the host side)
+    copy_row_segment(recv, (long)blockIdx.y * slot + (long)j * b.w, global, (long)(b.y0 + j) * gnx + b.x0, b.w, sg, segp, nt);
 }
 
 // grid.y = rank; j outer / i inner as field_mod.f90:1376-1386
@@ -1114,12 +1116,13 @@ extern "C" int dlesm_pack_inner_f64(const double *field, int ld, int ny, int xst
     const long n = nx > 0 && h > 0 ? (long)nx * h : 0;
     DLESM_REQUIRE(slot >= n, "slot of %ld doubles for a %dx%d region", slot, nx, h);
     if (slot == 0) return DLESM_OK;
-    if ((uintptr_t)field % 8 == 0 && (uintptr_t)send % 16 == 0 && tuning("util_rowseg", 1)) {
-        const int segs = n > 0 ? (((nx + 1) / 2 + SEG_PAIRS - 1) / SEG_PAIRS) : 0;
-        const long items = (long)segs * (n > 0 ? h : 0), zero_blocks = (slot - n + 1023) / 1024;
+    if ((uintptr_t)field % 8 == 0 && (uintptr_t)send % 16 == 0 && (n == 0 || nx >= ROWSEG_MIN_NX) && tuning("util_rowseg", 1)) {
+        int segs = 1, segp = 64;
+        if (n > 0) rowseg_split(nx, tuning("util_segp", 256), &segs, &segp);
+        const long items = n > 0 ? (long)segs * h : 0, zero_blocks = (slot - n + 1023) / 1024;
         if (items + zero_blocks < (1L << 31)) {
             hipLaunchKernelGGL(pack_inner_rowseg, dim3((unsigned)(items + zero_blocks)), dim3(256), 0, (hipStream_t)stream, field,
-                               ld, xstart - 1, ystart - 1, n > 0 ? nx : 0, n > 0 ? h : 0, segs > 0 ? segs : 1, slot, send,
+                               ld, xstart - 1, ystart - 1, n > 0 ? nx : 0, n > 0 ? h : 0, segs, segp, slot, send,
                                nt_stores_for(nx, 0, h - 1) != 0);
             DLESM_HIP_TRY(hipGetLastError());
             return DLESM_OK;
@@ -1162,10 +1165,14 @@ extern "C" int dlesm_unpack_gathered_f64(const double *recv, long slot, const dl
     if (e == hipSuccess) {
         int widest_w = 0;
         for (const GBox &b : boxes) widest_w = b.w > widest_w ? b.w : widest_w;
-        const int segs = ((widest_w + 1) / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? ((widest_w + 1) / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
-        if ((uintptr_t)recv % 8 == 0 && (uintptr_t)global % 16 == 0 && (long)segs * tallest < (1L << 31) && tuning("util_rowseg", 1)) {
+        int segs, segp, narrowest_w = widest_w;
+        for (const GBox &b : boxes)
+            if (b.w > 0 && b.h > 0 && b.w < narrowest_w) narrowest_w = b.w;
+        rowseg_split(widest_w, tuning("util_segp", 256), &segs, &segp);
+        if ((uintptr_t)recv % 8 == 0 && (uintptr_t)global % 16 == 0 && narrowest_w >= ROWSEG_MIN_NX &&
+            (long)segs * tallest < (1L << 31) && tuning("util_rowseg", 1)) {
             hipLaunchKernelGGL(unpack_gathered_rowseg, dim3((unsigned)((long)segs * tallest), (unsigned)nranks), dim3(256), 0, s, recv,
-                               slot, dboxes, d->global_nx, segs, global, nt_stores_for(d->global_nx, 0, d->global_ny - 1) != 0);
+                               slot, dboxes, d->global_nx, segs, segp, global, nt_stores_for(d->global_nx, 0, d->global_ny - 1) != 0);
         } else {
             long gx = tallest;
             if (gx > 2048) gx = 2048;

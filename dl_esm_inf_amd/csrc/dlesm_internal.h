@@ -66,6 +66,18 @@ __device__ __forceinline__ double from_upper(double x)
     }
 }
 
+// The value unchanged, through a CONVERGENT operation (a DPP move with the identity lane pattern quad_perm:[0,1,2,3]).
+// Code motion may not make a convergent operation control-dependent on a lane-varying condition, so whatever feeds
+// pin_here() -- in particular the LOADS behind it -- cannot be sunk into the masked store branches of a kernel: without
+// it the compiler moves a load whose only use is a conditional store into that branch, and a lane's loads are issued
+// one dependent round trip after the other instead of all together (seen in the ISA of the gather copies and of the
+// old-level loads of the shallow-water step).
+__device__ __forceinline__ double pin_here(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), 0xE4, 0xf, 0xf, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(x), 0xE4, 0xf, 0xf, true));
+}
+
 // shared by the frame/interior split of the distributed step (dlesm_halo.hip)
 int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, int xstop,
                     int ystart, int ystop, hipStream_t s);

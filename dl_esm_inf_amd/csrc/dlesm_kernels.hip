@@ -954,38 +954,37 @@ __global__ void fill_k(double *__restrict__ f, int ld, int x0, int y0, int nx, i
             f[(size_t)(y0 + j) * ld + x0 + i] = value;
 }
 
-// A box swept as ROW SEGMENTS (round 3; the forms above remain for unaligned base pointers): one workgroup = 16 KB of
-// one row of the box -- SEG_PAIRS 16-byte pairs, four per thread, anchored on the 16-byte boundaries of that row, the
-// unpaired element before / after them taken by thread 0 of the row's first / last segment -- numbered row-major,
-// so that workgroups, dispatched in index order and short-lived, sweep memory front to back like the linear copy that
-// sets the measured ceiling.  The earlier forms gave every workgroup whole rows (thousands of concurrent row fronts,
-// 8-byte lanes): 64-71 % of the HBM peak at 16384^2 (profiles/r02_aux_kernels.txt).
-constexpr int SEG_PAIRS = 1024;
-typedef double d2u __attribute__((ext_vector_type(2)));
+// Round 3: the utility sweeps as ROW SEGMENTS (dlesm_device.h); the forms above remain for unaligned base pointers and
+// rows of a few elements.  The earlier forms gave every workgroup whole rows (thousands of concurrent row fronts, 8-byte
+// lanes): 64-71 % of the HBM peak at 16384^2 (profiles/r02_aux_kernels.txt).
+typedef rs_d2 d2u;
+
+// the same value into n2 16-byte elements of contiguous memory: whole rows (set_field of a field) are one block
+__global__ __launch_bounds__(256) void fill_linear_k(double *__restrict__ f, size_t n2, double value, bool nt)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    if (nt) __builtin_nontemporal_store(d2u{value, value}, (d2u *)f + i);
+    else ((d2u *)f)[i] = d2u{value, value};
+}
 
 template <class GEN>   // GEN(i, j) -> value of element (0-based column i, row j)
-__global__ __launch_bounds__(256) void rowseg_write_k(double *__restrict__ f, int ld, int x0, int y0, int nx, int segs, bool nt,
-                                                      GEN gen)
+__global__ __launch_bounds__(256) void rowseg_write_k(double *__restrict__ f, int ld, int x0, int y0, int nx, int segs, int segp,
+                                                      bool nt, GEN gen)
 {
     const int jr = blockIdx.x / segs, sg = blockIdx.x - jr * segs, j = y0 + jr;
-    const size_t row = (size_t)j * ld;
-    const int head = (int)((row + x0) & 1);
-    const int npairs = (nx - head) / 2, tail = (nx - head) & 1;
-    double *r = f + row + x0;
-    if (threadIdx.x == 0) {
-        if (sg == 0 && head) r[0] = gen(x0, j);
-        if (sg == segs - 1 && tail) r[nx - 1] = gen(x0 + nx - 1, j);
-    }
-    d2u *rv = (d2u *)(r + head);
+    const long row = (long)j * ld, e0 = row + x0, e1 = e0 + nx - 1;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int p = sg * SEG_PAIRS + threadIdx.x + 256 * k;
-        if (p < npairs) {
-            const int i = x0 + head + 2 * p;
+        const RowPair pr = rowseg_pair(e0, e1, sg, segp, threadIdx.x, k);
+        if (!pr.any()) continue;
+        const int i = (int)(pr.el - row);
+        if (pr.full()) {
             const d2u v = d2u{gen(i, j), gen(i + 1, j)};
-            if (nt) __builtin_nontemporal_store(v, rv + p);
-            else rv[p] = v;
-        }
+            if (nt) __builtin_nontemporal_store(v, (d2u *)(f + pr.el));
+            else *(d2u *)(f + pr.el) = v;
+        } else if (pr.m0) f[pr.el] = gen(i, j);
+        else f[pr.el + 1] = gen(i + 1, j);
     }
 }
 struct GenConst {
@@ -1078,33 +1077,30 @@ __global__ __launch_bounds__(256) void abs_sum_rows(const double *__restrict__ f
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
-// the same sum as row segments (one partial per workgroup = per 16 KB of a row; see rowseg_write_k): the additions
-// happen in an order fixed by (ld, box) alone, so the result is deterministic run to run
+// the same sum as row segments (one partial per workgroup = per segment of a row; dlesm_device.h): the additions happen
+// in an order fixed by (ld, box) alone, so the result is deterministic run to run.  All four 16-byte loads of a lane are
+// issued before the first use (a pair that is not wholly inside the box reads the row's first whole pair instead and is
+// fixed up from scalar loads: only the two ends of a row have such pairs).
 __global__ __launch_bounds__(256) void abs_sum_rowseg(const double *__restrict__ f, int ld, int x0, int y0, int nx, int segs,
-                                                      double *__restrict__ partial)
+                                                      int segp, double *__restrict__ partial)
 {
     const int jr = blockIdx.x / segs, sg = blockIdx.x - jr * segs;
-    const size_t row = (size_t)(y0 + jr) * ld;
-    const int head = (int)((row + x0) & 1);
-    const int npairs = (nx - head) / 2, tail = (nx - head) & 1;
-    const double *r = f + row + x0;
-    double acc0 = 0.0, acc1 = 0.0;
-    if (threadIdx.x == 0) {
-        if (sg == 0 && head) acc0 += fabs(r[0]);
-        if (sg == segs - 1 && tail) acc1 += fabs(r[nx - 1]);
-    }
-    const d2u *rv = (const d2u *)(r + head);
+    const long row = (long)(y0 + jr) * ld, e0 = row + x0, e1 = e0 + nx - 1;
+    const long safe = (e0 + 1) & ~1L;                    // a pair wholly inside the row's part of the box (nx >= 3)
+    RowPair pr[4];
     d2u v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {                        // four 16-byte loads in flight per lane, each read once
-        const int p = sg * SEG_PAIRS + threadIdx.x + 256 * k;
-        v[k] = p < npairs ? __builtin_nontemporal_load(rv + p) : d2u{0.0, 0.0};
+    for (int k = 0; k < 4; k++) {
+        pr[k] = rowseg_pair(e0, e1, sg, segp, threadIdx.x, k);
+        v[k] = __builtin_nontemporal_load((const d2u *)(f + (pr[k].full() ? pr[k].el : safe)));
     }
-    acc0 += fabs(v[0].x) + fabs(v[0].y);
-    acc1 += fabs(v[1].x) + fabs(v[1].y);
-    acc0 += fabs(v[2].x) + fabs(v[2].y);
-    acc1 += fabs(v[3].x) + fabs(v[3].y);
-    const double acc = block_sum_256(acc0 + acc1);
+    double a[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        a[k] = pr[k].full() ? fabs(v[k].x) + fabs(v[k].y) : 0.0;
+        if (pr[k].any() && !pr[k].full()) a[k] = fabs(f[pr[k].m0 ? pr[k].el : pr[k].el + 1]);
+    }
+    const double acc = block_sum_256((a[0] + a[2]) + (a[1] + a[3]));
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
@@ -1336,10 +1332,16 @@ extern "C" int dlesm_fill_f64(double *f, int ld, int ny, int xstart, int xstop, 
     if (xstop < xstart || ystop < ystart) return DLESM_OK;
     if (int rc = check_box("dlesm_fill_f64", ld, ny, xstart, xstop, ystart, ystop, 0)) return rc;
     const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
-    const int segs = (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
-    if ((uintptr_t)f % 16 == 0 && (long)segs * nyb < (1L << 31) && tuning("util_rowseg", 1))
+    int segs, segp;
+    rowseg_split(nx, tuning("util_segp", SEG_PAIRS), &segs, &segp);
+    const size_t n = (size_t)nx * nyb;
+    double *f0 = f + lin(ld, xstart, ystart);
+    if (nx == ld && n % 2 == 0 && (uintptr_t)f0 % 16 == 0 && n / 2 < ((size_t)1 << 31) * 256 && tuning("util_rowseg", 1))
+        hipLaunchKernelGGL(fill_linear_k, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f0, n / 2, value,
+                           nt_stores_for(ld, ystart - 1, ystop - 1) != 0);
+    else if ((uintptr_t)f % 16 == 0 && nx >= ROWSEG_MIN_NX && (long)segs * nyb < (1L << 31) && tuning("util_rowseg", 1))
         hipLaunchKernelGGL((rowseg_write_k<GenConst>), dim3((unsigned)((long)segs * nyb)), dim3(256), 0, (hipStream_t)stream, f, ld,
-                           xstart - 1, ystart - 1, nx, segs, nt_stores_for(ld, ystart - 1, ystop - 1) != 0, GenConst{value});
+                           xstart - 1, ystart - 1, nx, segs, segp, nt_stores_for(ld, ystart - 1, ystop - 1) != 0, GenConst{value});
     else
         hipLaunchKernelGGL(fill_k, grid2d(nx, nyb), dim3(256), 0, (hipStream_t)stream, f, ld, xstart - 1,
                            ystart - 1, nx, nyb, value);
@@ -1355,10 +1357,11 @@ extern "C" int dlesm_hash_init_f64(double *f, int ld, int ny, int xstart, int xs
     if (xstop < xstart || ystop < ystart) return DLESM_OK;
     if (int rc = check_box("dlesm_hash_init_f64", ld, ny, xstart, xstop, ystart, ystop, 0)) return rc;
     const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
-    const int segs = (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
-    if ((uintptr_t)f % 16 == 0 && (long)segs * nyb < (1L << 31) && tuning("util_rowseg", 1))
+    int segs, segp;
+    rowseg_split(nx, tuning("util_segp", SEG_PAIRS), &segs, &segp);
+    if ((uintptr_t)f % 16 == 0 && nx >= ROWSEG_MIN_NX && (long)segs * nyb < (1L << 31) && tuning("util_rowseg", 1))
         hipLaunchKernelGGL((rowseg_write_k<GenHash>), dim3((unsigned)((long)segs * nyb)), dim3(256), 0, (hipStream_t)stream, f, ld,
-                           xstart - 1, ystart - 1, nx, segs, nt_stores_for(ld, ystart - 1, ystop - 1) != 0,
+                           xstart - 1, ystart - 1, nx, segs, segp, nt_stores_for(ld, ystart - 1, ystop - 1) != 0,
                            GenHash{seed, gx0, gy0});
     else
         hipLaunchKernelGGL(hash_init_k, grid2d(nx, nyb), dim3(256), 0, (hipStream_t)stream, f, ld, xstart - 1,
@@ -1372,9 +1375,17 @@ extern "C" int dlesm_hash_init_f64(double *f, int ld, int ny, int xstart, int xs
 static int enqueue_checksum(const double *f, int ld, int x0, int y0, int nx, int nyb, double *scratch, double *result_dev,
                             hipStream_t s)
 {
-    const int segs = (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
+    if (nx < ROWSEG_MIN_NX) {                                // a few columns: the whole-row form
+        const int blocks = nyb < kMaxPartials ? nyb : kMaxPartials;
+        hipLaunchKernelGGL(abs_sum_rows, dim3(blocks), dim3(256), 0, s, f, ld, x0, y0, nx, nyb, scratch);
+        hipLaunchKernelGGL(sum_partials, dim3(1), dim3(256), 0, s, scratch, blocks, result_dev);
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
+    int segs, segp;
+    rowseg_split(nx, tuning("util_segp", SEG_PAIRS), &segs, &segp);
     const long n1 = (long)segs * nyb;
-    hipLaunchKernelGGL(abs_sum_rowseg, dim3((unsigned)n1), dim3(256), 0, s, f, ld, x0, y0, nx, segs, scratch);
+    hipLaunchKernelGGL(abs_sum_rowseg, dim3((unsigned)n1), dim3(256), 0, s, f, ld, x0, y0, nx, segs, segp, scratch);
     const double *lvl = scratch;
     long n = n1;
     if (n > 4096) {
@@ -1390,9 +1401,11 @@ static int enqueue_checksum(const double *f, int ld, int x0, int y0, int nx, int
 }
 static long checksum_scratch_doubles(int nx, int nyb)
 {
-    const int segs = (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS > 0 ? (nx / 2 + SEG_PAIRS - 1) / SEG_PAIRS : 1;
+    int segs, segp;
+    rowseg_split(nx, tuning("util_segp", SEG_PAIRS), &segs, &segp);
     const long n1 = (long)segs * nyb;
-    return n1 + (n1 + 4095) / 4096 + 1;
+    const long need = n1 + (n1 + 4095) / 4096 + 1;
+    return need > kMaxPartials + 1 ? need : kMaxPartials + 1;
 }
 
 static double *g_cs_scratch = nullptr;   // grows with the largest box seen (g_scratch_mu)

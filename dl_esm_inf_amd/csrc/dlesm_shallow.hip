@@ -50,14 +50,7 @@ template <bool DPP> __device__ __forceinline__ V2 east_of(const V2 &a) { return 
 template <bool DPP> __device__ __forceinline__ V2 west_of(const V2 &a) { return V2{from_lower<DPP>(a.y), a.x}; }
 
 #define EW(expr_x, expr_y) V2{(expr_x), (expr_y)}
-// the value unchanged, through a CONVERGENT operation (a DPP move with the identity lane pattern quad_perm:[0,1,2,3]):
-// code motion may not make a convergent operation control-dependent on a lane-varying condition
-__device__ __forceinline__ double pin_here(double x)
-{
-    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), 0xE4, 0xf, 0xf, true),
-                            __builtin_amdgcn_mov_dpp(__double2loint(x), 0xE4, 0xf, 0xf, true));
-}
-__device__ __forceinline__ V2 pin_here(const V2 &a) { return V2{pin_here(a.x), pin_here(a.y)}; }
+__device__ __forceinline__ V2 pin_here(const V2 &a) { return V2{::dlesm::pin_here(a.x), ::dlesm::pin_here(a.y)}; }   // dlesm_internal.h
 // new time level stored non-temporally by default: +1.2 % at 8192^2 (profiles/r02_shallow_variants.txt)
 #define SW_NT_DEFAULT 2
 

@@ -61,6 +61,12 @@ timed("continuity (T, U, V fields + grid%area_t)", lambda: D.psy.invoke_continui
 del CF
 timed("copy_field (whole field)", lambda: D.copy_field(a, b, stream=s), 16)
 timed("set_field (fill)", lambda: D.set_field(b, 1.0, stream=s), 8)
+with torch.cuda.stream(s):
+    timed("  write-only reference: torch fill_ of the same array", lambda: b.data.fill_(1.0), 8 * g.nx * g.ny / cells)
+    timed("  write-only reference: torch zero_ (memset)", lambda: b.data.zero_(), 8 * g.nx * g.ny / cells)
+L.dlesm_set_tuning(b"j5_nt_stores", 0)
+timed("set_field, default stores", lambda: D.set_field(b, 1.0, stream=s), 8)
+L.dlesm_set_tuning(b"j5_nt_stores", -1)
 timed("hash_init", lambda: D.psy.hash_init(b, 7, stream=s), 8)
 timed("field_checksum (device part + 8 B to host)", lambda: L.dlesm_checksum_f64(
     a.device_ptr, g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop, C.byref(val), sp), 8, n=10)
@@ -69,5 +75,7 @@ timed("field_checksum, no host synchronisation (async entry)", lambda: L.dlesm_c
     a.device_ptr, g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop, C.c_void_p(res_dev.data_ptr()), sp), 8)
 timed("gather: pack_inner", lambda: L.dlesm_pack_inner_f64(
     a.device_ptr, g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop, C.c_void_p(send.data_ptr()), slot, sp), 16)
+timed("  pack of a box that starts on a 16-byte boundary", lambda: L.dlesm_pack_inner_f64(
+    a.device_ptr, g.nx, g.ny, 1, tile, it.ystart, it.ystop, C.c_void_p(send.data_ptr()), slot, sp), 16)
 timed("gather: unpack_gathered (1 rank)", lambda: L.dlesm_unpack_gathered_f64(
     C.c_void_p(send.data_ptr()), slot, C.byref(pd._info), pd.subdomains, 1, C.c_void_p(glob.data_ptr()), sp), 16, n=10)
