@@ -75,6 +75,12 @@ class CommTables(C.Structure):
                      nx=self.nxrecv[k], ny=self.nyrecv[k]) for k in range(self.nrecv)]
 
 
+class MsgDesc(C.Structure):
+    """dlesm_msg_desc: one ncclRecv / ncclSend of an exchange, in issue order"""
+    _fields_ = [(n, C.c_int) for n in ("is_recv", "peer", "dir", "field", "i0", "j0", "nx", "ny")] + \
+               [("count", C.c_long), ("buffer_offset", C.c_long)]
+
+
 class SwParams(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("fsdx", "fsdy", "tdts8", "tdtsdx", "tdtsdy")]
 
@@ -151,6 +157,7 @@ PROTOTYPES = {
     "dlesm_comm_size": (_i, []),
     "dlesm_halo_plan_create": (_i, [C.POINTER(CommTables), _i, _i, C.POINTER(_vp)]),
     "dlesm_halo_plan_destroy": (_i, [_vp]),
+    "dlesm_halo_plan_describe": (_i, [C.POINTER(CommTables), _i, _i, _i, C.c_uint, _i, C.POINTER(MsgDesc), _i, C.POINTER(_i)]),
     "dlesm_halo_exchange_f64": (_i, [_vp, _vp, C.c_uint, _vp]),
     "dlesm_halo_exchange_multi_f64": (_i, [_vp, C.POINTER(_vp), _i, C.c_uint, _vp]),
     "dlesm_jacobi5_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

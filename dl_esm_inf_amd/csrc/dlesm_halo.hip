@@ -142,6 +142,111 @@ __host__ __device__ static inline bool dir_enabled(unsigned mask, int dir)
     }
 }
 
+// ---- the host-only part of a plan: which messages, in which order, through which buffer slots ------------------
+// Everything RCCL is told comes from here, and dlesm_halo_plan_describe reports exactly this, so that the ordering
+// rule -- RCCL has no tags: between a pair of ranks the k-th send meets the k-th receive -- can be exercised by a
+// tag-free transport on the CPU (tests/gloo_worker.py) against the product's OWN lists, not a re-statement of them.
+struct MsgLists {
+    std::vector<Msg> sends, recvs;           // sorted by (peer, dir)
+    std::vector<Strip> spack, rpack;         // the strided strips of the single-field path, in list order
+    long sendbuf_len = 0, recvbuf_len = 0;   // doubles per field
+    int max_strip = 0;
+    std::vector<long> sagg, ragg;            // aggregated path: slot offset per message (doubles per field)
+    std::vector<Strip> sall, rall;
+    long sagg_len = 0, ragg_len = 0;
+    int max_msg = 0;
+};
+
+static bool by_peer_dir(const Msg &a, const Msg &b)
+{
+    return a.peer != b.peer ? a.peer < b.peer : a.dir < b.dir;
+}
+
+static int build_msg_lists(const dlesm_comm_tables *t, int ld, int ny, MsgLists &L)
+{
+    DLESM_REQUIRE(t != nullptr, "null pointer");
+    DLESM_REQUIRE(ld > 0 && ny > 0, "field extents %dx%d", ld, ny);
+    DLESM_REQUIRE(t->nsend >= 0 && t->nsend <= DLESM_MAXCOMM && t->nrecv >= 0 && t->nrecv <= DLESM_MAXCOMM,
+                  "message counts %d/%d", t->nsend, t->nrecv);
+    auto add = [&](std::vector<Msg> &list, int dir, int peer, int i1, int j1, int nx, int nyy) -> int {
+        if (peer < 0 || nx <= 0) return DLESM_OK; // skipped by the reference too (pcomms:1603,1639)
+        if (i1 < 1 || j1 < 1 || i1 + nx - 1 > ld || j1 + nyy - 1 > ny || nyy < 1)
+            return fail(DLESM_EINVAL, "message patch (%d,%d)+%dx%d outside field %dx%d", i1, j1, nx, nyy, ld, ny);
+        list.push_back(Msg{dir, peer, i1 - 1, j1 - 1, nx, nyy, (long)nx * nyy, -1});
+        return DLESM_OK;
+    };
+    for (int k = 0; k < t->nsend; k++)
+        if (int rc = add(L.sends, t->dirsend[k], t->destination[k], t->isrcsend[k], t->jsrcsend[k], t->nxsend[k], t->nysend[k]))
+            return rc;
+    for (int k = 0; k < t->nrecv; k++)
+        if (int rc = add(L.recvs, t->dirrecv[k], t->source[k], t->idesrecv[k], t->jdesrecv[k], t->nxrecv[k], t->nyrecv[k]))
+            return rc;
+    // pack-buffer slots of the strided strips are handed out in TABLE order (before the sort), as the reference
+    // numbers its buffers (parallel_comms_mod.f90:1664-1691); the lists are then sorted by (peer, direction)
+    auto slots = [&](std::vector<Msg> &list, std::vector<Strip> &pk, long &buflen) {
+        for (Msg &m : list)
+            if (m.ny > 1 && m.nx != ld) {        // rows of the patch are not adjacent in memory
+                m.off = buflen;
+                buflen += m.count;
+                if (m.count > L.max_strip) L.max_strip = (int)m.count;
+            }
+        std::stable_sort(list.begin(), list.end(), by_peer_dir);
+        for (const Msg &m : list)
+            if (m.off >= 0) pk.push_back(Strip{m.i0, m.j0, m.nx, m.ny, m.off, m.dir});
+    };
+    slots(L.sends, L.spack, L.sendbuf_len);
+    slots(L.recvs, L.rpack, L.recvbuf_len);
+    auto aggregate = [&](const std::vector<Msg> &list, std::vector<long> &agg, long &len, std::vector<Strip> &all) {
+        for (const Msg &m : list) {
+            agg.push_back(len);
+            all.push_back(Strip{m.i0, m.j0, m.nx, m.ny, len, m.dir});
+            len += (m.count + 15) & ~15L;                // every message starts on a 128-byte line
+            if (m.count > L.max_msg) L.max_msg = (int)m.count;
+        }
+    };
+    aggregate(L.sends, L.sagg, L.sagg_len, L.sall);
+    aggregate(L.recvs, L.ragg, L.ragg_len, L.rall);
+    return DLESM_OK;
+}
+
+// One ncclRecv / ncclSend of an exchange.  `off`: doubles from the start of the staging buffer (the receive buffer
+// for a receive, the send buffer for a send), or -1 when the message travels in place, at (i0, j0) of field `field`.
+struct Issue {
+    bool recv;
+    int peer, dir, field;          // field = -1: the message carries the strips of all nf fields, field after field
+    int i0, j0, nx, ny;            // 0-based strip
+    long count, off;
+};
+
+// The calls of ONE exchange of nf fields under `mask`, in issue order: the receives, then the sends (aggregated form);
+// per field the receives, then the sends (single-field form: field-major).  Within each group the order of the sorted
+// lists: ascending peer, then ascending direction code.  Disabled directions are left out.
+static void issue_list(const std::vector<Msg> &sends, const std::vector<Msg> &recvs, const std::vector<long> &sagg,
+                       const std::vector<long> &ragg, long sendbuf_len, long recvbuf_len, int nf, unsigned mask,
+                       bool aggregated, std::vector<Issue> &out)
+{
+    out.clear();
+    if (aggregated) {
+        for (size_t k = 0; k < recvs.size(); k++) {
+            const Msg &m = recvs[k];
+            if (dir_enabled(mask, m.dir)) out.push_back(Issue{true, m.peer, m.dir, -1, m.i0, m.j0, m.nx, m.ny, nf * m.count, nf * ragg[k]});
+        }
+        for (size_t k = 0; k < sends.size(); k++) {
+            const Msg &m = sends[k];
+            if (dir_enabled(mask, m.dir)) out.push_back(Issue{false, m.peer, m.dir, -1, m.i0, m.j0, m.nx, m.ny, nf * m.count, nf * sagg[k]});
+        }
+        return;
+    }
+    for (int f = 0; f < nf; f++) {
+        for (const Msg &m : recvs)
+            if (dir_enabled(mask, m.dir))
+                out.push_back(Issue{true, m.peer, m.dir, f, m.i0, m.j0, m.nx, m.ny, m.count, m.off >= 0 ? f * recvbuf_len + m.off : -1});
+        for (const Msg &m : sends)
+            if (dir_enabled(mask, m.dir))
+                out.push_back(Issue{false, m.peer, m.dir, f, m.i0, m.j0, m.nx, m.ny, m.count, m.off >= 0 ? f * sendbuf_len + m.off : -1});
+    }
+}
+
 // gather the strided strips into their slots: grid.y = strip, j outer / i inner
 // exactly like the pack loop of parallel_comms_mod.f90:1678-1683; strips of a direction the
 // mask disables are skipped (their workgroups leave at once)
@@ -240,63 +345,29 @@ extern "C" int dlesm_comm_size(void) { return g_size; }
 
 static int ensure_buffers(dlesm_halo_plan *p, int nfields, hipStream_t s = nullptr);
 
-static bool by_peer_dir(const Msg &a, const Msg &b)
-{
-    return a.peer != b.peer ? a.peer < b.peer : a.dir < b.dir;
-}
-
 extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny, dlesm_halo_plan **out)
 {
     DLESM_REQUIRE(t != nullptr && out != nullptr, "null pointer");
-    DLESM_REQUIRE(ld > 0 && ny > 0, "field extents %dx%d", ld, ny);
-    DLESM_REQUIRE(t->nsend >= 0 && t->nsend <= DLESM_MAXCOMM && t->nrecv >= 0 && t->nrecv <= DLESM_MAXCOMM,
-                  "message counts %d/%d", t->nsend, t->nrecv);
-    if (int rc = ensure_device()) return rc;
+    MsgLists L;
+    if (int rc0 = build_msg_lists(t, ld, ny, L)) return rc0;
+    if (int rc0 = ensure_device()) return rc0;
     dlesm_halo_plan *p = new dlesm_halo_plan;
     p->ld = ld;
     p->ny = ny;
-    std::vector<Strip> spack, rpack;
-    auto add = [&](std::vector<Msg> &list, std::vector<Strip> &pk, long &buflen, int dir, int peer, int i1,
-                   int j1, int nx, int nyy) -> int {
-        if (peer < 0 || nx <= 0) return DLESM_OK; // skipped by the reference too (pcomms:1603,1639)
-        if (i1 < 1 || j1 < 1 || i1 + nx - 1 > ld || j1 + nyy - 1 > ny || nyy < 1)
-            return fail(DLESM_EINVAL, "message patch (%d,%d)+%dx%d outside field %dx%d", i1, j1, nx, nyy, ld, ny);
-        Msg m{dir, peer, i1 - 1, j1 - 1, nx, nyy, (long)nx * nyy, -1};
-        if (nyy > 1 && nx != ld) { // rows of the patch are not adjacent in memory
-            m.off = buflen;
-            pk.push_back(Strip{m.i0, m.j0, nx, nyy, buflen, dir});
-            buflen += m.count;
-            if (m.count > p->max_strip) p->max_strip = (int)m.count;
-        }
-        list.push_back(m);
-        return DLESM_OK;
-    };
+    p->sends = L.sends;
+    p->recvs = L.recvs;
+    p->sendbuf_len = L.sendbuf_len;
+    p->recvbuf_len = L.recvbuf_len;
+    p->max_strip = L.max_strip;
+    p->n_spack = (int)L.spack.size();
+    p->n_rpack = (int)L.rpack.size();
+    p->sagg = L.sagg;
+    p->ragg = L.ragg;
+    p->sagg_len = L.sagg_len;
+    p->ragg_len = L.ragg_len;
+    p->max_msg = L.max_msg;
+    const std::vector<Strip> &spack = L.spack, &rpack = L.rpack, &sall = L.sall, &rall = L.rall;
     int rc = DLESM_OK;
-    for (int k = 0; k < t->nsend && !rc; k++)
-        rc = add(p->sends, spack, p->sendbuf_len, t->dirsend[k], t->destination[k], t->isrcsend[k],
-                 t->jsrcsend[k], t->nxsend[k], t->nysend[k]);
-    for (int k = 0; k < t->nrecv && !rc; k++)
-        rc = add(p->recvs, rpack, p->recvbuf_len, t->dirrecv[k], t->source[k], t->idesrecv[k],
-                 t->jdesrecv[k], t->nxrecv[k], t->nyrecv[k]);
-    if (rc) {
-        delete p;
-        return rc;
-    }
-    std::stable_sort(p->sends.begin(), p->sends.end(), by_peer_dir);
-    std::stable_sort(p->recvs.begin(), p->recvs.end(), by_peer_dir);
-    p->n_spack = (int)spack.size();
-    p->n_rpack = (int)rpack.size();
-    std::vector<Strip> sall, rall;
-    auto aggregate = [&](const std::vector<Msg> &list, std::vector<long> &agg, long &len, std::vector<Strip> &all) {
-        for (const Msg &m : list) {
-            agg.push_back(len);
-            all.push_back(Strip{m.i0, m.j0, m.nx, m.ny, len, m.dir});
-            len += (m.count + 15) & ~15L;                // every message starts on a 128-byte line
-            if (m.count > p->max_msg) p->max_msg = (int)m.count;
-        }
-    };
-    aggregate(p->sends, p->sagg, p->sagg_len, sall);
-    aggregate(p->recvs, p->ragg, p->ragg_len, rall);
     auto upload = [&](const std::vector<Strip> &v, Strip **d) -> int {
         if (v.empty()) return DLESM_OK;
         DLESM_HIP_TRY(hipMalloc((void **)d, v.size() * sizeof(Strip)));
@@ -356,6 +427,27 @@ extern "C" int dlesm_halo_plan_destroy(dlesm_halo_plan *p)
     if (p->ev_frame) (void)hipEventDestroy(p->ev_frame);
     if (p->ev_comm) (void)hipEventDestroy(p->ev_comm);
     delete p;
+    return DLESM_OK;
+}
+
+// What a plan made from `tables` for fields of ld x ny hands to RCCL in ONE exchange, call by call, in issue order.
+// Host only: no device, no communicator -- the lists are built by the code dlesm_halo_plan_create uses and walked by
+// the code the exchanges use.
+extern "C" int dlesm_halo_plan_describe(const dlesm_comm_tables *tables, int ld, int ny, int nfields, unsigned dirs_mask,
+                                        int aggregated, dlesm_msg_desc *out, int max_out, int *n_out)
+{
+    DLESM_REQUIRE(tables != nullptr && n_out != nullptr && (out != nullptr || max_out == 0), "null pointer");
+    DLESM_REQUIRE(nfields >= 1 && nfields <= 16, "%d fields", nfields);
+    MsgLists L;
+    if (int rc = build_msg_lists(tables, ld, ny, L)) return rc;
+    std::vector<Issue> calls;
+    issue_list(L.sends, L.recvs, L.sagg, L.ragg, L.sendbuf_len, L.recvbuf_len, nfields, dirs_mask, aggregated != 0, calls);
+    *n_out = (int)calls.size();
+    DLESM_REQUIRE((int)calls.size() <= max_out || max_out == 0, "%zu calls, room for %d", calls.size(), max_out);
+    for (size_t k = 0; k < calls.size() && (int)k < max_out; k++) {
+        const Issue &c = calls[k];
+        out[k] = dlesm_msg_desc{c.recv ? 1 : 0, c.peer, c.dir, c.field, c.i0 + 1, c.j0 + 1, c.nx, c.ny, c.count, c.off};
+    }
     return DLESM_OK;
 }
 
@@ -470,17 +562,11 @@ static int exchange_agg(dlesm_halo_plan *p, double *const *fields, int nf, unsig
     if (!(skip & 1)) {
         DLESM_NCCL_TRY(ncclGroupStart());
         ncclResult_t err = ncclSuccess;
-        for (size_t k = 0; k < p->recvs.size(); k++) {
-            const Msg &m = p->recvs[k];
-            if (!dir_enabled(mask, m.dir)) continue;
-            DLESM_NCCL_IN_GROUP(err, ncclRecv(p->recvagg + (size_t)nf * p->ragg[k], (size_t)nf * m.count, ncclDouble, m.peer,
-                                              g_comm, s));
-        }
-        for (size_t k = 0; k < p->sends.size(); k++) {
-            const Msg &m = p->sends[k];
-            if (!dir_enabled(mask, m.dir)) continue;
-            DLESM_NCCL_IN_GROUP(err, ncclSend(p->sendagg + (size_t)nf * p->sagg[k], (size_t)nf * m.count, ncclDouble, m.peer,
-                                              g_comm, s));
+        std::vector<Issue> calls;
+        issue_list(p->sends, p->recvs, p->sagg, p->ragg, p->sendbuf_len, p->recvbuf_len, nf, mask, true, calls);
+        for (const Issue &c : calls) {
+            if (c.recv) DLESM_NCCL_IN_GROUP(err, ncclRecv(p->recvagg + c.off, (size_t)c.count, ncclDouble, c.peer, g_comm, s));
+            else DLESM_NCCL_IN_GROUP(err, ncclSend(p->sendagg + c.off, (size_t)c.count, ncclDouble, c.peer, g_comm, s));
         }
         if (int rc = group_end(err, "aggregated halo exchange (ncclSend/ncclRecv)")) return rc;
     }
@@ -524,18 +610,12 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
     if (!(skip & 1)) {
         DLESM_NCCL_TRY(ncclGroupStart());
         ncclResult_t err = ncclSuccess;
-        for (int k = 0; k < nf; k++) {
-            double *f = fields[k];
-            for (const Msg &m : p->recvs) {
-                if (!dir_enabled(mask, m.dir)) continue;
-                double *dst = m.off >= 0 ? p->recvbuf + (size_t)k * p->recvbuf_len + m.off : f + (size_t)m.j0 * p->ld + m.i0;
-                DLESM_NCCL_IN_GROUP(err, ncclRecv(dst, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
-            }
-            for (const Msg &m : p->sends) {
-                if (!dir_enabled(mask, m.dir)) continue;
-                const double *src = m.off >= 0 ? p->sendbuf + (size_t)k * p->sendbuf_len + m.off : f + (size_t)m.j0 * p->ld + m.i0;
-                DLESM_NCCL_IN_GROUP(err, ncclSend(src, (size_t)m.count, ncclDouble, m.peer, g_comm, s));
-            }
+        std::vector<Issue> calls;
+        issue_list(p->sends, p->recvs, p->sagg, p->ragg, p->sendbuf_len, p->recvbuf_len, nf, mask, false, calls);
+        for (const Issue &c : calls) {
+            double *inplace = fields[c.field] + (size_t)c.j0 * p->ld + c.i0;
+            if (c.recv) DLESM_NCCL_IN_GROUP(err, ncclRecv(c.off >= 0 ? p->recvbuf + c.off : inplace, (size_t)c.count, ncclDouble, c.peer, g_comm, s));
+            else DLESM_NCCL_IN_GROUP(err, ncclSend(c.off >= 0 ? p->sendbuf + c.off : inplace, (size_t)c.count, ncclDouble, c.peer, g_comm, s));
         }
         if (int rc = group_end(err, "halo exchange (ncclSend/ncclRecv)")) return rc;
     }

@@ -446,6 +446,30 @@ int dlesm_halo_plan_create(const dlesm_comm_tables *tables, int ld, int ny,
                            dlesm_halo_plan **plan);
 int dlesm_halo_plan_destroy(dlesm_halo_plan *plan);
 
+/* One ncclRecv / ncclSend of an exchange, as dlesm_halo_plan_describe reports it. */
+typedef struct dlesm_msg_desc {
+    int is_recv;           /* 1 = ncclRecv, 0 = ncclSend                                                   */
+    int peer;              /* 0-based rank                                                                 */
+    int dir;               /* direction code of the strip (DLESM_IPLUS ...)                                */
+    int field;             /* which of the nfields fields; -1 = the strips of ALL fields, field after field */
+    int i0, j0, nx, ny;    /* the strip inside the field, 1-based origin                                   */
+    long count;            /* doubles on the wire                                                          */
+    long buffer_offset;    /* doubles from the start of the staging buffer (receive buffer for a receive,
+                              send buffer for a send); -1 = the message travels in place                  */
+} dlesm_msg_desc;
+
+/* The calls ONE exchange of `nfields` fields under `dirs_mask` makes on a plan created from `tables` for fields of
+ * ld x ny, in ISSUE ORDER -- the receives then the sends, each sorted by (peer, direction code); aggregated = 1: the
+ * one-message-per-neighbour-and-direction form (dlesm_halo_exchange_multi_f64, dlesm_halo_exchange_f64 on its own,
+ * the shallow-water step); 0: the Jacobi step's own form (rows in place, strided strips through the pack buffer;
+ * field-major).  RCCL has no tags (the reference matches messages by tag_orig + dir, parallel_comms_mod.f90:1606,
+ * 1647): between a pair of ranks the k-th send meets the k-th receive, so this order IS the protocol.  Host only (no
+ * GPU, no communicator); built and walked by the very code the plan and its exchanges use.  *n_out = number of
+ * calls; with max_out = 0 only the count is returned. */
+int dlesm_halo_plan_describe(const dlesm_comm_tables *tables, int ld, int ny, int nfields,
+                             unsigned dirs_mask, int aggregated, dlesm_msg_desc *out, int max_out,
+                             int *n_out);
+
 /* halo_exchange(depth=1) of one device field: pack -> grouped ncclSend/ncclRecv
  * -> unpack, all enqueued on `stream`.  dirs_mask selects the enabled edge
  * directions (bit d-1 for DLESM_IPLUS..DLESM_JMINUS: the comm1..comm4 arguments of

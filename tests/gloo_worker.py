@@ -2,9 +2,10 @@
 backend, no GPU).  It drives the PRODUCT's host logic for its own rank -- parallel_init,
 grid_type%decompose, grid_init (-> map_comms through the C ABI) -- and then plays the
 reference's dist_mem tests (test_halos / test_gsum / test_reduction) with numpy arrays as the
-fields and gloo send/recv as a TEST-ONLY transport that follows the product's message tables and,
-like RCCL, uses NO tags: messages between a pair of ranks match purely by issue order (per peer
-ascending direction code, the strips of all fields of a grouped exchange in one message), so the ordering rule of dlesm_halo.hip is what is tested.  What this checks is
+fields and gloo send/recv as a TEST-ONLY transport that issues exactly the calls the product's plan reports
+(dlesm_halo_plan_describe: peer, direction, count, staging slot, in ISSUE ORDER) and, like RCCL, uses NO tags:
+messages between a pair of ranks match purely by issue order, so the C++ ordering / masking / slot logic of
+dlesm_halo.hip itself is what is tested.  What this checks is
 everything about the N>1 path that is not the GPU itself: tile ownership, message tables,
 peer/ordering logic, scatter/gather index maps.
 
@@ -28,46 +29,72 @@ import ref_cases as R  # noqa: E402
 DIRS_ALL, DIRS_NO_DIAGONALS = 0xF, 0x10
 
 
-def dir_enabled(mask, d):
-    """dlesm_halo.hip dir_enabled: edges by their bit, diagonals when both their edges are (unless
-    DIRS_NO_DIAGONALS), parallel_comms_mod.f90:1557-1571"""
-    on = lambda k: (mask >> (k - 1)) & 1                       # noqa: E731
-    if 1 <= d <= 4:
-        return bool(on(d))
-    if mask & DIRS_NO_DIAGONALS:
-        return False
-    return bool({5: on(1) and on(3), 6: on(2) and on(4), 7: on(1) and on(4), 8: on(2) and on(3)}.get(d, 0))
+def plan_calls(tables, ld, ny, nf, mask, aggregated):
+    """the ncclRecv / ncclSend calls of ONE exchange, in issue order, as the PRODUCT reports them
+    (dlesm_halo_plan_describe: built by the code dlesm_halo_plan_create uses, walked by the code the exchanges use)"""
+    import ctypes as C
+    import dl_esm_inf_amd as D
+    L = D._cabi.lib()
+    n = C.c_int()
+    D._cabi.check(L.dlesm_halo_plan_describe(C.byref(tables), ld, ny, nf, mask, 1 if aggregated else 0, None, 0, C.byref(n)))
+    out = (D._cabi.MsgDesc * max(1, n.value))()
+    D._cabi.check(L.dlesm_halo_plan_describe(C.byref(tables), ld, ny, nf, mask, 1 if aggregated else 0, out, n.value, C.byref(n)))
+    return [out[k] for k in range(n.value)]
 
 
-def exchange_multi(fields, tables, rank, mask=DIRS_ALL):
-    """halo exchange of several (ny, ld) numpy fields over gloo, issued EXACTLY as dlesm_halo.hip
-    issues its ncclSend/ncclRecv: no tags (every message carries tag 0, as RCCL has none), the
-    receives then the sends, each list sorted by (peer, direction code); with more than one field
-    ONE message per neighbour and direction carries the strips of all fields, field after field
-    (exchange_agg).  Between a pair of ranks the k-th send therefore has to meet the k-th receive:
-    the ordering rule itself is what this transport tests."""
-    sends = sorted((m for m in tables.sends() if dir_enabled(mask, m["dir"])), key=lambda m: (m["dest"], m["dir"]))
-    recvs = sorted((m for m in tables.recvs() if dir_enabled(mask, m["dir"])), key=lambda m: (m["src"], m["dir"]))
+def exchange_multi(fields, tables, rank, mask=DIRS_ALL, aggregated=True):
+    """halo exchange of several (ny, ld) numpy fields over gloo, issued from the product's OWN call list: one
+    irecv / isend per reported ncclRecv / ncclSend, in the reported order, with NO tags (every message carries tag 0,
+    as RCCL has none) -- between a pair of ranks the k-th send therefore has to meet the k-th receive.  Payloads go
+    through staging buffers at the reported offsets (overlapping slots would corrupt them); in-place messages go
+    straight from / to the field.  A wrong sort, a wrong skip of a masked direction or a wrong slot layout in the
+    C++ shows up here as a mismatched or corrupted message."""
+    ny, ld = fields[0].shape
     nf = len(fields)
-    reqs, bufs = [], []
-    for m in recvs:
-        buf = torch.empty(nf * m["nx"] * m["ny"], dtype=torch.float64)
-        reqs.append(dist.irecv(buf, src=m["src"], tag=0))
-        bufs.append((m, buf))
-    for m in sends:
-        strips = [np.ascontiguousarray(f[m["jsrc"] - 1:m["jsrc"] - 1 + m["ny"], m["isrc"] - 1:m["isrc"] - 1 + m["nx"]]).reshape(-1)
-                  for f in fields]
-        reqs.append(dist.isend(torch.from_numpy(np.concatenate(strips)), dst=m["dest"], tag=0))
+    calls = plan_calls(tables, ld, ny, nf, mask, aggregated)
+    span = {True: 0, False: 0}
+    for c in calls:
+        if c.buffer_offset >= 0:
+            span[bool(c.is_recv)] = max(span[bool(c.is_recv)], c.buffer_offset + c.count)
+    rbuf, sbuf = torch.full((span[True],), float("nan"), dtype=torch.float64), torch.full((span[False],), float("nan"),
+                                                                                          dtype=torch.float64)
+    used = {True: [], False: []}
+
+    def slot(c):
+        """the call's slice of its staging buffer; slots of one exchange must not overlap"""
+        lo, hi = c.buffer_offset, c.buffer_offset + c.count
+        for (a, b) in used[bool(c.is_recv)]:
+            assert hi <= a or b <= lo, f"rank {rank}: staging slots overlap: [{lo},{hi}) and [{a},{b})"
+        used[bool(c.is_recv)].append((lo, hi))
+        return (rbuf if c.is_recv else sbuf)[lo:hi]
+
+    def strip(f, c):
+        return f[c.j0 - 1:c.j0 - 1 + c.ny, c.i0 - 1:c.i0 - 1 + c.nx]
+
+    reqs, landed = [], []
+    for c in calls:                                            # THE issue order
+        which = list(range(nf)) if c.field < 0 else [c.field]
+        assert c.count == len(which) * c.nx * c.ny
+        if c.is_recv:
+            buf = slot(c) if c.buffer_offset >= 0 else torch.empty(c.count, dtype=torch.float64)
+            reqs.append(dist.irecv(buf, src=c.peer, tag=0))
+            landed.append((c, which, buf))
+        else:
+            payload = torch.from_numpy(np.concatenate([np.ascontiguousarray(strip(fields[k], c)).reshape(-1) for k in which]))
+            if c.buffer_offset >= 0:
+                slot(c).copy_(payload)
+                payload = slot_view = sbuf[c.buffer_offset:c.buffer_offset + c.count]   # noqa: F841  (sent from the slot)
+            reqs.append(dist.isend(payload, dst=c.peer, tag=0))
     for q in reqs:
         q.wait()
-    for m, buf in bufs:
-        got = buf.numpy().reshape(nf, m["ny"], m["nx"])
-        for k in range(nf):
-            fields[k][m["jdes"] - 1:m["jdes"] - 1 + m["ny"], m["ides"] - 1:m["ides"] - 1 + m["nx"]] = got[k]
+    for c, which, buf in landed:
+        got = buf.numpy().reshape(len(which), c.ny, c.nx)
+        for n, k in enumerate(which):
+            strip(fields[k], c)[...] = got[n]
 
 
-def exchange(field, tables, rank, mask=DIRS_ALL):
-    exchange_multi([field], tables, rank, mask)
+def exchange(field, tables, rank, mask=DIRS_ALL, aggregated=True):
+    exchange_multi([field], tables, rank, mask, aggregated)
 
 
 def deep_halo_suite(D, nx, ny, depth, rank, world):
@@ -159,10 +186,12 @@ def main():
         it = internal.box()
         f = R.init_field_hill(ptype, g.nx, g.ny, it, sub.glob.xstart, sub.glob.ystart)
         before = f.copy()
-        exchange(f, t, rank)
+        f2 = f.copy()
+        exchange(f, t, rank)                                    # the aggregated form (dlesm_halo_exchange_f64 on its own)
+        exchange(f2, t, rank, aggregated=False)                 # rows in place, strided strips through the pack buffer
         bad = R.check_hill_halos(f, ptype, it, sub.glob.box(), nx, ny, corners=True)
-        if bad:
-            print(f"rank {rank}: ERROR in halo values for ptype {ptype}: {bad[:3]}", flush=True)
+        if bad or not np.array_equal(f, f2):
+            print(f"rank {rank}: ERROR in halo values for ptype {ptype}: {bad[:3]} (forms equal: {np.array_equal(f, f2)})", flush=True)
             errors += 1
         xs, xe, ys, ye = it
         if not np.array_equal(f[ys - 1:ye, xs - 1:xe], before[ys - 1:ye, xs - 1:xe]):
@@ -190,7 +219,7 @@ def main():
     corners = [(ys - 2, xs - 2), (ys - 2, xe), (ye, xs - 2), (ye, xe)]
     for (j, i) in corners:
         f[j, i] = -123.0
-    exchange(f, t, rank, DIRS_ALL | DIRS_NO_DIAGONALS)
+    exchange(f, t, rank, DIRS_ALL | DIRS_NO_DIAGONALS, aggregated=False)     # the Jacobi step's own form and mask
     if any(f[j, i] != -123.0 for (j, i) in corners):
         print(f"rank {rank}: ERROR edges-only exchange touched a corner halo", flush=True)
         errors += 1
@@ -198,6 +227,21 @@ def main():
     if bad:
         print(f"rank {rank}: ERROR edges-only exchange: {bad[:3]}", flush=True)
         errors += 1
+    # ---- comm1..comm4 subsets (exchange_generic's masks): both forms issue the same, consistent, subset -------------
+    for mask in (0xF, 0x1, 0x3, 0xC, 0x5, 0xA, 0x0, 0xF | DIRS_NO_DIAGONALS):
+        res = []
+        for agg in (True, False):
+            fm = [R.init_field_hill(R.GO_T, g.nx, g.ny, it, sub.glob.xstart, sub.glob.ystart) * (k + 1) for k in range(2)]
+            for f in fm:                                           # halos start wrecked: what arrives is what is compared
+                keep = f[ys - 1:ye, xs - 1:xe].copy()
+                f[:] = -77.0
+                f[ys - 1:ye, xs - 1:xe] = keep
+            exchange_multi(fm, t, rank, mask, aggregated=agg)      # completes only if every send has its receive
+            res.append(fm)
+        # two fields that differ by a factor: a message delivered to the wrong field, or the two forms disagreeing, shows
+        if not all(np.array_equal(a, b) for a, b in zip(*res)) or not np.array_equal(res[0][1], np.where(res[0][0] == -77.0, -77.0, 2 * res[0][0])):
+            print(f"rank {rank}: ERROR masked exchange {mask:#x}: forms differ or fields mixed up", flush=True)
+            errors += 1
     # ---- test_gsum: checksum of ones == jpiglo*jpjglo --------------------------------
     internal, _ = D.field_mod.field_bounds(g, R.GO_T)
     f = R.gsum_field(g.nx, g.ny, internal.box())

@@ -226,6 +226,52 @@ def test_untagged_message_order_matches_between_every_pair_of_ranks(nx, ny, nran
             assert sends == recvs, (a, b, sends, recvs)
 
 
+def _calls(t, ld, ny, nf, mask, agg):
+    n = C.c_int()
+    _cabi.check(L.dlesm_halo_plan_describe(C.byref(t), ld, ny, nf, mask, agg, None, 0, C.byref(n)))
+    out = (_cabi.MsgDesc * max(1, n.value))()
+    _cabi.check(L.dlesm_halo_plan_describe(C.byref(t), ld, ny, nf, mask, agg, out, n.value, C.byref(n)))
+    return [out[k] for k in range(n.value)]
+
+
+@pytest.mark.parametrize("nx,ny,nranks,depth", [(16, 32, 8, None), (10, 10, 6, None), (64, 64, 16, None), (32, 64, 8, 4)])
+@pytest.mark.parametrize("nf,mask,agg", [(1, 0xF, 1), (3, 0xF, 1), (1, 0x1F, 0), (2, 0xF, 0), (2, 0x5, 1), (2, 0xA, 0), (1, 0, 1)])
+def test_plan_issue_lists_pair_up_call_by_call(nx, ny, nranks, depth, nf, mask, agg):
+    """the same rule on the product's OWN issue lists (dlesm_halo_plan_describe -- what dlesm_halo_exchange*_f64 and the
+    distributed steps hand to ncclRecv / ncclSend, in order): for every ordered pair of ranks the k-th send of a to b
+    is the k-th receive of b from a (same count, same direction, same field); staging slots of one exchange do not
+    overlap, aggregated ones start on 128-byte lines; a masked direction appears on neither side"""
+    d = D.go_decompose(nx, ny, ndomains=nranks, halo_width=depth or 1)
+    hw = depth or 1
+    lists = []
+    for r in range(nranks):
+        t = D.map_comms(d, rank1=r + 1, nranks=nranks, depth=depth)
+        g = d.subdomains[r].glob
+        ld, nyy = g.nx + 1 + (r % 2), g.ny + 1             # extents as grid_init makes them (odd and even pitches)
+        calls = _calls(t, ld, nyy, nf, mask, agg)
+        lists.append(calls)
+        seen_send = False
+        for c in calls:                                     # per field group: the receives, then the sends
+            assert c.peer != r and 0 <= c.peer < nranks and c.count == (nf if c.field < 0 else 1) * c.nx * c.ny
+            assert (c.field == -1) == bool(agg)
+            seen_send |= not c.is_recv
+        for kind in (0, 1):
+            spans = sorted((c.buffer_offset, c.buffer_offset + c.count) for c in calls if c.is_recv == kind and c.buffer_offset >= 0)
+            assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), spans
+            if agg:
+                assert all(lo % (16 * nf) == 0 for lo, _ in spans) and len(spans) == sum(c.is_recv == kind for c in calls)
+        if not mask & 0xF:
+            assert not calls
+    for a in range(nranks):
+        for b in range(nranks):
+            if a == b:
+                continue
+            sends = [(c.dir, c.field, c.count) for c in lists[a] if not c.is_recv and c.peer == b]
+            recvs = [(c.dir, c.field, c.count) for c in lists[b] if c.is_recv and c.peer == a]
+            assert sends == recvs, (a, b, sends, recvs)
+    assert hw >= 1
+
+
 def test_map_comms_depth_needs_room():
     t = _cabi.CommTables()
     d = D.go_decompose(40, 40, ndomains=4, halo_width=2)

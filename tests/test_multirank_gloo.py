@@ -50,7 +50,9 @@ def test_deep_halos_and_staged_steps_over_gloo(nx, ny, world, depth):
 
 
 # world_size 2 (x-split and y-split) as the contract asks, plus the reference's 4- and 6-rank cases
-@pytest.mark.parametrize("nx,ny,world", [(10, 4, 2), (4, 10, 2), (10, 10, 4), (10, 10, 6)])
+# ... and BASELINE configs[4]'s 2 x 4 mesh (16384 x 32768 over 8 ranks) at a small tile, uneven 3 x 3 and 1 x 5 meshes
+@pytest.mark.parametrize("nx,ny,world", [(10, 4, 2), (4, 10, 2), (10, 10, 4), (10, 10, 6), (16, 32, 8), (13, 11, 9),
+                                         (7, 40, 5)])
 def test_dist_mem_suite_over_gloo(nx, ny, world):
     port = _free_port()
     procs = []
