@@ -163,6 +163,8 @@ PROTOTYPES = {
     "dlesm_jacobi5_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_jacobi5_step_dm_pipelined": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_halo_plan_join": (_i, [_vp, _vp]),
+    "dlesm_wait_timed_out": (_i, [_i]),
+    "dlesm_probe_stream_concurrency": (_i, [_vp]),
     "dlesm_jacobi5_multi_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_shallow_step_dm": (_i, [_vp, C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_shallow_step_dm_pipelined": (_i, [_vp, C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),

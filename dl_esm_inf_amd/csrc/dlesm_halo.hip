@@ -396,7 +396,6 @@ extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny
     if (!p->sends.empty() || !p->recvs.empty()) {
         void *words = nullptr;
         if (hipMalloc(&words, 256) != hipSuccess || hipMemset(words, 0, 256) != hipSuccess ||
-            hipHostMalloc((void **)&p->frame_timed_out, sizeof(int), hipHostMallocMapped) != hipSuccess ||
             hipDeviceSynchronize() != hipSuccess) {
             dlesm_halo_plan_destroy(p);
             return fail(DLESM_EHIP, "halo plan: cannot allocate the frame flag");
@@ -404,7 +403,10 @@ extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny
         p->frame_flag = (unsigned long long *)words;                 // three words, 64 bytes apart
         p->frame_counter = (unsigned *)((char *)words + 64);
         p->halo_flag = (unsigned long long *)((char *)words + 128);
-        *p->frame_timed_out = 0;
+        p->frame_timed_out = wait_timed_out_word();         // ONE word for the process: sticky, checked by every entry
+        // the probe the one-launch forms rest on (kernels of two streams side by side), once, here, for the stream most
+        // programs use -- not inside somebody's first time step
+        (void)streams_run_concurrently(nullptr);
     }
     *out = p;
     return DLESM_OK;
@@ -423,7 +425,6 @@ extern "C" int dlesm_halo_plan_destroy(dlesm_halo_plan *p)
     if (p->sendbuf) (void)hipFree(p->sendbuf);
     if (p->recvbuf) (void)hipFree(p->recvbuf);
     if (p->frame_flag) (void)hipFree(p->frame_flag);
-    if (p->frame_timed_out) (void)hipHostFree(p->frame_timed_out);
     if (p->ev_frame) (void)hipEventDestroy(p->ev_frame);
     if (p->ev_comm) (void)hipEventDestroy(p->ev_comm);
     delete p;
@@ -709,6 +710,7 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
         job.halo_flag = p->halo_flag;
         job.halo_seq = can_chain ? p->pending_seq : 0;
         job.timed_out = p->frame_timed_out;
+        job.halo_wait_ticks = remote_wait_ticks();
         // chained step: the previous exchange was not unpacked -- `in`'s west/east halo columns are the
         // received strips themselves, read from the receive buffer (the same mask was exchanged)
         const bool virt = can_chain && p->pending_field == in && tuning("j5_dm_lazy_unpack", 1);
@@ -766,7 +768,7 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
     // joined form of the one-launch step: a one-wave kernel on the caller's stream that sleeps on the
     // exchange's completion flag -- a kernel launch costs the stream ~2.5 us, an event wait 7-8
     // (scripts/syncbench.hip); the halos were released at device scope when the exchange's last kernel ended
-    if (fused && tuning("dm_flag_join", 1)) return launch_frame_flag_wait(p->halo_flag, p->frame_seq, p->frame_timed_out, s);
+    if (fused && tuning("dm_flag_join", 1)) return launch_frame_flag_wait(p->halo_flag, p->frame_seq, p->frame_timed_out, s, true);
     DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
     return DLESM_OK;
 }
@@ -824,6 +826,7 @@ extern "C" int dlesm_stencil9_step_dm(dlesm_halo_plan *p, const double *in, doub
         job.flag = p->frame_flag;
         job.seq = p->frame_seq + 1;
         job.timed_out = p->frame_timed_out;
+        job.halo_wait_ticks = remote_wait_ticks();
         bool fused = false;
         if (int rc = launch_stencil9_framed(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, job, s, &fused)) return rc;
         if (fused) {
@@ -832,7 +835,7 @@ extern "C" int dlesm_stencil9_step_dm(dlesm_halo_plan *p, const double *in, doub
             if (int rc = exchange_on(p, out, mask, side, prepacked)) return rc;
             if (int rc = launch_flag_set(p->halo_flag, job.seq, side)) return rc;
             DLESM_HIP_TRY(hipEventRecord(p->ev_comm, side));
-            if (tuning("dm_flag_join", 1)) return launch_frame_flag_wait(p->halo_flag, job.seq, p->frame_timed_out, s);
+            if (tuning("dm_flag_join", 1)) return launch_frame_flag_wait(p->halo_flag, job.seq, p->frame_timed_out, s, true);
             DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
             return DLESM_OK;
         }
@@ -983,6 +986,7 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
         job.halo_flag = p->halo_flag;
         job.halo_seq = can_chain ? p->pending_seq : 0;
         job.timed_out = p->frame_timed_out;
+        job.halo_wait_ticks = remote_wait_ticks();
         bool fused = false;
         if (int rc = launch_shallow_framed(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew,
                                            pnew, job, s, &fused))
@@ -1002,7 +1006,7 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
                 return DLESM_OK;
             }
             if (tuning("dm_flag_join", 1))               // as in the Jacobi step: a flag-wait kernel instead of an event wait
-                return launch_frame_flag_wait(p->halo_flag, job.seq, p->frame_timed_out, s);
+                return launch_frame_flag_wait(p->halo_flag, job.seq, p->frame_timed_out, s, true);
             DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
             return DLESM_OK;
         }

@@ -31,6 +31,13 @@ int ensure_device();
 hipStream_t side_stream();     // created by ensure_device()
 hipStream_t transfer_stream(); // for the non-blocking sync callbacks
 int tuning(const char *key, int fallback);
+// the process-wide pinned word a device-side wait raises when it gives up (checked by every device entry point)
+int *wait_timed_out_word();
+// forget what streams_run_concurrently has measured (a time-out was acknowledged, the runtime was finalised)
+void invalidate_concurrency_probe();
+// bound, in ticks of the 100 MHz counter, of a wait whose release depends on OTHER ranks (an exchange completing):
+// dm_wait_seconds, default 600; 0 = no limit, as the reference waits in MPI_Waitany
+unsigned long long remote_wait_ticks();
 
 // column-major 1-based -> linear offset (field_mod.f90:350)
 __host__ __device__ inline size_t lin(int ld, int ji, int jj)
@@ -139,6 +146,7 @@ struct FrameJob {
     // *halo_flag >= halo_seq -- the previous step's exchange has landed in `in`'s halos
     const unsigned long long *halo_flag;
     unsigned long long halo_seq;  // 0: no wait
+    unsigned long long halo_wait_ticks;   // bound of that wait (remote_wait_ticks(); 0 = none)
     int *timed_out;               // pinned host word raised by a wait that gives up
     // pipelined steps: the west/east halo columns of `in` have NOT been unpacked into the field; they
     // are read from the receive buffer of the previous exchange (contiguous), strip by strip
@@ -154,7 +162,10 @@ int launch_stencil5_framed(const double *in, double *out, int ld, int ny, int xs
 int launch_stencil9_framed(const double *in, double *out, const double *coef, int ld, int ny, int xstart, int xstop,
                            int ystart, int ystop, FrameJob job, hipStream_t s, bool *fused);
 // park stream `s` (one sleeping wave) until *flag >= seq; bounded, see frame_flag_wait
-int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s);
+// remote = the flag is raised when an EXCHANGE has completed (depends on other ranks): bounded by remote_wait_ticks()
+// instead of the 30 s that bound a wait for this GPU's own frame workgroups
+int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s,
+                           bool remote = false);
 // true when kernels of two streams execute side by side in this process (probed once; false under
 // kernel-serialising tools): precondition of the one-launch / time-loop forms of the distributed step
 bool streams_run_concurrently(hipStream_t callers);
@@ -182,6 +193,7 @@ struct SwFrameJob {
     // previous step's exchange has landed in the halos of u, v, p and is done with the send buffers
     const unsigned long long *halo_flag;
     unsigned long long halo_seq;  // 0: no wait
+    unsigned long long halo_wait_ticks;   // bound of that wait (remote_wait_ticks(); 0 = none)
     int *timed_out;
     int diag;                     // profiling only (results wrong): 1 = no frame cells, 2 = south/north rows only
 };

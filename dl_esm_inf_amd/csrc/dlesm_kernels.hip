@@ -360,12 +360,13 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_framed(const double *__rest
     if (fj.halo_seq) {
         // pipelined steps: `in`'s halos (and the send buffer) belong to the previous step's exchange
         // until its completion flag is up.  In steady state it has been up for a long time -- the
-        // exchange ends well inside the previous interior sweep -- and this costs one load.  Bounded.
+        // exchange ends well inside the previous interior sweep -- and this costs one load.  The flag depends on the
+        // OTHER ranks: bounded by dm_wait_seconds (default 10 min, 0 = no limit), not by the 30 s of a local wait.
         if (threadIdx.x == 0) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             while (__hip_atomic_load(fj.halo_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fj.halo_seq) {
                 __builtin_amdgcn_s_sleep(32);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) {   // ~30 s of the 100 MHz counter
+                if (fj.halo_wait_ticks && __builtin_amdgcn_s_memrealtime() - t0 > fj.halo_wait_ticks) {   // 100 MHz counter
                     __hip_atomic_store(fj.timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
@@ -747,7 +748,7 @@ __global__ void frame_flag_wait(const unsigned long long *flag, unsigned long lo
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
         __builtin_amdgcn_s_sleep(64);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) {        // 100 MHz counter
+        if (max_ticks && __builtin_amdgcn_s_memrealtime() - t0 > max_ticks) {        // 100 MHz counter; 0 = no limit
             __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
@@ -766,9 +767,18 @@ int launch_flag_set(unsigned long long *flag, unsigned long long seq, hipStream_
     return DLESM_OK;
 }
 
-int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s)
+unsigned long long remote_wait_ticks()
 {
-    hipLaunchKernelGGL(frame_flag_wait, dim3(1), dim3(64), 0, s, flag, seq, timed_out, 3000000000ull);   // ~30 s
+    const int sec = tuning("dm_wait_seconds", 600);
+    return sec <= 0 ? 0ull : (unsigned long long)sec * 100000000ull;
+}
+
+int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long seq, int *timed_out, hipStream_t s, bool remote)
+{
+    // local: this GPU's own frame workgroups report within microseconds -- 30 s means a failed launch.  remote: the flag
+    // follows an exchange, i.e. it waits for the slowest neighbour (a rank that is writing output, say), which the
+    // reference does without limit (MPI_Waitany, parallel_comms_mod.f90:1773-1798): dm_wait_seconds, default 10 minutes.
+    hipLaunchKernelGGL(frame_flag_wait, dim3(1), dim3(64), 0, s, flag, seq, timed_out, remote ? remote_wait_ticks() : 3000000000ull);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -779,11 +789,24 @@ int launch_frame_flag_wait(const unsigned long long *flag, unsigned long long se
 // AMD_SERIALIZE_KERNEL) the waiter would run alone and only leave through its time-out (seen: a --pmc
 // run of the loop-back script crawled from time-out to time-out).  Probe once per process: a waiter
 // with a 50 ms bound on the side stream, the releasing store on the caller's stream.
+static std::mutex g_probe_mu;
+static std::map<hipStream_t, int> g_probe_seen;
+
+void invalidate_concurrency_probe()
+{
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    g_probe_seen.clear();
+}
+
 bool streams_run_concurrently(hipStream_t callers)
 {
-    // per caller's stream: which hardware queue a stream lands on is the runtime's choice
-    static std::mutex mu;
-    static std::map<hipStream_t, int> seen;
+    // per caller's stream: which hardware queue a stream lands on is the runtime's choice.  The answer is kept until it
+    // is invalidated: dlesm_probe_stream_concurrency (the host program re-created a stream, attached a tool), an
+    // acknowledged wait time-out, dlesm_finalize.  The FIRST call for a stream synchronises the device once (so that
+    // the probe's two kernels start together), allocates 64 bytes and waits up to 50 ms: do it outside graph captures
+    // (the steps ask for it only when they are not being captured) -- dlesm_halo_plan_create does it for the null stream.
+    std::mutex &mu = g_probe_mu;
+    std::map<hipStream_t, int> &seen = g_probe_seen;
     std::lock_guard<std::mutex> lk(mu);
     auto it = seen.find(callers);
     if (it != seen.end()) return it->second != 0;
@@ -1470,4 +1493,14 @@ extern "C" int dlesm_checksum_async_f64(const double *f, int ld, int ny, int xst
     const int rc = enqueue_checksum(f, ld, xstart - 1, ystart - 1, nx, nyb, scratch, result_dev, s);
     DLESM_HIP_TRY(hipFreeAsync(scratch, s));
     return rc;
+}
+
+extern "C" int dlesm_probe_stream_concurrency(void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_probe_mu);
+        g_probe_seen.erase((hipStream_t)stream);
+    }
+    return streams_run_concurrently((hipStream_t)stream) ? 1 : 0;
 }

@@ -30,11 +30,32 @@ static int g_device = -1;
 static hipStream_t g_side = nullptr, g_xfer = nullptr;
 static std::map<std::string, int> g_tuning;
 
+// DLESM_DM_SAFE=1 (environment, read once) or dlesm_set_tuning("dm_safe", 1): ONE switch that takes every distributed
+// step to its conservative form -- frame in its own launch, the exchange ordered by events on both sides, every received
+// strip unpacked into the field before anything reads it, no device-side flag waits at all.  The form to fall back to
+// when a first run on new hardware (several GPUs over xGMI) fails its self-check: it relies on kernel boundaries and
+// stream-ordered events only.
+static const char *const kSafeOff[] = {"j5_dm_fused", "sw_dm_fused", "s9_dm_fused", "dm_flag_join", "j5_dm_lazy_unpack",
+                                       "j5_dm_chain", "sw_dm_chain"};
+static bool dm_safe_nolock()
+{
+    static const bool env = [] { const char *e = getenv("DLESM_DM_SAFE"); return e && *e && strcmp(e, "0") != 0; }();
+    auto it = g_tuning.find("dm_safe");
+    return it != g_tuning.end() ? it->second != 0 : env;
+}
+
 static int tuning_nolock(const char *key, int fallback)
 {
+    if (dm_safe_nolock())
+        for (const char *k : kSafeOff)
+            if (!strcmp(k, key)) return 0;
     auto it = g_tuning.find(key);
     return it == g_tuning.end() ? fallback : it->second;
 }
+
+// One pinned host word for the whole process, raised (system scope) by any device-side wait that gives up.  Sticky:
+// every later device entry point fails loudly (ensure_device) until the host program acknowledges it.
+static int *g_wait_timed_out = nullptr;
 
 static int bind_device(int device)
 {
@@ -55,15 +76,27 @@ static int bind_device(int device)
         DLESM_HIP_TRY(hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, prio));
     }
     if (!g_xfer) DLESM_HIP_TRY(hipStreamCreateWithFlags(&g_xfer, hipStreamNonBlocking));
+    if (!g_wait_timed_out) {
+        DLESM_HIP_TRY(hipHostMalloc((void **)&g_wait_timed_out, sizeof(int), hipHostMallocMapped));
+        *g_wait_timed_out = 0;
+    }
     g_device = device;
     g_ready = true;
     return DLESM_OK;
 }
 
+static int timed_out_error()
+{
+    return fail(DLESM_EHIP, "a distributed step gave up waiting on a device flag (a frame that never reported, or an exchange "
+                            "whose messages did not arrive within dm_wait_seconds): everything enqueued behind that wait may "
+                            "have read halos that had not arrived -- results since then are INVALID.  Destroy the halo plans, "
+                            "then dlesm_wait_timed_out(1) to acknowledge (or restart the program)");
+}
+
 int ensure_device()
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_ready) return DLESM_OK;
+    if (g_ready) return (g_wait_timed_out && *(volatile int *)g_wait_timed_out) ? timed_out_error() : DLESM_OK;
     // lazily adopt the device the host program already selected (e.g. torch.cuda.set_device)
     int cur = 0;
     if (hipGetDevice(&cur) != hipSuccess) {
@@ -73,14 +106,14 @@ int ensure_device()
     return bind_device(cur);
 }
 
+int *wait_timed_out_word() { return g_wait_timed_out; }
 hipStream_t side_stream() { return g_side; }
 hipStream_t transfer_stream() { return g_xfer; }
 
 int tuning(const char *key, int fallback)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_tuning.find(key);
-    return it == g_tuning.end() ? fallback : it->second;
+    return tuning_nolock(key, fallback);
 }
 
 } // namespace dlesm
@@ -107,11 +140,29 @@ extern "C" int dlesm_init(int device)
     return bind_device(device);
 }
 
+extern "C" int dlesm_wait_timed_out(int clear)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_wait_timed_out) return 0;
+    const int was = *(volatile int *)g_wait_timed_out != 0;
+    if (clear && was) {
+        (void)hipDeviceSynchronize();                     // nothing that could still raise it is left in flight
+        *(volatile int *)g_wait_timed_out = 0;
+        invalidate_concurrency_probe();                   // whatever made the wait fail may have changed how streams run
+    }
+    return was;
+}
+
 extern "C" int dlesm_finalize(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_ready) return DLESM_OK;
     (void)hipDeviceSynchronize();
+    if (g_wait_timed_out) {
+        (void)hipHostFree(g_wait_timed_out);
+        g_wait_timed_out = nullptr;
+    }
+    invalidate_concurrency_probe();
     if (g_side) (void)hipStreamDestroy(g_side);
     if (g_xfer) (void)hipStreamDestroy(g_xfer);
     g_side = g_xfer = nullptr;
@@ -125,6 +176,8 @@ extern "C" int dlesm_set_tuning(const char *key, int value)
     std::lock_guard<std::mutex> lk(g_mu);
     int prev = g_tuning.count(key) ? g_tuning[key] : 0;
     g_tuning[key] = value;
+    // diagnostic: raise the process-wide time-out word exactly as a device-side wait that gives up does
+    if (!strcmp(key, "dm_inject_timeout") && value && g_wait_timed_out) *(volatile int *)g_wait_timed_out = 1;
     return prev;
 }
 

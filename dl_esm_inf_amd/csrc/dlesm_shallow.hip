@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             while (__hip_atomic_load(fj.halo_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fj.halo_seq) {
                 __builtin_amdgcn_s_sleep(32);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) {   // ~30 s of the 100 MHz counter
+                if (fj.halo_wait_ticks && __builtin_amdgcn_s_memrealtime() - t0 > fj.halo_wait_ticks) {   // dm_wait_seconds
                     __hip_atomic_store(fj.timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }

@@ -520,6 +520,24 @@ int dlesm_jacobi5_step_dm_pipelined(dlesm_halo_plan *plan, const double *in, dou
 /* order `stream` behind the exchange a pipelined step left in flight (no-op when there is none) */
 int dlesm_halo_plan_join(dlesm_halo_plan *plan, void *stream);
 
+/* Device-side waits of the distributed steps are bounded: 30 s for this GPU's own frame workgroups, and
+ * dm_wait_seconds (dlesm_set_tuning; default 600, 0 = no limit, as the reference waits in MPI_Waitany,
+ * parallel_comms_mod.f90:1773-1798) wherever the wait is for an EXCHANGE, i.e. for the slowest neighbour.  A wait
+ * that gives up raises ONE process-wide flag; the stream then runs on, so whatever was enqueued behind the wait may
+ * have read halos that never arrived.  From that moment EVERY device entry point of this library (steps, checksum,
+ * gather, field callbacks ...) fails with DLESM_EHIP: wrong numbers cannot leave silently.  Returns 1 if the flag is
+ * up; clear != 0 acknowledges it (after the host program has destroyed its halo plans) and makes the library
+ * re-measure whether streams still run side by side. */
+int dlesm_wait_timed_out(int clear);
+
+/* The one-launch and time-loop forms park a waiting kernel on the library's side stream while the kernel that
+ * releases it runs on the caller's stream: that needs kernels of the two streams to execute side by side (not so
+ * under tools that serialise kernels).  Measured once per caller's stream -- at dlesm_halo_plan_create for the null
+ * stream, else at the first step on a stream: one device synchronisation, 64 bytes, at most 50 ms -- and remembered.
+ * This call measures again NOW (after re-creating a stream, attaching a tool ...): 1 = side by side (one-launch
+ * forms are used), 0 = not (the steps take their event-ordered form), < 0 on error.  Not inside a graph capture. */
+int dlesm_probe_stream_concurrency(void *stream);
+
 /* The distributed step of any 3 x 3 weighted kernel (dlesm_stencil9_f64's coefficients and
  * evaluation order): out = stencil9(in) on the box, then the halos of `out` valid as after
  * out%halo_exchange(1) -- all eight directions when a corner weight is non-zero (corner halos are

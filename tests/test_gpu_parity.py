@@ -1354,3 +1354,56 @@ def test_distributed_step_on_small_and_ragged_boxes(D, nx, ny):
         x, y = y, x
         D.copy_field(x, z)
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+def test_a_wait_that_gave_up_is_loud_everywhere_and_dm_safe_changes_no_bit(D):
+    """(i) DLESM_DM_SAFE / dm_safe: ONE switch to the conservative distributed forms (own frame launch, event joins,
+    every strip unpacked) -- same bits as the one-launch / time-loop forms; (ii) a device-side wait that gives up raises a
+    process-wide sticky flag: from then on EVERY device entry fails loudly (not only the next step), until the host
+    program acknowledges it; the stream-concurrency probe can be re-run on demand"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dm_overhead import loopback_tables
+    D.parallel_init(0, 1, use_rccl=True)
+    L = D._cabi.lib()
+    g = _grid(D, 333, 129, 2)
+    a, b, c, d = (D.r2d_field(g, D.GO_T_POINTS) for _ in range(4))
+    it = a.internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    D.psy.hash_init(a, SEED + 21)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, a.device_ptr, D._cabi.DIRS_ALL, None))
+    for f in (b, c, d):
+        D.copy_field(a, f)
+    assert L.dlesm_probe_stream_concurrency(None) in (0, 1)
+    results = []
+    for safe in (0, 1):
+        _set_tuning(D, dm_safe=safe)
+        x, y = (a, b) if not safe else (c, d)
+        if safe:
+            D.copy_field(a, c)                            # (a was left untouched by the first pass: 4 steps -> a is `in` again)
+        for k in range(4):
+            step = L.dlesm_jacobi5_step_dm_pipelined if k < 3 else L.dlesm_jacobi5_step_dm
+            D._cabi.check(step(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), None))
+            x, y = y, x
+        D._cabi.check(L.dlesm_halo_plan_join(plan, None))
+        torch.cuda.synchronize()
+        results.append(x.get_data())
+    _set_tuning(D, dm_safe=0)
+    assert np.array_equal(results[0], results[1])
+    # (ii)
+    assert L.dlesm_wait_timed_out(0) == 0
+    _set_tuning(D, dm_inject_timeout=1)
+    val = C.c_double()
+    assert L.dlesm_wait_timed_out(0) == 1
+    for rc in (L.dlesm_checksum_f64(a.device_ptr, g.nx, g.ny, *it.box(), C.byref(val), None),
+               L.dlesm_stencil5_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), None),
+               L.dlesm_jacobi5_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), None),
+               L.dlesm_fill_f64(b.device_ptr, g.nx, g.ny, 1, 2, 1, 2, 0.0, None)):
+        assert rc == D._cabi.EHIP and b"gave up waiting" in L.dlesm_last_error()
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))        # destroying the plan is still possible
+    _set_tuning(D, dm_inject_timeout=0)
+    assert L.dlesm_wait_timed_out(1) == 1 and L.dlesm_wait_timed_out(0) == 0
+    D._cabi.check(L.dlesm_checksum_f64(a.device_ptr, g.nx, g.ny, *it.box(), C.byref(val), None))
