@@ -184,7 +184,10 @@ def jacobi_config(D, torch, stream, tile, alignment, steps, warmup=10):
     out = {"workload": f"jacobi5 {tile}x{tile} fp64, DL_ESM_ALIGNMENT={alignment} (ld {g.nx}; {baseline_config(tile)})",
            "tile": tile, "DL_ESM_ALIGNMENT": alignment, "ld": g.nx, "steps": steps,
            "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),
-           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           # two ping-pong arrays below ~150 MB each largely live in the 256 MiB Infinity Cache (the library keeps cached
+           # stores there for that reason): such a configuration is NOT bounded by HBM alone, and says so
+           "roofline": {"bound": "hbm" if g.nx * g.ny * 8 >= (150 << 20) else "hbm+infinity-cache",
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic_for(tile, alignment),
                         "traffic_source": TRAFFIC_SOURCE, "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells},
            "checksum": D.field_checksum(a)}
@@ -929,7 +932,8 @@ def main():
         "hbm_gbs_per_gpu": round(achieved, 1),
         "checksum": checksum, "dm_step_equals_stencil_plus_exchange": selfcheck,
         "dm_safe_fallback": dm_safe_fallback,
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm" if grid.nx * grid.ny * 8 >= (150 << 20) else "hbm+infinity-cache",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic_for(args.tile, args.alignment, fused), "traffic_source": TRAFFIC_SOURCE,
                      "kernel": j5_kernel if fused == 1 else f"jacobi5xt_tile<{fused},{XT_ROWS[fused]},dpp>",

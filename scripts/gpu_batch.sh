@@ -90,7 +90,7 @@ swcounters)   # occupancy / VALU / L2 counters of shallow_tile, one counter per 
     cat $OUT/swcounters_table.txt ;;
 pmcconfigs)   # fabric traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the other BASELINE Jacobi configurations
     [ -f $OUT/traffic.json ] || { [ -f profiles/traffic.json ] && cp profiles/traffic.json $OUT/traffic.json; }
-    for cfg in "8192 64" "4096 64" "16384 1"; do
+    for cfg in "8192 64" "4096 64" "16384 1" "4096 1"; do
         set -- $cfg
         rm -rf $OUT/pmcc_fetch $OUT/pmcc_write
         step pmccF$1 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcc_fetch -- python3 bench.py --tile $1 --alignment $2 --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile > $OUT/pmcc_fetch.log 2>&1
