@@ -81,6 +81,14 @@ shallowpmc)
     python scripts/parse_rocprof.py pmc $OUT/swpmc_fetch $OUT/swpmc_write "shallow 8192x8192/A64" $OUT/traffic_shallow.json shallow_tile 2>&1 | tail -12
     step swP 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sw_prof -- python3 scripts/shallow_bench.py --steps 10 --no-cpu --out $OUT/sw_tmp.json > $OUT/sw_prof.log 2>&1
     python scripts/parse_rocprof.py stats $OUT/sw_prof $OUT/sw_prof_summary.md | cut -c1-170 | tail -8 ;;
+swkpmc)   # fabric traffic of the seven GOcean kernels launched one by one (and time_smooth), 8192^2
+    rm -rf $OUT/swk_fetch $OUT/swk_write
+    step swkF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/swk_fetch -- python3 scripts/shallow_r3_probe.py --what kernels --steps 4 --passes 1 --out $OUT/swk_tmp.json > $OUT/swk_fetch.log 2>&1
+    step swkW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/swk_write -- python3 scripts/shallow_r3_probe.py --what kernels --steps 4 --passes 1 --out $OUT/swk_tmp.json > $OUT/swk_write.log 2>&1
+    rm -f $OUT/traffic_swk.json
+    for k in CuNE CvNE ZNE HNE UnewNE VnewNE PnewNE TimeSmooth; do
+        python scripts/parse_rocprof.py pmc $OUT/swk_fetch $OUT/swk_write "swk $k 8192x8192/A64" $OUT/traffic_swk.json "::$k," 2>&1 | grep -E "hbm_bytes_per_launch|no counter"
+    done ;;
 swcounters)   # occupancy / VALU / L2 counters of shallow_tile, one counter per pass (bench.py's shallow leg: 8192^2)
     rm -rf $OUT/swcounters
     for cnt in ${PMC_LIST:-VALUBusy MemUnitStalled MeanOccupancyPerActiveCU TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCP_TCC_READ_REQ_sum SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU FETCH_SIZE WRITE_SIZE}; do
