@@ -232,7 +232,9 @@ struct CellAcc {
     template <int k, int di, int dj> __device__ __forceinline__ double at() const { return a.in[k][o + di + (long)dj * ld]; }
 };
 
-template <class K, int R, bool NT>
+// NT: non-temporal stores of the output; NTL: non-temporal loads of the arrays this kernel reads exactly once per cell
+// (no south / north / west / east operand: uold in compute_unew, all three arrays of time_smooth ...)
+template <class K, int R, bool NT, bool NTL = false>
 __global__ __launch_bounds__(512) void swk_tile(KArgs a, int ld, int x0, int x1, int y0, int y1, int cb, int nxw)
 {
     const int lane = threadIdx.x & 63;
@@ -261,7 +263,9 @@ __global__ __launch_bounds__(512) void swk_tile(KArgs a, int ld, int x0, int x1,
         for (int k = 1 - K::RS[n]; k <= R + K::RN[n]; k++) {
             int jj = jb - 1 + k;
             if (jj > je + K::RN[n]) jj = je + K::RN[n];
-            const d2 v = *(const d2 *)(a.in[n] + (size_t)jj * ld + col);
+            const bool once = NTL && K::RS[n] == 0 && K::RN[n] == 0 && K::EW[n] == 0;
+            const d2 v = once ? __builtin_nontemporal_load((const d2 *)(a.in[n] + (size_t)jj * ld + col))
+                              : *(const d2 *)(a.in[n] + (size_t)jj * ld + col);
             rows[n][k] = V2{v.x, v.y};
             edge[n][k] = 0.0;
             if ((K::EW[n] & 1) && lane == 0) edge[n][k] = a.in[n][(size_t)jj * ld + ecol];
@@ -332,15 +336,21 @@ int launch_kernel(const char *who, const KArgs &a, int ld, int ny, int xstart, i
         if (tpb > 8) tpb = 8;                                  // the kernel is bounded to 512 threads
         const int strips = (h + R - 1) / R;
         const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
-        // store policy: as the other sweeps, non-temporal once the arrays outgrow the Infinity Cache -- except for a
-        // kernel that updates an array in place (time_smooth): the line it writes is the line it has just read
+        // Store policy: as the other sweeps, non-temporal once the arrays outgrow the Infinity Cache.  A kernel that updates
+        // an array IN PLACE (time_smooth) writes the line it has just read: with ordinary loads that line sits in L2 when the
+        // store arrives, and the kernel ran at 66-68 % of peak whatever the store policy; with non-temporal loads AND stores
+        // 75.4 % (8192^2, one process, scripts/shallow_r3_probe.py) -- a linear in-place sweep of the same arrays reaches
+        // 71.3-71.9 %, scripts/inplace_probe.py.  For the other kernels non-temporal loads of the once-read arrays change
+        // nothing (74.3 against 74.3 %), so only in-place kernels take them.
         bool in_place = false;
         for (int n = 0; n < K::NIN; n++) in_place = in_place || (const double *)a.out == a.in[n];
-        const int key = tuning("swk_nt", -1);
-        if (key >= 0 ? key != 0 : (nt_stores_for(ld, y0, y1) && !in_place))
-            hipLaunchKernelGGL((swk_tile<K, R, true>), dim3(grid), dim3(64 * tpb), 0, s, a, ld, x0, x1, y0, y1, cb, nxw);
-        else
-            hipLaunchKernelGGL((swk_tile<K, R, false>), dim3(grid), dim3(64 * tpb), 0, s, a, ld, x0, x1, y0, y1, cb, nxw);
+        const int key = tuning("swk_nt", -1), lkey = tuning("swk_ntl", -1);
+        const bool nts = key >= 0 ? key != 0 : nt_stores_for(ld, y0, y1) != 0;
+        const bool ntl = lkey >= 0 ? lkey != 0 : (in_place && nts);
+        if (nts && ntl) hipLaunchKernelGGL((swk_tile<K, R, true, true>), dim3(grid), dim3(64 * tpb), 0, s, a, ld, x0, x1, y0, y1, cb, nxw);
+        else if (nts) hipLaunchKernelGGL((swk_tile<K, R, true>), dim3(grid), dim3(64 * tpb), 0, s, a, ld, x0, x1, y0, y1, cb, nxw);
+        else if (ntl) hipLaunchKernelGGL((swk_tile<K, R, false, true>), dim3(grid), dim3(64 * tpb), 0, s, a, ld, x0, x1, y0, y1, cb, nxw);
+        else hipLaunchKernelGGL((swk_tile<K, R, false>), dim3(grid), dim3(64 * tpb), 0, s, a, ld, x0, x1, y0, y1, cb, nxw);
     } else {
         hipLaunchKernelGGL((swk_direct<K>), dim3((nx + 255) / 256, h > 4096 ? 4096 : h), dim3(256), 0, s, a, ld, x0, x1, y0, y1);
     }

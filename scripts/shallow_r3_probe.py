@@ -155,8 +155,8 @@ def main():
             "time_smooth": (32, lambda: L.dlesm_time_smooth_f64(ld, ny, xs, xe, ys, ye, 0.001, P["u"], P["unew"], P["uold"], sp)),
         }
         with torch.cuda.stream(s):
-          for swk_nt in (0, 1, -1):
-            tune(swk_nt=swk_nt)
+          for swk_nt in (0, 1, -1, 10, 11, 9):      # >= 9: + non-temporal loads of the once-read arrays (swk_ntl), store policy swk_nt - 10
+            tune(swk_nt=swk_nt if swk_nt < 9 else swk_nt - 10, swk_ntl=1 if swk_nt >= 9 else (0 if swk_nt >= 0 else -1))
             total = 0.0
             for name, (bytes_per_cell, fn) in calls.items():
                 def go():
@@ -180,6 +180,7 @@ def main():
                             out[f"shape {name} tpb={tpb} nxw={65 + pad}"] = ms
                     print(f"shapes {name:12s} " + " ".join(line), flush=True)
                 tune(j5_autoshape=1, j5_tpb=0, j5_pad_tiles=0)
+            tune(swk_nt=-1, swk_ntl=-1)
 
             def seq():   # (default store policy: the last pass above)
                 D.psy.invoke_shallow_kernel_sequence(tdt, *[F[n] for n in names9[:6]], F["cu"], F["cv"], F["z"], F["h"],

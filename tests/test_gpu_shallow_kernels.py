@@ -58,7 +58,7 @@ def _launch(D, name, offset, ld, ny, box, out, ins, s0, s1):
     return fn(offset, ld, ny, *box, o, *ptr, None)
 
 
-@pytest.mark.parametrize("swk_kernel", [0, 1], ids=["tile", "direct"])
+@pytest.mark.parametrize("swk_kernel", [0, 1, 2], ids=["tile", "direct", "tile-nt-loads-and-stores"])
 @pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW"])
 @pytest.mark.parametrize("name", O.SW_KERNELS)
 def test_each_kernel_matches_its_oracle_loop_nest(D, name, sw_offset, swk_kernel):
@@ -66,7 +66,10 @@ def test_each_kernel_matches_its_oracle_loop_nest(D, name, sw_offset, swk_kernel
     boxes from one cell to the largest the kernel's stencil allows (touching the array edge on the sides it does
     not read), ragged widths around the 62/63/64-lane tile boundaries; nothing outside the box is written"""
     import torch
-    D._cabi.lib().dlesm_set_tuning(b"swk_kernel", swk_kernel)
+    D._cabi.lib().dlesm_set_tuning(b"swk_kernel", swk_kernel & 1)
+    if swk_kernel == 2:                      # the cache policies large arrays get (in-place kernels: loads too)
+        D._cabi.lib().dlesm_set_tuning(b"swk_nt", 1)
+        D._cabi.lib().dlesm_set_tuning(b"swk_ntl", 1)
     prm = N.Params(DX, DY, DT)
     s0, s1 = N.kernel_scalars(name, prm)
     rw, re, rs, rn = N.KERNEL_RING[sw_offset][name]
@@ -96,7 +99,8 @@ def test_each_kernel_matches_its_oracle_loop_nest(D, name, sw_offset, swk_kernel
                 D._cabi.check(rc)
                 assert np.array_equal(out.cpu().numpy(), want), (name, sw_offset, ld, nyarr, box)
     finally:
-        D._cabi.lib().dlesm_set_tuning(b"swk_kernel", 0)
+        for key in (b"swk_kernel", b"swk_nt", b"swk_ntl"):
+            D._cabi.lib().dlesm_set_tuning(key, 0 if key == b"swk_kernel" else -1)
 
 
 def test_kernel_entries_reject_what_a_loop_nest_could_not_run(D):
