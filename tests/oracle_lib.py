@@ -217,6 +217,8 @@ def fortran_psy_lib():
         _flib = C.CDLL(so)
         _flib.psy_jacobi5_f.argtypes = [_dp, _dp] + [C.c_int] * 7
         _flib.psy_jacobi5_f.restype = None
+        _flib.psy_shallow_step_f.argtypes = [_dp] + [C.c_int] * 6 + [_dp] * 13 + [C.c_int]
+        _flib.psy_shallow_step_f.restype = None
     return _flib
 
 
@@ -300,3 +302,11 @@ def sw_kernel(name, sw_offset, ld, box, out, ins, s0=0.0, s1=0.0):
     assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"]
     rc = lib().orc_sw_kernel(SW_KERNELS.index(name), 1 if sw_offset else 0, ld, *box, s0, s1, out.ctypes.data, *ptr)
     assert rc == 0, rc
+
+
+def sw_step_fortran(prm, ld, box, u, v, p, uold, vold, pold, unew, vnew, pnew, threads=1, scratch=None):
+    """the NE-offset step as the seven Fortran PSy loop nests over pointwise GOcean kernels (oracle/cpu_psy_loops.f90),
+    OpenMP over jj: what a GOcean application runs on the CPU"""
+    sc = scratch if scratch is not None else [np.zeros_like(p) for _ in range(4)]
+    pr = np.array([prm.fsdx, prm.fsdy, prm.tdts8, prm.tdtsdx, prm.tdtsdy])
+    fortran_psy_lib().psy_shallow_step_f(pr, ld, p.shape[0], *box, u, v, p, uold, vold, pold, *sc, unew, vnew, pnew, threads)

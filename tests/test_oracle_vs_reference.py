@@ -253,6 +253,24 @@ def test_sw_step_against_independent_numpy(nx, ny, ld_extra):
         assert np.all(got[2] == 9.0)                       # nothing outside the box is written
 
 
+@pytest.mark.parametrize("threads", [1, 3])
+def test_fortran_psy_shallow_loops_equal_the_c_oracle(threads):
+    """the CPU form a GOcean application runs (pointwise Fortran kernels called from seven PSy loop nests, OpenMP over
+    jj; oracle/cpu_psy_loops.f90 -- timed by bench.py's shallow-water cpu_baseline) == orc_sw_step, bit for bit"""
+    import sw_numpy as N
+    ld, nyarr, box = 70, 41, (2, 68, 2, 39)
+    rng = np.random.default_rng(5)
+    prm = N.Params(1.0e5, 0.7e5, 90.0)
+    u, v, uold, vold = (rng.random((nyarr, ld)) - 0.5 for _ in range(4))
+    p, pold = (rng.random((nyarr, ld)) + 1.0 for _ in range(2))
+    want = [np.full((nyarr, ld), 9.0) for _ in range(3)]
+    got = [np.full((nyarr, ld), 9.0) for _ in range(3)]
+    O.sw_step(prm, ld, box, u, v, p, uold, vold, pold, *want)
+    O.sw_step_fortran(prm, ld, box, u, v, p, uold, vold, pold, *got, threads=threads)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
 def test_sw_constant_state_is_a_fixed_point():
     """u = v = c, p = P everywhere: z = 0, h uniform, divergence 0 => new == old exactly"""
     import sw_numpy as N
