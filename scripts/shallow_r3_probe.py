@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--tile", type=int, default=8192)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--passes", type=int, default=3)
+    ap.add_argument("--alignment", type=int, default=64, help="DL_ESM_ALIGNMENT (1 = the reference's default: odd leading dimension)")
     ap.add_argument("--what", default="ceilings,fused,periodic,kernels")
     ap.add_argument("--out", default="gpurun_out/shallow_r3_probe.json")
     args = ap.parse_args()
@@ -32,7 +33,7 @@ def main():
     import dl_esm_inf_amd as D
     L = D._cabi.lib()
     torch.cuda.set_device(0)
-    os.environ["DL_ESM_ALIGNMENT"] = "64"
+    os.environ["DL_ESM_ALIGNMENT"] = str(args.alignment)
     D.parallel_init(0, 1)
     s = torch.cuda.Stream()
     N = args.tile
@@ -86,7 +87,7 @@ def main():
     g = make_grid(False)
     F = make_state(g, False)
     ld, ny = g.nx, g.ny
-    nfield = ld * ny
+    nfield = (ld * ny) & ~1          # the linear sweeps take an even number of doubles
     prm = D.psy.shallow_params(g.dx, g.dy, 90.0)
     tdt = 180.0
 
