@@ -285,6 +285,15 @@ module dlesm_hip_mod
        type(c_ptr), value :: field, field_new, field_old, stream
        integer(c_int) :: rc
      end function
+     function dlesm_periodic_halos_apply_multi_f64(fields, nfields, ld, ny, internal, bc_x, bc_y, stream) &
+          bind(C, name="dlesm_periodic_halos_apply_multi_f64") result(rc)
+       import :: c_int, c_ptr, c_region
+       type(c_ptr), intent(in) :: fields(*)
+       integer(c_int), value :: nfields, ld, ny, bc_x, bc_y
+       type(c_region), intent(in) :: internal
+       type(c_ptr), value :: stream
+       integer(c_int) :: rc
+     end function
      function dlesm_periodic_halos_apply_f64(field, ld, ny, internal, bc_x, bc_y, stream) &
           bind(C, name="dlesm_periodic_halos_apply_f64") result(rc)
        import :: c_int, c_ptr, c_region

@@ -55,7 +55,7 @@ module dlesm_psy_mod
   public :: shallow_params, c_sw_params, device_sync, grid_to_device
   public :: invoke_compute_cu, invoke_compute_cv, invoke_compute_z, invoke_compute_h
   public :: invoke_compute_unew, invoke_compute_vnew, invoke_compute_pnew, invoke_time_smooth
-  public :: invoke_shallow_step_sw_periodic, plan_shallow_step_sw
+  public :: invoke_shallow_step_sw_periodic, plan_shallow_step_sw, invoke_periodic_halos_multi
 
 contains
 
@@ -505,6 +505,32 @@ contains
                                         int(fld%grid%boundary_conditions(2), c_int), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_periodic_halos: ' // dlesm_error_text())
   end subroutine invoke_periodic_halos
+
+  !> invoke_periodic_halos of up to four fields of one grid and internal region in TWO launches (all x copies, then all y
+  !! copies) instead of two per field: what follows compute_cu / cv / z / h, or the three kernels of the new time level
+  subroutine invoke_periodic_halos_multi(f1, f2, f3, f4)
+    type(r2d_field), intent(inout), target :: f1, f2
+    type(r2d_field), intent(inout), target, optional :: f3, f4
+    type(c_ptr) :: ptrs(4)
+    type(c_region) :: cint
+    integer(c_int) :: rc, n
+    if (f1%num_halos == 0) return
+    call need_device(f1);  call need_device(f2)
+    ptrs(1) = field_device_data(f1);  ptrs(2) = field_device_data(f2);  n = 2
+    if (present(f3)) then
+       call need_device(f3);  n = n + 1;  ptrs(n) = field_device_data(f3)
+    end if
+    if (present(f4)) then
+       call need_device(f4);  n = n + 1;  ptrs(n) = field_device_data(f4)
+    end if
+    associate (it => f1%internal)
+      cint = c_region(it%nx, it%ny, it%xstart, it%xstop, it%ystart, it%ystop)
+    end associate
+    rc = dlesm_periodic_halos_apply_multi_f64(ptrs, n, int(f1%grid%nx, c_int), int(f1%grid%ny, c_int), cint, &
+                                              int(f1%grid%boundary_conditions(1), c_int), &
+                                              int(f1%grid%boundary_conditions(2), c_int), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_periodic_halos_multi: ' // dlesm_error_text())
+  end subroutine invoke_periodic_halos_multi
 
   !> Optional planning call for invoke_shallow_step (like plan_jacobi5): the library times its
   !! launch shapes and cache policies on these fields once -- every trial is the same valid step

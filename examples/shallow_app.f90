@@ -73,6 +73,9 @@ program shallow_app
   if (mode > 0) then
      cu = r2d_field(model_grid, GO_U_POINTS);  cv = r2d_field(model_grid, GO_V_POINTS)
      z = r2d_field(model_grid, GO_F_POINTS);   h = r2d_field(model_grid, GO_T_POINTS)
+     ! place the four intermediates in HBM now (the PSy wrappers would otherwise allocate and upload them at their first
+     ! use, inside the timed loop: 4 x 537 MB over PCIe at 8192^2)
+     call invoke_copy(cu, f(1));  call invoke_copy(cv, f(1));  call invoke_copy(z, f(1));  call invoke_copy(h, f(1))
   else
      ! planning call (once, outside the time loop): the new level receives one valid step
      call plan_shallow_step_sw(shallow_params(model_grid%dx, model_grid%dy, dt), &
@@ -91,20 +94,17 @@ program shallow_app
         call invoke_compute_cv(cv, f(cur(3)), f(cur(2)))
         call invoke_compute_z(z, f(cur(3)), f(cur(1)), f(cur(2)))
         call invoke_compute_h(h, f(cur(3)), f(cur(1)), f(cur(2)))
-        call invoke_periodic_halos(cu);  call invoke_periodic_halos(cv)
-        call invoke_periodic_halos(z);   call invoke_periodic_halos(h)
+        call invoke_periodic_halos_multi(cu, cv, z, h)     ! the periodic copies of the four intermediates: two launches
         call invoke_compute_unew(f(new(1)), f(old(1)), z, cv, h, tdt)
         call invoke_compute_vnew(f(new(2)), f(old(2)), z, cu, h, tdt)
         call invoke_compute_pnew(f(new(3)), f(old(3)), cu, cv, tdt)
-        do k = 1, 3
-           call invoke_periodic_halos(f(new(k)))
-        end do
+        call invoke_periodic_halos_multi(f(new(1)), f(new(2)), f(new(3)))
      end if
      if (mode == 2) then
         do k = 1, 3
            call invoke_time_smooth(f(cur(k)), f(new(k)), f(old(k)), alpha)
-           call invoke_periodic_halos(f(old(k)))
         end do
+        call invoke_periodic_halos_multi(f(old(1)), f(old(2)), f(old(3)))
         tmp = cur;  cur = new;  new = tmp                  ! u <- unew; uold holds the smoothed u already
      else
         tmp = old;  old = cur;  cur = new;  new = tmp      ! leapfrog rotation

@@ -222,6 +222,23 @@ def main():
                     out[f"sw_nt={nt} {label}"] = {"ms": ms, "gbs": gbs, "frac": gbs / 8000.0}
                     print(f"periodic sw_nt={nt} {label:24s}: {ms:.4f} ms  {gbs:7.0f} GB/s  {gbs / 80:.2f} %", flush=True)
             tune(sw_nt=2)
+            # the seven kernels on this (SW-offset, periodic) grid: with the periodic copies of the intermediates, and bare
+            cur, old, new = [G[n] for n in "uvp"], [G[n + "old"] for n in "uvp"], [G[n + "new"] for n in "uvp"]
+
+            def seq_p():
+                D.psy.invoke_shallow_kernel_sequence(tdt, *cur, *old, G["cu"], G["cv"], G["z"], G["h"], *new, stream=s)
+
+            def seq_p_halos():
+                seq_p()
+                D.psy.apply_periodic_halos_multi(new, stream=s)
+
+            def copies4():
+                D.psy.apply_periodic_halos_multi([G["cu"], G["cv"], G["z"], G["h"]], stream=s)
+            for label, fn in (("seven kernels + copies of cu, cv, z, h", seq_p), ("... + copies of the new level", seq_p_halos),
+                              ("the periodic copies of four fields alone (2 launches)", copies4)):
+                ms = timed(fn, max(4, args.steps // 3))
+                out[label] = {"ms": ms}
+                print(f"periodic {label:56s}: {ms:.4f} ms  {cells / ms / 1e3:9.0f} Mcells/s", flush=True)
         res["periodic"] = out
 
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
