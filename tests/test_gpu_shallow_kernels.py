@@ -103,6 +103,96 @@ def test_each_kernel_matches_its_oracle_loop_nest(D, name, sw_offset, swk_kernel
             D._cabi.lib().dlesm_set_tuning(key, 0 if key == b"swk_kernel" else -1)
 
 
+@pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW"])
+@pytest.mark.parametrize("name", O.SW_KERNELS)
+def test_each_kernel_follows_ieee_on_special_values_like_the_cpu(D, name, sw_offset):
+    """subnormals (not flushed), signed zeros, infinities, NaNs, overflow, and -- compute_z -- division by an exact zero
+    and 0/0: bit-identical to the CPU loop nest wherever its result is not a NaN, NaN where it has a NaN"""
+    import torch
+    prm = N.Params(DX, DY, DT)
+    s0, s1 = N.kernel_scalars(name, prm)
+    rw, re, rs, rn = N.KERNEL_RING[sw_offset][name]
+    ld, nyarr = 260, 40
+    rng = np.random.default_rng(11 + len(name))
+    host = []
+    for k in range(N.KERNEL_NIN[name]):
+        h = rng.random((nyarr, ld)) - 0.5
+        h[2:6, 10:60] = (rng.random((4, 50)) - 0.5) * 1e-310            # subnormals
+        h[8:10, 20:70] = -0.0
+        h[8:10, 70:120] = 0.0
+        h[12:14, 30:90] = 1.5e308 * (1 if k % 2 else -1)                  # sums / products overflow
+        h[16, 40 + 3 * k] = np.inf
+        h[17, 90 + 5 * k] = -np.inf
+        h[19, 130 + 7 * k] = np.nan
+        h[22:26, 100:200] = np.ldexp(rng.random((4, 100)), -1068)         # results around the subnormal boundary
+        host.append(h)
+    if name == "z":
+        host[0][28:32, 50:150] = 0.0                                      # the four p's of the denominator: x/0 and 0/0
+        host[1][30:32, 50:150] = 0.0
+        host[2][30:32, 50:150] = 0.0
+    dev = [torch.from_numpy(h).cuda() for h in host]
+    box = (1 + rw, ld - re, 1 + rs, nyarr - rn)
+    offset = D.GO_OFFSET_SW if sw_offset else D.GO_OFFSET_NE
+    with np.errstate(all="ignore"):
+        if name == "time_smooth":
+            want = host[2].copy()
+            O.sw_kernel(name, sw_offset, ld, box, want, [host[0], host[1], want], s0, s1)
+            out = dev[2].clone()
+            rc = _launch(D, name, offset, ld, nyarr, box, out, [dev[0], dev[1], out], s0, s1)
+        else:
+            want = np.full((nyarr, ld), 9.0)
+            O.sw_kernel(name, sw_offset, ld, box, want, host, s0, s1)
+            out = torch.full((nyarr, ld), 9.0, dtype=torch.float64, device="cuda")
+            rc = _launch(D, name, offset, ld, nyarr, box, out, dev, s0, s1)
+    D._cabi.check(rc)
+    got = out.cpu().numpy()
+    nan_w = np.isnan(want)
+    assert np.array_equal(nan_w, np.isnan(got)), name
+    assert np.array_equal(got[~nan_w].view(np.uint64), want[~nan_w].view(np.uint64)), name
+    assert np.count_nonzero(nan_w) > 0
+    if name == "z":
+        assert np.count_nonzero(np.isinf(want)) > 0
+
+
+@pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW"])
+@pytest.mark.parametrize("sw_nt", [2, 10])
+def test_fused_step_follows_ieee_on_special_values_like_the_cpu(D, sw_offset, sw_nt):
+    """the fused step (wave-tile kernel, plain and straight-line form) on states that hold subnormals, signed zeros,
+    infinities, NaNs, overflowing products and zero depth (division by zero in the vorticity): as the oracle's step"""
+    import torch
+    L = D._cabi.lib()
+    L.dlesm_set_tuning(b"sw_nt", sw_nt)
+    ld, nyarr, box = 264, 40, (2, 262, 2, 39)
+    rng = np.random.default_rng(3)
+    H = []
+    for k in range(6):
+        h = rng.random((nyarr, ld)) - 0.5 + (1.5 if k in (2, 5) else 0.0)
+        h[3:6, 10:60] = (rng.random((3, 50)) - 0.5) * 1e-310
+        h[8:10, 20:70] = -0.0
+        h[12:14, 30:90] = 1.2e308 * (1 if k % 2 else -1)
+        h[16, 40 + 3 * k] = np.inf
+        h[19, 130 + 7 * k] = np.nan
+        h[22:26, 100:200] = np.ldexp(rng.random((4, 100)), -1068)
+        H.append(h)
+    H[2][28:32, 50:150] = 0.0                                             # p = 0: z = x/0, 0/0
+    prm = D.psy.shallow_params(DX, DY, DT)
+    want = [np.full((nyarr, ld), 9.0) for _ in range(3)]
+    with np.errstate(all="ignore"):
+        (O.sw_step_sw if sw_offset else O.sw_step)(prm, ld, box, *H, *want)
+    dev = [torch.from_numpy(h).cuda() for h in H]
+    out = [torch.full((nyarr, ld), 9.0, dtype=torch.float64, device="cuda") for _ in range(3)]
+    fn = L.dlesm_shallow_step_sw_f64 if sw_offset else L.dlesm_shallow_step_f64
+    D._cabi.check(fn(C.byref(prm), ld, nyarr, *box, *[C.c_void_p(t.data_ptr()) for t in dev + out], None))
+    torch.cuda.synchronize()
+    L.dlesm_set_tuning(b"sw_nt", 2)
+    for w, o in zip(want, out):
+        got = o.cpu().numpy()
+        nan_w = np.isnan(w)
+        assert np.array_equal(nan_w, np.isnan(got))
+        assert np.array_equal(got[~nan_w].view(np.uint64), w[~nan_w].view(np.uint64))
+        assert np.count_nonzero(nan_w) > 0
+
+
 def test_kernel_entries_reject_what_a_loop_nest_could_not_run(D):
     import torch
     L = D._cabi.lib()
