@@ -125,6 +125,8 @@ PROTOTYPES = {
     "dlesm_shallow_step_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_shallow_autotune_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_shallow_autotune_sw_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
+    "dlesm_shallow_step_smooth_f64": (_i, [C.POINTER(SwParams), _d, _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
+    "dlesm_shallow_step_sw_smooth_periodic_f64": (_i, [C.POINTER(SwParams), _d, _i, _i, C.POINTER(Region), _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_compute_cu_f64": (_i, [_i] * 7 + [_vp] * 3 + [_vp]),
     "dlesm_compute_cv_f64": (_i, [_i] * 7 + [_vp] * 3 + [_vp]),
     "dlesm_compute_z_f64": (_i, [_i] * 7 + [_d, _d] + [_vp] * 4 + [_vp]),

@@ -201,7 +201,8 @@ struct SwFrameJob {
 void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,
                          const double *u, const double *v, const double *p, const double *uold,
                          const double *vold, const double *pold, double *unew, double *vnew,
-                         double *pnew, hipStream_t s, bool sw_offset = false, SwFrameJob *fj = nullptr, int wrap = 0);
+                         double *pnew, hipStream_t s, bool sw_offset = false, SwFrameJob *fj = nullptr, int wrap = 0,
+                         const double *smooth_alpha = nullptr);   // non-null: also uold/vold/pold <- time_smooth, in place
 // frame of the box + interior sweep of the NE shallow-water step in one launch; *fused = false (nothing
 // launched) when the arrays do not qualify for the tile kernel
 int launch_shallow_framed(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart, int ystop,

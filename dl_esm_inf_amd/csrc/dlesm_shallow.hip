@@ -50,6 +50,14 @@ template <bool DPP> __device__ __forceinline__ V2 east_of(const V2 &a) { return 
 template <bool DPP> __device__ __forceinline__ V2 west_of(const V2 &a) { return V2{from_lower<DPP>(a.y), a.x}; }
 
 #define EW(expr_x, expr_y) V2{(expr_x), (expr_y)}
+// The Asselin filter of the GOcean leapfrog (time_smooth) folded into the step: with uo != nullptr
+// the old level is ALSO updated in place, uold <- u + alpha*(unew - 2*u + uold) (likewise v, p), from values the lane
+// already holds -- three more stores per cell instead of three more launches that re-read nine arrays: 96 B/cell for a
+// whole filtered time step against 72 + 3 x 32 = 168.  uo, vo, po are the old arrays themselves (writable).
+struct SwSmooth {
+    double alpha;
+    double *uo, *vo, *po;
+};
 __device__ __forceinline__ V2 pin_here(const V2 &a) { return V2{::dlesm::pin_here(a.x), ::dlesm::pin_here(a.y)}; }   // dlesm_internal.h
 // new time level stored non-temporally by default: +1.2 % at 8192^2 (profiles/r02_shallow_variants.txt)
 #define SW_NT_DEFAULT 2
@@ -61,8 +69,9 @@ template <int R, bool DPP, int NTM>
 __device__ __forceinline__ void shallow_tile_body(
     const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
-    const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
-    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, unsigned block, int stack = 1)
+    const double *uold, const double *vold, const double *pold,
+    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, unsigned block, int stack = 1,
+    SwSmooth sm = SwSmooth{0.0, nullptr, nullptr, nullptr})
 {
     auto east = [](const V2 &a) { return east_of<DPP>(a); };
     auto west = [](const V2 &a) { return west_of<DPP>(a); };
@@ -204,6 +213,19 @@ __device__ __forceinline__ void shallow_tile_body(
             if (m0) { unew[o] = un.x; vnew[o] = vn.x; pnew[o] = pn.x; }
             if (m1) { unew[o + 1] = un.y; vnew[o + 1] = vn.y; pnew[o + 1] = pn.y; }
         }
+        if (sm.uo) {     // time_smooth of the old level, in place: field_old = field + alpha*(field_new - 2*field + field_old)
+            const V2 us = EW(U[k].x + sm.alpha * (un.x - 2.0 * U[k].x + UO[k - 1].x), U[k].y + sm.alpha * (un.y - 2.0 * U[k].y + UO[k - 1].y));
+            const V2 vs = EW(Vv[k].x + sm.alpha * (vn.x - 2.0 * Vv[k].x + VO[k - 1].x), Vv[k].y + sm.alpha * (vn.y - 2.0 * Vv[k].y + VO[k - 1].y));
+            const V2 ps = EW(P[k].x + sm.alpha * (pn.x - 2.0 * P[k].x + PO[k - 1].x), P[k].y + sm.alpha * (pn.y - 2.0 * P[k].y + PO[k - 1].y));
+            if (m0 && m1) {
+                st2<(NTM & 2) != 0>(sm.uo + o, us);
+                st2<(NTM & 2) != 0>(sm.vo + o, vs);
+                st2<(NTM & 2) != 0>(sm.po + o, ps);
+            } else {
+                if (m0) { sm.uo[o] = us.x; sm.vo[o] = vs.x; sm.po[o] = ps.x; }
+                if (m1) { sm.uo[o + 1] = us.y; sm.vo[o + 1] = vs.y; sm.po[o + 1] = ps.y; }
+            }
+        }
     }
 }
 
@@ -212,10 +234,10 @@ template <int R, bool DPP, int NTM>
 __global__ __launch_bounds__(512) void shallow_tile(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
-    const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
-    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, int stack)
+    const double *uold, const double *vold, const double *pold,
+    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, int stack, SwSmooth sm)
 {
-    shallow_tile_body<R, DPP, NTM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, blockIdx.x, stack);
+    shallow_tile_body<R, DPP, NTM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, blockIdx.x, stack, sm);
 }
 
 // The distributed shallow-water step in ONE launch on the caller's stream (as jacobi5_tile_framed): the
@@ -298,8 +320,8 @@ template <int R, bool DPP, int NTM>
 __global__ __launch_bounds__(512) void shallow_tile_sw(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
-    const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
-    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, int wrap)
+    const double *uold, const double *vold, const double *pold,
+    double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, int wrap, SwSmooth sm)
 {
     auto east = [](const V2 &a) { return east_of<DPP>(a); };
     auto west = [](const V2 &a) { return west_of<DPP>(a); };
@@ -413,23 +435,33 @@ __global__ __launch_bounds__(512) void shallow_tile_sw(
             if (jj == y0) rows[nrows++] = y1 + 1;
             if (jj == y1) rows[nrows++] = y0 - 1;
         }
-        for (int r = 0; r < nrows; r++) {
-            const size_t row = (size_t)rows[r] * ld, o = row + (size_t)c * 2;
-            if (m0 && m1) {
-                st2<(NTM & 2) != 0>(unew + o, un);
-                st2<(NTM & 2) != 0>(vnew + o, vn);
-                st2<(NTM & 2) != 0>(pnew + o, pn);
-            } else {
-                if (m0) { unew[o] = un.x; vnew[o] = vn.x; pnew[o] = pn.x; }
-                if (m1) { unew[o + 1] = un.y; vnew[o + 1] = vn.y; pnew[o + 1] = pn.y; }
+        // one time level (three arrays) into this row and its periodic images
+        auto store3 = [&](double *fu, double *fv, double *fp, const V2 &a, const V2 &b, const V2 &d) {
+            for (int r = 0; r < nrows; r++) {
+                const size_t row = (size_t)rows[r] * ld, o = row + (size_t)c * 2;
+                if (m0 && m1) {
+                    st2<(NTM & 2) != 0>(fu + o, a);
+                    st2<(NTM & 2) != 0>(fv + o, b);
+                    st2<(NTM & 2) != 0>(fp + o, d);
+                } else {
+                    if (m0) { fu[o] = a.x; fv[o] = b.x; fp[o] = d.x; }
+                    if (m1) { fu[o + 1] = a.y; fv[o + 1] = b.y; fp[o + 1] = d.y; }
+                }
+                if (wrap & 1) {     // the first / last internal column also goes to the opposite halo column
+                    const int i0 = 2 * c, i1 = 2 * c + 1;
+                    if (m0 && i0 == x0) { fu[row + x1 + 1] = a.x; fv[row + x1 + 1] = b.x; fp[row + x1 + 1] = d.x; }
+                    if (m1 && i1 == x0) { fu[row + x1 + 1] = a.y; fv[row + x1 + 1] = b.y; fp[row + x1 + 1] = d.y; }
+                    if (m0 && i0 == x1) { fu[row + x0 - 1] = a.x; fv[row + x0 - 1] = b.x; fp[row + x0 - 1] = d.x; }
+                    if (m1 && i1 == x1) { fu[row + x0 - 1] = a.y; fv[row + x0 - 1] = b.y; fp[row + x0 - 1] = d.y; }
+                }
             }
-            if (wrap & 1) {     // the first / last internal column also goes to the opposite halo column
-                const int i0 = 2 * c, i1 = 2 * c + 1;
-                if (m0 && i0 == x0) { unew[row + x1 + 1] = un.x; vnew[row + x1 + 1] = vn.x; pnew[row + x1 + 1] = pn.x; }
-                if (m1 && i1 == x0) { unew[row + x1 + 1] = un.y; vnew[row + x1 + 1] = vn.y; pnew[row + x1 + 1] = pn.y; }
-                if (m0 && i0 == x1) { unew[row + x0 - 1] = un.x; vnew[row + x0 - 1] = vn.x; pnew[row + x0 - 1] = pn.x; }
-                if (m1 && i1 == x1) { unew[row + x0 - 1] = un.y; vnew[row + x0 - 1] = vn.y; pnew[row + x0 - 1] = pn.y; }
-            }
+        };
+        store3(unew, vnew, pnew, un, vn, pn);
+        if (sm.uo) {     // time_smooth of the old level, in place (and its periodic images): see SwSmooth
+            const V2 us = EW(U[k].x + sm.alpha * (un.x - 2.0 * U[k].x + UO[k - 1].x), U[k].y + sm.alpha * (un.y - 2.0 * U[k].y + UO[k - 1].y));
+            const V2 vs = EW(Vv[k].x + sm.alpha * (vn.x - 2.0 * Vv[k].x + VO[k - 1].x), Vv[k].y + sm.alpha * (vn.y - 2.0 * Vv[k].y + VO[k - 1].y));
+            const V2 ps = EW(P[k].x + sm.alpha * (pn.x - 2.0 * P[k].x + PO[k - 1].x), P[k].y + sm.alpha * (pn.y - 2.0 * P[k].y + PO[k - 1].y));
+            store3(sm.uo, sm.vo, sm.po, us, vs, ps);
         }
     }
 }
@@ -487,10 +519,12 @@ static void sw_rule_shape(int ld, int x0, int x1, int *nxw_out, int *tpb_out)
 void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1,
                          const double *u, const double *v, const double *p, const double *uold,
                          const double *vold, const double *pold, double *unew, double *vnew,
-                         double *pnew, hipStream_t s, bool sw_offset, SwFrameJob *fj, int wrap)
+                         double *pnew, hipStream_t s, bool sw_offset, SwFrameJob *fj, int wrap, const double *smooth_alpha)
 {
     const int cb = sw_first_chunk(x0);
     int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & 15;
+    SwSmooth sm{0.0, nullptr, nullptr, nullptr};
+    if (smooth_alpha) sm = SwSmooth{*smooth_alpha, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold)};
     {
         std::lock_guard<std::mutex> lk(g_sw_mu);
         auto it = g_sw_cache.find(SwKey{ld, x0, x1, y0, y1, sw_offset ? 1 : 0});
@@ -499,6 +533,9 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
         else sw_rule_shape(ld, x0, x1, &nxw, &tpb);
     }
     if (tpb > 8) tpb = 8;                                // the kernel is bounded to 512 threads
+    // the old level updated in place: non-temporal stores want non-temporal loads of it too (the in-place finding of
+    // time_smooth, dlesm_shallow_kernels.hip: a store into a line its own load has just left in L2 is the slow case)
+    if (sm.uo && (ntm & 2) && tuning("sw_smooth_ntl", 1)) ntm |= 1;
     int R = tuning("sw_tile_rows", 2);
     if (R != 1 && R != 3) R = 2;
     const int h = y1 - y0 + 1, strips = (h + R - 1) / R;
@@ -530,10 +567,10 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     do {                                                                                                       \
         if (sw_offset)                                                                                         \
             hipLaunchKernelGGL((shallow_tile_sw<RR, DD, NN>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
-                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, wrap);                \
+                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, wrap, sm);            \
         else                                                                                                   \
             hipLaunchKernelGGL((shallow_tile<RR, DD, NN>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
-                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, stack);               \
+                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, stack, sm);           \
     } while (0)
 #define DLESM_SW2(RR, DD)                                                                                      \
     do {                                                                                                       \
@@ -703,6 +740,81 @@ extern "C" int dlesm_shallow_step_sw_periodic_f64(const dlesm_sw_params *q, int 
     if (!wrap) return DLESM_OK;
     double *fields[3] = {unew, vnew, pnew};
     return dlesm_periodic_halos_apply_multi_f64(fields, 3, ld, ny, internal, bc_x, bc_y, stream);
+}
+
+// ---- the step WITH the Asselin filter of the old level (time_smooth) folded in: one launch = one whole time step of
+// the GOcean leapfrog, 96 B/cell (six arrays read, six written) instead of 72 + 3 x 32 = 168 for step + three filters.
+static bool nine_aligned(int ld, int xstop, const double *u, const double *v, const double *p, const double *uold,
+                         const double *vold, const double *pold, const double *unew, const double *vnew, const double *pnew)
+{
+    bool aligned = ld % 2 == 0 || (xstop - 1) + 1 <= 2 * (ld / 2) - 1;
+    for (const double *f : {u, v, p, uold, vold, pold, unew, vnew, pnew}) aligned = aligned && ((uintptr_t)f % 16 == 0);
+    return aligned;
+}
+static int nine_distinct(const char *who, const double *u, const double *v, const double *p, const double *uold,
+                         const double *vold, const double *pold, const double *unew, const double *vnew, const double *pnew)
+{
+    const double *a[9] = {u, v, p, uold, vold, pold, unew, vnew, pnew};
+    for (int i = 0; i < 9; i++)
+        for (int j = i + 1; j < 9; j++)
+            if (a[i] == a[j]) return fail(DLESM_EINVAL, "%s: the nine fields must be nine different arrays", who);
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_shallow_step_smooth_f64(const dlesm_sw_params *q, double alpha, int ld, int ny, int xstart, int xstop,
+                                             int ystart, int ystop, const double *u, const double *v, const double *p,
+                                             double *uold, double *vold, double *pold, double *unew, double *vnew,
+                                             double *pnew, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(q && u && v && p && uold && vold && pold && unew && vnew && pnew, "null pointer");
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("dlesm_shallow_step_smooth_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    if (int rc = nine_distinct("dlesm_shallow_step_smooth_f64", u, v, p, uold, vold, pold, unew, vnew, pnew)) return rc;
+    const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
+    const bool thin = nx <= tuning("sw_thin_box", 8) && nyb > 8;
+    if (nine_aligned(ld, xstop, u, v, p, uold, vold, pold, unew, vnew, pnew) && tuning("sw_kernel", 0) == 0 && !thin &&
+        tuning("sw_smooth_fused", 1)) {
+        launch_shallow_tile(*q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold, unew, vnew, pnew,
+                            (hipStream_t)stream, false, nullptr, 0, &alpha);
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
+    // the definition: the step, then time_smooth of each prognostic field
+    if (int rc = dlesm_shallow_step_f64(q, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, unew, vnew, pnew, stream))
+        return rc;
+    if (int rc = dlesm_time_smooth_f64(ld, ny, xstart, xstop, ystart, ystop, alpha, u, unew, uold, stream)) return rc;
+    if (int rc = dlesm_time_smooth_f64(ld, ny, xstart, xstop, ystart, ystop, alpha, v, vnew, vold, stream)) return rc;
+    return dlesm_time_smooth_f64(ld, ny, xstart, xstop, ystart, ystop, alpha, p, pnew, pold, stream);
+}
+
+extern "C" int dlesm_shallow_step_sw_smooth_periodic_f64(const dlesm_sw_params *q, double alpha, int ld, int ny,
+                                                         const dlesm_region *internal, int bc_x, int bc_y, const double *u,
+                                                         const double *v, const double *p, double *uold, double *vold,
+                                                         double *pold, double *unew, double *vnew, double *pnew, void *stream)
+{
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(q && internal && u && v && p && uold && vold && pold && unew && vnew && pnew, "null pointer");
+    const int xstart = internal->xstart, xstop = internal->xstop, ystart = internal->ystart, ystop = internal->ystop;
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("dlesm_shallow_step_sw_smooth_periodic_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    if (int rc = nine_distinct("dlesm_shallow_step_sw_smooth_periodic_f64", u, v, p, uold, vold, pold, unew, vnew, pnew)) return rc;
+    const int wrap = (bc_x == DLESM_BC_PERIODIC ? 1 : 0) | (bc_y == DLESM_BC_PERIODIC ? 2 : 0);
+    if (nine_aligned(ld, xstop, u, v, p, uold, vold, pold, unew, vnew, pnew) && tuning("sw_kernel", 0) == 0 &&
+        tuning("sw_wrap_fused", 1) && tuning("sw_smooth_fused", 1)) {
+        launch_shallow_tile(*q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold, unew, vnew, pnew,
+                            (hipStream_t)stream, true, nullptr, wrap, &alpha);
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
+    if (int rc = dlesm_shallow_step_sw_f64(q, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, unew, vnew, pnew, stream))
+        return rc;
+    if (int rc = dlesm_time_smooth_f64(ld, ny, xstart, xstop, ystart, ystop, alpha, u, unew, uold, stream)) return rc;
+    if (int rc = dlesm_time_smooth_f64(ld, ny, xstart, xstop, ystart, ystop, alpha, v, vnew, vold, stream)) return rc;
+    if (int rc = dlesm_time_smooth_f64(ld, ny, xstart, xstop, ystart, ystop, alpha, p, pnew, pold, stream)) return rc;
+    if (!wrap) return DLESM_OK;
+    double *fields[6] = {unew, vnew, pnew, uold, vold, pold};
+    return dlesm_periodic_halos_apply_multi_f64(fields, 6, ld, ny, internal, bc_x, bc_y, stream);
 }
 
 // Up to 16 fields x 2 independent patch copies in one launch: grid.y = field * 2 + copy.

@@ -56,6 +56,7 @@ module dlesm_psy_mod
   public :: invoke_compute_cu, invoke_compute_cv, invoke_compute_z, invoke_compute_h
   public :: invoke_compute_unew, invoke_compute_vnew, invoke_compute_pnew, invoke_time_smooth
   public :: invoke_shallow_step_sw_periodic, plan_shallow_step_sw, invoke_periodic_halos_multi
+  public :: invoke_shallow_step_smooth, invoke_shallow_step_sw_smooth_periodic
 
 contains
 
@@ -342,6 +343,50 @@ contains
                                             c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_shallow_step_sw_periodic: ' // dlesm_error_text())
   end subroutine invoke_shallow_step_sw_periodic
+
+  !> One WHOLE time step of the GOcean leapfrog in one launch (NE offset): the u/v/h update and the Asselin filter of the
+  !! old level (time_smooth) in place -- == invoke_shallow_step followed by invoke_time_smooth of u, v and p, bit for bit, at
+  !! 96 B/cell instead of 168.  Afterwards rotate u <- unew (uold already holds the filtered u).
+  subroutine invoke_shallow_step_smooth(prm, alpha, u, v, p, uold, vold, pold, unew, vnew, pnew)
+    type(c_sw_params), intent(in) :: prm
+    real(go_wp), intent(in) :: alpha
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    rc = dlesm_shallow_step_smooth_f64(prm, alpha, int(p%grid%nx, c_int), int(p%grid%ny, c_int), &
+                                       int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                                       int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                                       field_device_data(u), field_device_data(v), field_device_data(p), &
+                                       field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                       field_device_data(unew), field_device_data(vnew), field_device_data(pnew), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_smooth: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_smooth
+
+  !> The same for the SW-offset periodic model: update, filter and the periodic images of the new and of the filtered old
+  !! level in ONE launch -- a whole time step of the GOcean `shallow` benchmark.
+  subroutine invoke_shallow_step_sw_smooth_periodic(prm, alpha, u, v, p, uold, vold, pold, unew, vnew, pnew)
+    type(c_sw_params), intent(in) :: prm
+    real(go_wp), intent(in) :: alpha
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew
+    type(c_region) :: cint
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    associate (it => p%internal)
+      cint = c_region(it%nx, it%ny, it%xstart, it%xstop, it%ystart, it%ystop)
+    end associate
+    rc = dlesm_shallow_step_sw_smooth_periodic_f64(prm, alpha, int(p%grid%nx, c_int), int(p%grid%ny, c_int), cint, &
+                                                   int(p%grid%boundary_conditions(1), c_int), &
+                                                   int(p%grid%boundary_conditions(2), c_int), &
+                                                   field_device_data(u), field_device_data(v), field_device_data(p), &
+                                                   field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                                   field_device_data(unew), field_device_data(vnew), field_device_data(pnew), &
+                                                   c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_sw_smooth_periodic: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_sw_smooth_periodic
 
   !> plan_shallow_step for the SW-offset step
   subroutine plan_shallow_step_sw(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)

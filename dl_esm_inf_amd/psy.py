@@ -258,6 +258,27 @@ def invoke_shallow_step_sw_periodic(params, u, v, p, uold, vold, pold, unew, vne
                                                          vnew.device_ptr, pnew.device_ptr, _stream_ptr(stream)))
 
 
+def invoke_shallow_step_smooth(params, alpha, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
+    """one whole leapfrog step of the GOcean benchmark in one launch (NE offset): the u/v/h update + time_smooth of the
+    old level in place (== invoke_shallow_step + 3 x invoke_time_smooth, bit for bit).  Afterwards rotate u <- unew."""
+    g, it = p.grid, p.internal
+    check(_cabi.lib().dlesm_shallow_step_smooth_f64(C.byref(params), float(alpha), g.nx, g.ny, it.xstart, it.xstop, it.ystart,
+                                                    it.ystop, u.device_ptr, v.device_ptr, p.device_ptr, uold.device_ptr,
+                                                    vold.device_ptr, pold.device_ptr, unew.device_ptr, vnew.device_ptr,
+                                                    pnew.device_ptr, _stream_ptr(stream)))
+
+
+def invoke_shallow_step_sw_smooth_periodic(params, alpha, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
+    """the same for the SW-offset periodic model: step + time_smooth + the periodic images of the new and of the filtered
+    old level, one launch"""
+    g = p.grid
+    check(_cabi.lib().dlesm_shallow_step_sw_smooth_periodic_f64(C.byref(params), float(alpha), g.nx, g.ny, C.byref(p.internal),
+                                                                g.boundary_conditions[0], g.boundary_conditions[1],
+                                                                u.device_ptr, v.device_ptr, p.device_ptr, uold.device_ptr,
+                                                                vold.device_ptr, pold.device_ptr, unew.device_ptr,
+                                                                vnew.device_ptr, pnew.device_ptr, _stream_ptr(stream)))
+
+
 def apply_periodic_halos(fld, stream=None):
     """the periodic-boundary copies of a field (field_mod.f90:1394-1464), on the device"""
     g = fld.grid

@@ -11,7 +11,9 @@
 !!                the new level -- seven kernel launches per step, every intermediate through HBM
 !!   2  kernels + time_smooth: mode 1 followed by the Asselin filter of the old level (alpha = 0.001), as the
 !!                benchmark's time loop has it; uold <- smoothed u, u <- unew by rotation
-!! Modes 0 and 1 print the same bits.
+!!   3  fused + time_smooth: ONE launch per time step (invoke_shallow_step_sw_smooth_periodic: update, Asselin filter of the
+!!                old level, periodic images of both levels)
+!! Modes 0 and 1 print the same bits; so do modes 2 and 3.
 !!     shallow_app.exe N NSTEPS [MODE]
 program shallow_app
   use iso_c_binding
@@ -70,7 +72,7 @@ program shallow_app
      call invoke_copy(f(k + 6), f(k))
   end do
   cur = (/1, 2, 3/);  old = (/4, 5, 6/);  new = (/7, 8, 9/)
-  if (mode > 0) then
+  if (mode == 1 .or. mode == 2) then
      cu = r2d_field(model_grid, GO_U_POINTS);  cv = r2d_field(model_grid, GO_V_POINTS)
      z = r2d_field(model_grid, GO_F_POINTS);   h = r2d_field(model_grid, GO_T_POINTS)
      ! place the four intermediates in HBM now (the PSy wrappers would otherwise allocate and upload them at their first
@@ -89,6 +91,10 @@ program shallow_app
         call invoke_shallow_step_sw_periodic(shallow_params(model_grid%dx, model_grid%dy, dt), &
                                              f(cur(1)), f(cur(2)), f(cur(3)), f(old(1)), f(old(2)), f(old(3)), &
                                              f(new(1)), f(new(2)), f(new(3)))
+     else if (mode == 3) then
+        call invoke_shallow_step_sw_smooth_periodic(shallow_params(model_grid%dx, model_grid%dy, dt), alpha, &
+                                                    f(cur(1)), f(cur(2)), f(cur(3)), f(old(1)), f(old(2)), f(old(3)), &
+                                                    f(new(1)), f(new(2)), f(new(3)))
      else
         call invoke_compute_cu(cu, f(cur(3)), f(cur(1)))
         call invoke_compute_cv(cv, f(cur(3)), f(cur(2)))
@@ -105,6 +111,8 @@ program shallow_app
            call invoke_time_smooth(f(cur(k)), f(new(k)), f(old(k)), alpha)
         end do
         call invoke_periodic_halos_multi(f(old(1)), f(old(2)), f(old(3)))
+     end if
+     if (mode >= 2) then
         tmp = cur;  cur = new;  new = tmp                  ! u <- unew; uold holds the smoothed u already
      else
         tmp = old;  old = cur;  cur = new;  new = tmp      ! leapfrog rotation

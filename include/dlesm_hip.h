@@ -327,6 +327,25 @@ int dlesm_shallow_step_sw_periodic_f64(const dlesm_sw_params *params, int ld, in
                                        const double *uold, const double *vold, const double *pold,
                                        double *unew, double *vnew, double *pnew, void *stream);
 
+/* One WHOLE time step of the GOcean leapfrog in one launch: the u/v/h update AND the Asselin filter of the old level
+ * (the benchmark's time_smooth kernel), from values the lanes already hold --
+ *     unew, vnew, pnew <- step(u, v, p, uold, vold, pold);   uold <- u + alpha*(unew - 2*u + uold)   (likewise vold, pold; in place)
+ * -- bit for bit what dlesm_shallow_step_f64 followed by three dlesm_time_smooth_f64 calls leave, at 96 B/cell
+ * (six arrays read, six written) instead of 72 + 3 x 32 = 168.  After the call the host program rotates
+ * u <- unew (uold already holds the filtered u; the former u buffers are free).  The nine arrays must be distinct. */
+int dlesm_shallow_step_smooth_f64(const dlesm_sw_params *params, double alpha, int ld, int ny,
+                                  int xstart, int xstop, int ystart, int ystop,
+                                  const double *u, const double *v, const double *p,
+                                  double *uold, double *vold, double *pold,
+                                  double *unew, double *vnew, double *pnew, void *stream);
+/* ... and the SW-offset form over the internal region of periodic fields, the periodic images of the new level AND of
+ * the filtered old level written by the same launch: a whole time step of the GOcean `shallow` benchmark = ONE launch. */
+int dlesm_shallow_step_sw_smooth_periodic_f64(const dlesm_sw_params *params, double alpha, int ld, int ny,
+                                              const dlesm_region *internal, int bc_x, int bc_y,
+                                              const double *u, const double *v, const double *p,
+                                              double *uold, double *vold, double *pold,
+                                              double *unew, double *vnew, double *pnew, void *stream);
+
 /* The GOcean `shallow` kernel set as SEPARATE launch entries: one per PSy loop nest, which is what a
  * PSyclone-generated PSy layer has -- `do jj / do ji / call compute_cu_code(ji, jj, cu%data, p%data,
  * u%data)` becomes dlesm_compute_cu_f64 over the same index box (kernel form infrastructure_mod.f90:13-41,

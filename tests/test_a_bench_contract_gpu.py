@@ -45,6 +45,8 @@ def test_bench_line_and_secondary_legs():
     un = sw["unfused"]
     assert "error" not in un and un["bit_identical_to_fused_step"] is True and un["roofline"]["algorithmic_bytes_per_cell"] == 224, un
     assert set(un["per_kernel"]) == {"cu", "cv", "z", "h", "unew", "vnew", "pnew"} and un["time_smooth"]["ms"] > 0, un
+    ts = sw["with_time_smooth"]
+    assert "error" not in ts and ts["bit_identical_to_step_plus_time_smooth"] is True and ts["roofline"]["algorithmic_bytes_per_cell"] == 96, ts
     assert sw["copy_ceiling"]["best_gbs"] > 0 and 0 < sw["roofline"]["frac_of_copy_ceiling"] < 2, sw
     assert sw["sw_offset_periodic"]["one_launch_equals_step_plus_halo_copies"] is True, sw["sw_offset_periodic"]
     assert d["copy_ceiling"]["best_gbs"] > 0 and 0 < d["roofline"]["frac_of_copy_ceiling"] < 2, d["copy_ceiling"]

@@ -273,7 +273,7 @@ def test_fortran_device_io_and_jacobi_on_gpu(exe):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["fused", "seven-kernels", "seven-kernels+time_smooth"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["fused", "seven-kernels", "seven-kernels+time_smooth", "fused+time_smooth"])
 @pytest.mark.parametrize("n,nsteps,alignment", [(10, 5, None), (256, 6, 64)])
 def test_fortran_periodic_shallow_app_on_gpu(exe, n, nsteps, alignment, mode):
     """examples/shallow_app.f90 -- a GOcean-style SW-offset, doubly periodic shallow-water model written
@@ -298,7 +298,7 @@ def test_fortran_periodic_shallow_app_on_gpu(exe, n, nsteps, alignment, mode):
         O.sw_step_sw(prm, ld, it, *cur, *old, *new)
         for f in new:
             O.apply_periodic_halos(f, ld, it, 0, 0)
-        if mode == 2:
+        if mode >= 2:
             for c, nw, o in zip(cur, new, old):
                 O.sw_kernel("time_smooth", True, ld, it, o, [c, nw, o], 0.001)
                 O.apply_periodic_halos(o, ld, it, 0, 0)

@@ -332,3 +332,88 @@ def test_shallow_model_with_time_smoothing_against_the_oracle(D, nx, ny, alignme
             assert np.array_equal(got[:ye + 1, :xe + 1], H[n][:ye + 1, :xe + 1]), (step, n)
         cur, old, new = new, old, cur                  # u <- unew; uold already holds the smoothed u; the former u buffers are free
     assert np.all(np.isfinite(H[cur[2]][ys - 1:ye, xs - 1:xe]))
+
+
+@pytest.mark.parametrize("sw_kernel,sw_nt", [(0, 2), (0, 10), (0, 0), (1, 2)], ids=["tile", "tile-straight", "tile-cached", "direct"])
+@pytest.mark.parametrize("nx,ny,alignment", [(10, 10, None), (37, 5, 2), (64, 48, 8), (300, 77, None), (1021, 33, 64), (130, 260, 64)])
+@pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW-periodic"])
+def test_step_with_the_filter_folded_in_equals_step_plus_time_smooth(D, nx, ny, alignment, sw_offset, sw_kernel, sw_nt):
+    """one launch = one whole leapfrog step of the GOcean benchmark (dlesm_shallow_step_smooth_f64 /
+    dlesm_shallow_step_sw_smooth_periodic_f64: update + Asselin filter of the old level in place [+ the periodic images of
+    both levels]) == the fused step, three time_smooth launches [and the periodic copies], every field and halo, every bit;
+    and == the oracle's loop nests.  Three steps with the benchmark's rotation (u <- unew, uold keeps the filtered u)."""
+    import torch
+    L = D._cabi.lib()
+    L.dlesm_set_tuning(b"sw_kernel", sw_kernel)
+    L.dlesm_set_tuning(b"sw_nt", sw_nt)
+    try:
+        g = _grid(D, nx, ny, alignment, sw_offset)
+        names, A = _state(D, g)
+        _, B = _state(D, g)                                   # the same state twice
+        alpha = 0.001
+        prm = D.psy.shallow_params(g.dx, g.dy, DT)
+        oprm = N.Params(g.dx, g.dy, DT)
+        it = A["p"].internal
+        xs, xe, ys, ye = it.box()
+        torch.cuda.synchronize()
+        H = {n: A[n].get_data() for n in names}
+        cur, old, new = ["u", "v", "p"], ["uold", "vold", "pold"], ["unew", "vnew", "pnew"]
+        for step in range(3):
+            a = [A[n] for n in cur + old + new]
+            b = [B[n] for n in cur + old + new]
+            if sw_offset:
+                D.psy.invoke_shallow_step_sw_smooth_periodic(prm, alpha, *a)
+                D.psy.invoke_shallow_step_sw_periodic(prm, *b)
+            else:
+                D.psy.invoke_shallow_step_smooth(prm, alpha, *a)
+                D.psy.invoke_shallow_step(prm, *b)
+            for c, nw, o in zip(cur, new, old):
+                D.psy.invoke_time_smooth(B[c], B[nw], B[o], alpha)
+            if sw_offset:
+                D.psy.apply_periodic_halos_multi([B[n] for n in old])
+            # the oracle, loop nest by loop nest
+            (O.sw_step_sw if sw_offset else O.sw_step)(oprm, g.nx, it.box(), *[H[n] for n in cur + old + new])
+            for c, nw, o in zip(cur, new, old):
+                O.sw_kernel("time_smooth", sw_offset, g.nx, it.box(), H[o], [H[c], H[nw], H[o]], alpha)
+            if sw_offset:
+                for n in new + old:
+                    O.apply_periodic_halos(H[n], g.nx, it.box(), 0, 0)
+            torch.cuda.synchronize()
+            for n in new + old:
+                ga, gb = A[n].get_data(), B[n].get_data()
+                assert np.array_equal(ga[:ye + 1, :xe + 1], gb[:ye + 1, :xe + 1]), (step, n, "one launch != step + time_smooth")
+                assert np.array_equal(ga[:ye + 1, :xe + 1], H[n][:ye + 1, :xe + 1]), (step, n, "!= oracle")
+            cur, new = new, cur                               # u <- unew; uold holds the filtered u already
+    finally:
+        L.dlesm_set_tuning(b"sw_kernel", 0)
+        L.dlesm_set_tuning(b"sw_nt", 2)
+
+
+@pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW-periodic"])
+def test_step_with_the_filter_folded_in_at_8192(D, sw_offset):
+    """BASELINE configs[3]'s size: the one-launch time step against step + three time_smooth launches, on the device"""
+    import torch
+    g = _grid(D, 8192, 8192, 64, sw_offset)
+    names, A = _state(D, g)
+    del A["cu"], A["cv"], A["z"], A["h"]
+    prm = D.psy.shallow_params(g.dx, g.dy, DT)
+    B = {n: D.r2d_field(g, A[n].defined_on) for n in names[3:]}
+    for n in names[3:6]:
+        D.copy_field(A[n], B[n])
+    cur = [A[n] for n in names[:3]]
+    a = cur + [A[n] for n in names[3:]]
+    b = cur + [B[n] for n in names[3:]]
+    if sw_offset:
+        D.psy.invoke_shallow_step_sw_smooth_periodic(prm, 0.001, *a)
+        D.psy.invoke_shallow_step_sw_periodic(prm, *b)
+    else:
+        D.psy.invoke_shallow_step_smooth(prm, 0.001, *a)
+        D.psy.invoke_shallow_step(prm, *b)
+    for k in range(3):
+        D.psy.invoke_time_smooth(cur[k], b[6 + k], b[3 + k], 0.001)
+    if sw_offset:
+        D.psy.apply_periodic_halos_multi(b[3:6])
+    torch.cuda.synchronize()
+    n = 8192
+    for k in range(3, 9):
+        assert bool(torch.equal(a[k].data[:n + 2, :n + 2], b[k].data[:n + 2, :n + 2])), names[k]
