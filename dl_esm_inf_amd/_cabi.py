@@ -170,6 +170,8 @@ PROTOTYPES = {
     "dlesm_jacobi5_multi_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_shallow_step_dm": (_i, [_vp, C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_shallow_step_dm_pipelined": (_i, [_vp, C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
+    "dlesm_shallow_step_smooth_dm": (_i, [_vp, C.POINTER(SwParams), _d, _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
+    "dlesm_shallow_step_smooth_dm_pipelined": (_i, [_vp, C.POINTER(SwParams), _d, _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_global_sum_f64": (_i, [C.POINTER(_d)]),
     "dlesm_gather_f64": (_i, [_vp, _vp, _i]),
     "dlesm_pack_inner_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, C.c_long, _vp]),

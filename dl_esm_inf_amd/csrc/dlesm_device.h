@@ -116,6 +116,16 @@ __device__ __forceinline__ SwPoint shallow_values_ne(
     return r;
 }
 
+// time_smooth of ONE cell of the old level, in place: field_old = field + alpha*(field_new -
+// 2*field + field_old) for u, v and p, r holding the new level of the cell
+__device__ __forceinline__ void smooth_old_level(double alpha, size_t o, const double *u, const double *v, const double *p,
+                                                 const SwPoint &r, double *uold, double *vold, double *pold)
+{
+    uold[o] = u[o] + alpha * (r.un - 2.0 * u[o] + uold[o]);
+    vold[o] = v[o] + alpha * (r.vn - 2.0 * v[o] + vold[o]);
+    pold[o] = p[o] + alpha * (r.pn - 2.0 * p[o] + pold[o]);
+}
+
 __device__ __forceinline__ void shallow_point_ne(
     const dlesm_sw_params &q, int ld, size_t o, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ p, const double *__restrict__ uold, const double *__restrict__ vold,

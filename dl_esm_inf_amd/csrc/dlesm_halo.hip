@@ -924,7 +924,7 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
                                 int xstop, int ystart, int ystop, const double *u, const double *v,
                                 const double *pf, const double *uold, const double *vold,
                                 const double *pold, double *unew, double *vnew, double *pnew,
-                                hipStream_t s, bool pipelined)
+                                hipStream_t s, bool pipelined, const double *smooth_alpha = nullptr)
 {
     DLESM_REQUIRE(p != nullptr && q != nullptr, "null pointer");
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
@@ -941,6 +941,9 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
     if (!can_chain)
         if (int rc = join_pending(p, s)) return rc;
     auto box = [&](int xs, int xe, int ys, int ye) {
+        if (smooth_alpha)
+            return dlesm_shallow_step_smooth_f64(q, *smooth_alpha, ld, ny, xs, xe, ys, ye, u, v, pf, const_cast<double *>(uold),
+                                                 const_cast<double *>(vold), const_cast<double *>(pold), unew, vnew, pnew, s);
         return dlesm_shallow_step_f64(q, ld, ny, xs, xe, ys, ye, u, v, pf, uold, vold, pold, unew, vnew, pnew, s);
     };
     const bool comms = !p->sends.empty() || !p->recvs.empty();
@@ -989,7 +992,7 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
         job.halo_wait_ticks = remote_wait_ticks();
         bool fused = false;
         if (int rc = launch_shallow_framed(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew,
-                                           pnew, job, s, &fused))
+                                           pnew, job, s, &fused, smooth_alpha))
             return rc;
         if (fused) {
             p->frame_seq = job.seq;
@@ -1017,7 +1020,7 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
     }
     if (one_frame) {
         if (int rc = launch_shallow_frame(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew,
-                                          pnew, prepacked ? &fp : nullptr, s))
+                                          pnew, prepacked ? &fp : nullptr, s, smooth_alpha))
             return rc;
     } else {
         if (int rc = box(xstart, xstop, ystart, ystart)) return rc;
@@ -1056,6 +1059,26 @@ extern "C" int dlesm_shallow_step_dm_pipelined(dlesm_halo_plan *p, const dlesm_s
 {
     return shallow_step_dm_impl(p, q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew,
                                 (hipStream_t)stream, true);
+}
+
+// The distributed step with the Asselin filter of the old level folded in (dlesm_shallow_step_smooth_f64's arithmetic,
+// dlesm_shallow_step_dm's exchange): the filtered old level needs no exchange -- the next step reads it at (i, j) only.
+extern "C" int dlesm_shallow_step_smooth_dm(dlesm_halo_plan *p, const dlesm_sw_params *q, double alpha, int ld, int ny,
+                                            int xstart, int xstop, int ystart, int ystop, const double *u, const double *v,
+                                            const double *pf, double *uold, double *vold, double *pold, double *unew,
+                                            double *vnew, double *pnew, void *stream)
+{
+    return shallow_step_dm_impl(p, q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew,
+                                (hipStream_t)stream, false, &alpha);
+}
+
+extern "C" int dlesm_shallow_step_smooth_dm_pipelined(dlesm_halo_plan *p, const dlesm_sw_params *q, double alpha, int ld,
+                                                      int ny, int xstart, int xstop, int ystart, int ystop, const double *u,
+                                                      const double *v, const double *pf, double *uold, double *vold,
+                                                      double *pold, double *unew, double *vnew, double *pnew, void *stream)
+{
+    return shallow_step_dm_impl(p, q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew,
+                                (hipStream_t)stream, true, &alpha);
 }
 
 extern "C" int dlesm_global_sum_f64(double *value)

@@ -131,7 +131,7 @@ struct FramePack3 {
 int launch_shallow_frame(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                          const double *u, const double *v, const double *p, const double *uold,
                          const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
-                         const FramePack3 *pack, hipStream_t s);
+                         const FramePack3 *pack, hipStream_t s, const double *smooth_alpha = nullptr);
 
 // the frame as the first workgroups of the interior launch (jacobi5_tile_framed): when their last
 // one is done, `seq` is stored to `flag` (device memory; frame_flag_wait sleeps on it)
@@ -195,6 +195,8 @@ struct SwFrameJob {
     unsigned long long halo_seq;  // 0: no wait
     unsigned long long halo_wait_ticks;   // bound of that wait (remote_wait_ticks(); 0 = none)
     int *timed_out;
+    int smooth;                   // != 0: the Asselin filter of the old level folded in (time_smooth, coefficient alpha)
+    double alpha;
     int diag;                     // profiling only (results wrong): 1 = no frame cells, 2 = south/north rows only
 };
 // shallow-water step, register-tiled linear sweep (dlesm_shallow.hip); 0-based inclusive box
@@ -208,7 +210,7 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
 int launch_shallow_framed(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                           const double *u, const double *v, const double *p, const double *uold,
                           const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
-                          SwFrameJob job, hipStream_t s, bool *fused);
+                          SwFrameJob job, hipStream_t s, bool *fused, const double *smooth_alpha = nullptr);
 
 } // namespace dlesm
 

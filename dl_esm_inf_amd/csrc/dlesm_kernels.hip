@@ -910,21 +910,25 @@ __global__ __launch_bounds__(256) void shallow_step_direct_cols(
 // send buffer of the three new fields (FramePack3)
 __global__ __launch_bounds__(256) void shallow_frame_k(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, const double *__restrict__ u,
-    const double *__restrict__ v, const double *__restrict__ p, const double *__restrict__ uold,
-    const double *__restrict__ vold, const double *__restrict__ pold, double *__restrict__ unew,
-    double *__restrict__ vnew, double *__restrict__ pnew, FramePack3 pk)
+    const double *__restrict__ v, const double *__restrict__ p, const double *uold,
+    const double *vold, const double *pold, double *__restrict__ unew,
+    double *__restrict__ vnew, double *__restrict__ pnew, FramePack3 pk, int smooth, double alpha)
 {
     const long total = frame_cells(x1 - x0 + 1, y1 - y0 + 1);
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         int i, j;
         frame_index(t, x0, x1, y0, y1, i, j);
         const size_t o = (size_t)j * ld + i;
-        shallow_point_ne(q, ld, o, u, v, p, uold, vold, pold, unew, vnew, pnew);
+        const SwPoint r = shallow_values_ne(q, ld, o, u, v, p, uold, vold, pold);
+        unew[o] = r.un;
+        vnew[o] = r.vn;
+        pnew[o] = r.pn;
+        if (smooth) smooth_old_level(alpha, o, u, v, p, r, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold));
         for (int k = 0; k < pk.n; k++)
             if (pk.holds(k, i, j)) {
-                pk.buf[pk.slot(k, 0, i, j)] = unew[o];
-                pk.buf[pk.slot(k, 1, i, j)] = vnew[o];
-                pk.buf[pk.slot(k, 2, i, j)] = pnew[o];
+                pk.buf[pk.slot(k, 0, i, j)] = r.un;
+                pk.buf[pk.slot(k, 1, i, j)] = r.vn;
+                pk.buf[pk.slot(k, 2, i, j)] = r.pn;
             }
     }
 }
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(256) void shallow_frame_k(
 int launch_shallow_frame(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                          const double *u, const double *v, const double *p, const double *uold,
                          const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
-                         const FramePack3 *pack, hipStream_t s)
+                         const FramePack3 *pack, hipStream_t s, const double *smooth_alpha)
 {
     if (xstop < xstart || ystop < ystart) return DLESM_OK;
     if (int rc = check_box("shallow frame", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
@@ -942,7 +946,8 @@ int launch_shallow_frame(const dlesm_sw_params &q, int ld, int ny, int xstart, i
     FramePack3 pk{};
     if (pack) pk = *pack;
     hipLaunchKernelGGL(shallow_frame_k, dim3(blocks), dim3(256), 0, s, q, ld, xstart - 1, xstop - 1, ystart - 1,
-                       ystop - 1, u, v, p, uold, vold, pold, unew, vnew, pnew, pk);
+                       ystop - 1, u, v, p, uold, vold, pold, unew, vnew, pnew, pk, smooth_alpha ? 1 : 0,
+                       smooth_alpha ? *smooth_alpha : 0.0);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }

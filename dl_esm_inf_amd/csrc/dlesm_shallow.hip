@@ -250,12 +250,14 @@ template <int R, bool DPP, int NTM>
 __global__ __launch_bounds__(512) void shallow_tile_framed(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
-    const double *__restrict__ uold, const double *__restrict__ vold, const double *__restrict__ pold,
+    const double *uold, const double *vold, const double *pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, SwFrameJob fj)
 {
     if (blockIdx.x >= (unsigned)fj.nblocks) {
+        const SwSmooth sm = fj.smooth ? SwSmooth{fj.alpha, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold)}
+                                      : SwSmooth{0.0, nullptr, nullptr, nullptr};
         shallow_tile_body<R, DPP, NTM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew,
-                                       blockIdx.x - fj.nblocks);
+                                       blockIdx.x - fj.nblocks, 1, sm);
         return;
     }
     auto put = [](double *ptr, double val) { __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -288,6 +290,8 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
         put(unew + o, r.un);
         put(vnew + o, r.vn);
         put(pnew + o, r.pn);
+        // the filtered old level is read by nobody before the next launch: ordinary stores
+        if (fj.smooth) smooth_old_level(fj.alpha, o, u, v, p, r, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold));
         for (int k = 0; k < fj.pk.n; k++)
             if (fj.pk.holds(k, i, j)) {
                 put(fj.pk.buf + fj.pk.slot(k, 0, i, j), r.un);
@@ -551,6 +555,8 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     if ((ntm & 4) && (fj || sw_offset || R != 2 || !dpp)) ntm &= 11;      // old-level-first: NE only
     if ((ntm & 8) && (fj || R != 2 || !dpp)) ntm &= 3;                     // straight-line: both staggerings, R = 2, DPP
     if (fj) {   // NE offset, R = 2, the default wave shifts: the one form the distributed step uses
+        fj->smooth = sm.uo ? 1 : 0;
+        fj->alpha = sm.alpha;
         const long cells = 2L * (fj->fx1 - fj->fx0 + 1) + 2L * (fj->fy1 - fj->fy0 + 1);
         long nb = ((cells + 64 * tpb - 1) / (64 * tpb) + 7) & ~7L;    // a multiple of 8: tile groups keep their XCD
         fj->nblocks = (int)(nb < 8 ? 8 : nb > 512 ? 512 : nb);
@@ -613,7 +619,7 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
 int dlesm::launch_shallow_framed(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart,
                                  int ystop, const double *u, const double *v, const double *p, const double *uold,
                                  const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
-                                 SwFrameJob job, hipStream_t s, bool *fused)
+                                 SwFrameJob job, hipStream_t s, bool *fused, const double *smooth_alpha)
 {
     *fused = false;
     if (xstop - xstart < 2 || ystop - ystart < 2) return DLESM_OK;          // no interior: two-launch path
@@ -626,7 +632,7 @@ int dlesm::launch_shallow_framed(const dlesm_sw_params &q, int ld, int ny, int x
     job.fx0 = xstart - 1, job.fx1 = xstop - 1, job.fy0 = ystart - 1, job.fy1 = ystop - 1;
     job.diag = tuning("sw_dm_diag", 0);
     launch_shallow_tile(q, ld, xstart, xstop - 2, ystart, ystop - 2, u, v, p, uold, vold, pold, unew, vnew, pnew, s,
-                        false, &job);
+                        false, &job, 0, smooth_alpha);
     DLESM_HIP_TRY(hipGetLastError());
     *fused = true;
     return DLESM_OK;

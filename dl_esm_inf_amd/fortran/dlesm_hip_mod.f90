@@ -234,6 +234,26 @@ module dlesm_hip_mod
        type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
        integer(c_int) :: rc
      end function
+     function dlesm_shallow_step_smooth_dm(plan, params, alpha, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
+          uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_step_smooth_dm") result(rc)
+       import :: c_int, c_ptr, c_sw_params, c_double
+       type(c_ptr), value :: plan
+       type(c_sw_params), intent(in) :: params
+       real(c_double), value :: alpha
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_shallow_step_smooth_dm_pipelined(plan, params, alpha, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
+          uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_step_smooth_dm_pipelined") result(rc)
+       import :: c_int, c_ptr, c_sw_params, c_double
+       type(c_ptr), value :: plan
+       type(c_sw_params), intent(in) :: params
+       real(c_double), value :: alpha
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
+       integer(c_int) :: rc
+     end function
      function dlesm_shallow_autotune_sw_f64(params, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
           uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_autotune_sw_f64") result(rc)
        import :: c_int, c_ptr, c_sw_params

@@ -56,7 +56,7 @@ module dlesm_psy_mod
   public :: invoke_compute_cu, invoke_compute_cv, invoke_compute_z, invoke_compute_h
   public :: invoke_compute_unew, invoke_compute_vnew, invoke_compute_pnew, invoke_time_smooth
   public :: invoke_shallow_step_sw_periodic, plan_shallow_step_sw, invoke_periodic_halos_multi
-  public :: invoke_shallow_step_smooth, invoke_shallow_step_sw_smooth_periodic
+  public :: invoke_shallow_step_smooth, invoke_shallow_step_sw_smooth_periodic, invoke_shallow_step_smooth_dm
 
 contains
 
@@ -387,6 +387,44 @@ contains
                                                    c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_shallow_step_sw_smooth_periodic: ' // dlesm_error_text())
   end subroutine invoke_shallow_step_sw_smooth_periodic
+
+  !> The distributed form of invoke_shallow_step_smooth (one launch + the exchange of the new level hidden behind the interior):
+  !! `pipelined` = the time-loop form (halo_join(grid) after the loop); serial builds fall back to invoke_shallow_step_smooth.
+  subroutine invoke_shallow_step_smooth_dm(prm, alpha, u, v, p, uold, vold, pold, unew, vnew, pnew, pipelined)
+    use parallel_comms_mod, only: halo_plan_for
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(c_sw_params), intent(in) :: prm
+    real(go_wp), intent(in) :: alpha
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew
+    logical, intent(in), optional :: pipelined
+    logical :: pipe
+    integer(c_int) :: rc
+    if (.not. DIST_MEM_ENABLED) then
+       call invoke_shallow_step_smooth(prm, alpha, u, v, p, uold, vold, pold, unew, vnew, pnew)
+       return
+    end if
+    pipe = .false.
+    if (present(pipelined)) pipe = pipelined
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    if (pipe) then
+       rc = dlesm_shallow_step_smooth_dm_pipelined(halo_plan_for(p%grid%nx, p%grid%ny), prm, alpha, &
+                int(p%grid%nx, c_int), int(p%grid%ny, c_int), int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                field_device_data(u), field_device_data(v), field_device_data(p), &
+                field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                field_device_data(unew), field_device_data(vnew), field_device_data(pnew), c_null_ptr)
+    else
+       rc = dlesm_shallow_step_smooth_dm(halo_plan_for(p%grid%nx, p%grid%ny), prm, alpha, &
+                int(p%grid%nx, c_int), int(p%grid%ny, c_int), int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                field_device_data(u), field_device_data(v), field_device_data(p), &
+                field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                field_device_data(unew), field_device_data(vnew), field_device_data(pnew), c_null_ptr)
+    end if
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_smooth_dm: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_smooth_dm
 
   !> plan_shallow_step for the SW-offset step
   subroutine plan_shallow_step_sw(prm, u, v, p, uold, vold, pold, unew, vnew, pnew)

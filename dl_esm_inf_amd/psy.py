@@ -341,6 +341,15 @@ def invoke_shallow_step_dm_pipelined(params, u, v, p, uold, vold, pold, unew, vn
                                                       pnew.device_ptr, _stream_ptr(stream)))
 
 
+def invoke_shallow_step_smooth_dm(params, alpha, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None, pipelined=False):
+    """the distributed step with the Asselin filter of the old level folded in (joined or time-loop form)"""
+    g, it = p.grid, p.internal
+    fn = _cabi.lib().dlesm_shallow_step_smooth_dm_pipelined if pipelined else _cabi.lib().dlesm_shallow_step_smooth_dm
+    check(fn(grid_mod.halo_plan(g), C.byref(params), float(alpha), g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop,
+             u.device_ptr, v.device_ptr, p.device_ptr, uold.device_ptr, vold.device_ptr, pold.device_ptr, unew.device_ptr,
+             vnew.device_ptr, pnew.device_ptr, _stream_ptr(stream)))
+
+
 def halo_exchange_multi(fields, stream=None, dirs=_cabi.DIRS_ALL):
     """halo_exchange(1) of several fields of one grid in a single grouped RCCL launch"""
     g = fields[0].grid

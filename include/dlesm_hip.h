@@ -597,6 +597,21 @@ int dlesm_shallow_step_dm_pipelined(dlesm_halo_plan *plan, const dlesm_sw_params
                                     const double *uold, const double *vold, const double *pold,
                                     double *unew, double *vnew, double *pnew, void *stream);
 
+/* The two distributed forms of dlesm_shallow_step_smooth_f64 (the step with the Asselin filter of the old level folded
+ * in): dlesm_shallow_step_dm[_pipelined]'s frame / exchange / interior, uold, vold, pold filtered in place.  The filtered
+ * old level needs no exchange: the next step reads it at (i, j) only.  Same results as dlesm_shallow_step_dm[_pipelined]
+ * followed by three dlesm_time_smooth_f64 calls over the box, bit for bit. */
+int dlesm_shallow_step_smooth_dm(dlesm_halo_plan *plan, const dlesm_sw_params *params, double alpha, int ld, int ny,
+                                 int xstart, int xstop, int ystart, int ystop,
+                                 const double *u, const double *v, const double *p,
+                                 double *uold, double *vold, double *pold,
+                                 double *unew, double *vnew, double *pnew, void *stream);
+int dlesm_shallow_step_smooth_dm_pipelined(dlesm_halo_plan *plan, const dlesm_sw_params *params, double alpha,
+                                           int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                                           const double *u, const double *v, const double *p,
+                                           double *uold, double *vold, double *pold,
+                                           double *unew, double *vnew, double *pnew, void *stream);
+
 /* global_sum, parallel_utils_mod.f90:230-238: in-place sum of one host double
  * over all ranks (synchronous). */
 int dlesm_global_sum_f64(double *value);

@@ -277,3 +277,65 @@ def test_time_loop_forms_of_both_steps_share_a_plan(D):
     assert np.array_equal(q.get_data(), hq)
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
     g._halo_plan = None
+
+
+@pytest.mark.parametrize("nx,ny,alignment", [(2, 3, 2), (40, 33, 8), (257, 66, 64), (130, 9, None), (700, 300, 64)])
+@pytest.mark.parametrize("one_launch_frame,fused,pipelined", [(1, 1, True), (1, 1, False), (1, 0, False), (0, 0, False)])
+def test_distributed_step_with_the_filter_folded_in(D, nx, ny, alignment, one_launch_frame, fused, pipelined):
+    """dlesm_shallow_step_smooth_dm[_pipelined] -- the distributed step that also filters the old level in place (Asselin,
+    time_smooth) -- in a four-step time loop with the benchmark's rotation, RCCL in loop-back, against the oracle's step +
+    exchange of the new level + time_smooth of the old level, every field and halo, bit for bit; in the one-launch,
+    own-frame-launch and four-thin-boxes forms"""
+    import torch
+    from dm_overhead import loopback_tables
+    L = D._cabi.lib()
+    L.dlesm_set_tuning(b"sw_dm_frame", one_launch_frame)
+    L.dlesm_set_tuning(b"sw_dm_fused", fused)
+    try:
+        if alignment is None:
+            os.environ.pop("DL_ESM_ALIGNMENT", None)
+        else:
+            os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+        g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+        g.decompose(nx, ny)
+        D.grid_init(g, 1.0e5, 1.0e5)
+        os.environ.pop("DL_ESM_ALIGNMENT", None)
+        names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+        pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+        F = {n: D.r2d_field(g, pts[n[0]]) for n in names}
+        it = F["p"].internal
+        t = loopback_tables(D, it)
+        plan = C.c_void_p()
+        D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+        g._halo_plan = plan
+        for k, n in enumerate(names[:6]):
+            D.psy.hash_init(F[n], 300 + k)
+            F[n].data.mul_(0.01)
+            F[n].data.add_(1.0 if n[0] == "p" else -0.005)
+        for n in names[6:]:
+            D.set_field(F[n], 9.0)
+        D.psy.halo_exchange_multi([F[n] for n in names[:6]])
+        torch.cuda.synchronize()
+        H = {n: F[n].get_data() for n in names}
+        alpha = 0.001
+        prm = D.psy.shallow_params(g.dx, g.dy, 20.0)
+        oc = O.Comms()
+        C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+        cur, old, new = names[:3], names[3:6], names[6:]
+        for step in range(4):
+            D.psy.invoke_shallow_step_smooth_dm(prm, alpha, *[F[n] for n in cur + old + new], pipelined=pipelined)
+            O.sw_step(prm, g.nx, it.box(), *[H[n] for n in cur + old + new])
+            for n in new:
+                assert O.exchange_all([H[n]], [g.nx], [oc]) == 0
+            for c, nw, o in zip(cur, new, old):
+                O.sw_kernel("time_smooth", False, g.nx, it.box(), H[o], [H[c], H[nw], H[o]], alpha)
+            cur, new = new, cur
+        D.psy.halo_join(g)
+        torch.cuda.synchronize()
+        for n in names:
+            assert np.array_equal(F[n].get_data(), H[n]), n
+        D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+        g._halo_plan = None
+    finally:
+        L.dlesm_set_tuning(b"sw_dm_frame", 1)
+        L.dlesm_set_tuning(b"sw_dm_fused", 1)
