@@ -548,6 +548,7 @@ def shallow_water_periodic(D, torch, stream, alignment, tile, steps):
     prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
     cur, old, new = [F["u"], F["v"], F["p"]], [F["uold"], F["vold"], F["pold"]], [F["unew"], F["vnew"], F["pnew"]]
     # leapfrog: S(p) of the even and of the odd time levels are conserved separately
+    stream.synchronize()              # (the sums below run on torch's current stream, not on `stream`)
     p0 = [float(F[n].data[1:tile + 1, 1:tile + 1].sum().item()) for n in ("p", "pold")]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 

@@ -50,6 +50,12 @@ template <bool DPP> __device__ __forceinline__ V2 east_of(const V2 &a) { return 
 template <bool DPP> __device__ __forceinline__ V2 west_of(const V2 &a) { return V2{from_lower<DPP>(a.y), a.x}; }
 
 #define EW(expr_x, expr_y) V2{(expr_x), (expr_y)}
+// the old level: read-only and restrict-qualified in the plain step; the filtered step (SM) also writes it, through
+// SwSmooth's pointers, so there it must not promise no-alias
+typedef const double *__restrict__ OldLevelRO;
+typedef const double *OldLevelRW;
+template <bool SM> struct OldLevel { typedef OldLevelRO ptr; };
+template <> struct OldLevel<true> { typedef OldLevelRW ptr; };
 // The Asselin filter of the GOcean leapfrog (time_smooth) folded into the step: with uo != nullptr
 // the old level is ALSO updated in place, uold <- u + alpha*(unew - 2*u + uold) (likewise v, p), from values the lane
 // already holds -- three more stores per cell instead of three more launches that re-read nine arrays: 96 B/cell for a
@@ -65,11 +71,11 @@ __device__ __forceinline__ V2 pin_here(const V2 &a) { return V2{::dlesm::pin_her
 // NTM bit 0: the old time level (read exactly once, by one lane) is loaded non-temporally;
 // bit 1: the new time level is stored non-temporally.  u, v, p keep the default policy: their
 // rows are re-read by the tile below.
-template <int R, bool DPP, int NTM>
+template <int R, bool DPP, int NTM, bool SM = false>
 __device__ __forceinline__ void shallow_tile_body(
     const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
-    const double *uold, const double *vold, const double *pold,
+    typename OldLevel<SM>::ptr uold, typename OldLevel<SM>::ptr vold, typename OldLevel<SM>::ptr pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, unsigned block, int stack = 1,
     SwSmooth sm = SwSmooth{0.0, nullptr, nullptr, nullptr})
 {
@@ -213,7 +219,7 @@ __device__ __forceinline__ void shallow_tile_body(
             if (m0) { unew[o] = un.x; vnew[o] = vn.x; pnew[o] = pn.x; }
             if (m1) { unew[o + 1] = un.y; vnew[o + 1] = vn.y; pnew[o + 1] = pn.y; }
         }
-        if (sm.uo) {     // time_smooth of the old level, in place: field_old = field + alpha*(field_new - 2*field + field_old)
+        if constexpr (SM) {   // time_smooth of the old level, in place: field_old = field + alpha*(field_new - 2*field + field_old)
             const V2 us = EW(U[k].x + sm.alpha * (un.x - 2.0 * U[k].x + UO[k - 1].x), U[k].y + sm.alpha * (un.y - 2.0 * U[k].y + UO[k - 1].y));
             const V2 vs = EW(Vv[k].x + sm.alpha * (vn.x - 2.0 * Vv[k].x + VO[k - 1].x), Vv[k].y + sm.alpha * (vn.y - 2.0 * Vv[k].y + VO[k - 1].y));
             const V2 ps = EW(P[k].x + sm.alpha * (pn.x - 2.0 * P[k].x + PO[k - 1].x), P[k].y + sm.alpha * (pn.y - 2.0 * P[k].y + PO[k - 1].y));
@@ -230,14 +236,14 @@ __device__ __forceinline__ void shallow_tile_body(
 }
 
 
-template <int R, bool DPP, int NTM>
+template <int R, bool DPP, int NTM, bool SM = false>
 __global__ __launch_bounds__(512) void shallow_tile(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
-    const double *uold, const double *vold, const double *pold,
+    typename OldLevel<SM>::ptr uold, typename OldLevel<SM>::ptr vold, typename OldLevel<SM>::ptr pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, int stack, SwSmooth sm)
 {
-    shallow_tile_body<R, DPP, NTM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, blockIdx.x, stack, sm);
+    shallow_tile_body<R, DPP, NTM, SM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, blockIdx.x, stack, sm);
 }
 
 // The distributed shallow-water step in ONE launch on the caller's stream (as jacobi5_tile_framed): the
@@ -246,18 +252,18 @@ __global__ __launch_bounds__(512) void shallow_tile(
 // running -- into the fields and, where a neighbour will receive it, into the aggregated send buffer; the last of them
 // publishes `seq` in the flag the side stream's waiter sleeps on.  All other workgroups are the ordinary
 // tile sweep over the interior.
-template <int R, bool DPP, int NTM>
+template <int R, bool DPP, int NTM, bool SM = false>
 __global__ __launch_bounds__(512) void shallow_tile_framed(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
-    const double *uold, const double *vold, const double *pold,
+    typename OldLevel<SM>::ptr uold, typename OldLevel<SM>::ptr vold, typename OldLevel<SM>::ptr pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, SwFrameJob fj)
 {
     if (blockIdx.x >= (unsigned)fj.nblocks) {
         const SwSmooth sm = fj.smooth ? SwSmooth{fj.alpha, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold)}
                                       : SwSmooth{0.0, nullptr, nullptr, nullptr};
-        shallow_tile_body<R, DPP, NTM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew,
-                                       blockIdx.x - fj.nblocks, 1, sm);
+        shallow_tile_body<R, DPP, NTM, SM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew,
+                                           blockIdx.x - fj.nblocks, 1, sm);
         return;
     }
     auto put = [](double *ptr, double val) { __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
         put(vnew + o, r.vn);
         put(pnew + o, r.pn);
         // the filtered old level is read by nobody before the next launch: ordinary stores
-        if (fj.smooth) smooth_old_level(fj.alpha, o, u, v, p, r, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold));
+        if constexpr (SM) smooth_old_level(fj.alpha, o, u, v, p, r, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold));
         for (int k = 0; k < fj.pk.n; k++)
             if (fj.pk.holds(k, i, j)) {
                 put(fj.pk.buf + fj.pk.slot(k, 0, i, j), r.un);
@@ -320,11 +326,11 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
 // last internal column over the internal rows; then north halo row <- first internal row, south halo row <- last
 // internal row over the columns widened by the two halo columns, which is what makes the corner halos the doubly
 // wrapped cells) without the two extra launches.
-template <int R, bool DPP, int NTM>
+template <int R, bool DPP, int NTM, bool SM = false>
 __global__ __launch_bounds__(512) void shallow_tile_sw(
     dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
-    const double *uold, const double *vold, const double *pold,
+    typename OldLevel<SM>::ptr uold, typename OldLevel<SM>::ptr vold, typename OldLevel<SM>::ptr pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, int wrap, SwSmooth sm)
 {
     auto east = [](const V2 &a) { return east_of<DPP>(a); };
@@ -432,17 +438,17 @@ __global__ __launch_bounds__(512) void shallow_tile_sw(
             un = pin_here(un); vn = pin_here(vn); pn = pin_here(pn);
             if (jj > je) continue;
         }
-        // this row, and the halo row(s) it is the periodic image of
-        int rows[3], nrows = 1;
-        rows[0] = jj;
-        if (wrap & 2) {
-            if (jj == y0) rows[nrows++] = y1 + 1;
-            if (jj == y1) rows[nrows++] = y0 - 1;
-        }
+        // this row, and the halo row(s) it is the periodic image of.  (Scalars, not a small array: an array captured by
+        // the lambda below survives until the compiler moves it into LDS, which costs the kernel 2-5 %.)
+        const int image_n = ((wrap & 2) && jj == y0) ? y1 + 1 : -1;
+        const int image_s = ((wrap & 2) && jj == y1) ? y0 - 1 : -1;
         // one time level (three arrays) into this row and its periodic images
         auto store3 = [&](double *fu, double *fv, double *fp, const V2 &a, const V2 &b, const V2 &d) {
-            for (int r = 0; r < nrows; r++) {
-                const size_t row = (size_t)rows[r] * ld, o = row + (size_t)c * 2;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int jr = r == 0 ? jj : r == 1 ? image_n : image_s;
+                if (jr < 0) continue;
+                const size_t row = (size_t)jr * ld, o = row + (size_t)c * 2;
                 if (m0 && m1) {
                     st2<(NTM & 2) != 0>(fu + o, a);
                     st2<(NTM & 2) != 0>(fv + o, b);
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(512) void shallow_tile_sw(
             }
         };
         store3(unew, vnew, pnew, un, vn, pn);
-        if (sm.uo) {     // time_smooth of the old level, in place (and its periodic images): see SwSmooth
+        if constexpr (SM) {   // time_smooth of the old level, in place (and its periodic images): see SwSmooth
             const V2 us = EW(U[k].x + sm.alpha * (un.x - 2.0 * U[k].x + UO[k - 1].x), U[k].y + sm.alpha * (un.y - 2.0 * U[k].y + UO[k - 1].y));
             const V2 vs = EW(Vv[k].x + sm.alpha * (vn.x - 2.0 * Vv[k].x + VO[k - 1].x), Vv[k].y + sm.alpha * (vn.y - 2.0 * Vv[k].y + VO[k - 1].y));
             const V2 ps = EW(P[k].x + sm.alpha * (pn.x - 2.0 * P[k].x + PO[k - 1].x), P[k].y + sm.alpha * (pn.y - 2.0 * P[k].y + PO[k - 1].y));
@@ -541,14 +547,14 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     // time_smooth, dlesm_shallow_kernels.hip: a store into a line its own load has just left in L2 is the slow case)
     if (sm.uo && (ntm & 2) && tuning("sw_smooth_ntl", 1)) ntm |= 1;
     int R = tuning("sw_tile_rows", 2);
-    if (R != 1 && R != 3) R = 2;
+    if ((R != 1 && R != 3) || sm.uo) R = 2;               // (the filtered step exists for two-row tiles)
     const int h = y1 - y0 + 1, strips = (h + R - 1) / R;
     const long tiles = (long)nxw * strips;
     unsigned grid = (unsigned)((tiles + tpb - 1) / tpb);
     const bool dpp = tuning("sw_dpp", 1);
     // experiments (NE offset, R = 2, DPP): sw_stack = vertically adjacent tiles per workgroup; sw_nt bit 2 = the old
     // level requested before u, v, p
-    int stack = (!fj && !sw_offset && R == 2 && dpp) ? tuning("sw_stack", 1) : 1;
+    int stack = (!fj && !sw_offset && R == 2 && dpp && !sm.uo) ? tuning("sw_stack", 1) : 1;
     if (stack != 2 && stack != 4) stack = 1;
     if (stack > tpb) stack = 1;
     if (stack > 1) grid = (unsigned)(((nxw + tpb / stack - 1) / (tpb / stack)) * (long)((strips + stack - 1) / stack));
@@ -561,12 +567,44 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
         long nb = ((cells + 64 * tpb - 1) / (64 * tpb) + 7) & ~7L;    // a multiple of 8: tile groups keep their XCD
         fj->nblocks = (int)(nb < 8 ? 8 : nb > 512 ? 512 : nb);
         const unsigned g2 = grid + (unsigned)fj->nblocks;
-        switch (ntm) {
-        case 1: hipLaunchKernelGGL((shallow_tile_framed<2, true, 1>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj); break;
-        case 2: hipLaunchKernelGGL((shallow_tile_framed<2, true, 2>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj); break;
-        case 3: hipLaunchKernelGGL((shallow_tile_framed<2, true, 3>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj); break;
-        default: hipLaunchKernelGGL((shallow_tile_framed<2, true, 0>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj); break;
+#define DLESM_SWF(NN, SS) hipLaunchKernelGGL((shallow_tile_framed<2, true, NN, SS>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj)
+        if (sm.uo) {
+            switch (ntm & 3) {
+            case 1: DLESM_SWF(1, true); break;
+            case 2: DLESM_SWF(2, true); break;
+            case 3: DLESM_SWF(3, true); break;
+            default: DLESM_SWF(0, true); break;
+            }
+        } else {
+            switch (ntm & 3) {
+            case 1: DLESM_SWF(1, false); break;
+            case 2: DLESM_SWF(2, false); break;
+            case 3: DLESM_SWF(3, false); break;
+            default: DLESM_SWF(0, false); break;
+            }
         }
+#undef DLESM_SWF
+        return;
+    }
+    if (sm.uo) {   // the filter folded in: the R = 2, DPP form with the plain / non-temporal policies
+#define DLESM_SWS(NN)                                                                                          \
+    do {                                                                                                       \
+        if (sw_offset)                                                                                         \
+            hipLaunchKernelGGL((shallow_tile_sw<2, true, NN, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
+                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, wrap, sm);            \
+        else                                                                                                   \
+            hipLaunchKernelGGL((shallow_tile<2, true, NN, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
+                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, 1, sm);               \
+    } while (0)
+        switch ((ntm == 10 || ntm == 11) ? ntm : (ntm & 3)) {
+        case 1: DLESM_SWS(1); break;
+        case 2: DLESM_SWS(2); break;
+        case 3: DLESM_SWS(3); break;
+        case 10: DLESM_SWS(10); break;
+        case 11: DLESM_SWS(11); break;
+        default: DLESM_SWS(0); break;
+        }
+#undef DLESM_SWS
         return;
     }
 #define DLESM_SW3(RR, DD, NN)                                                                                  \
