@@ -14,6 +14,7 @@ UNIQUE_ID_BYTES = 128
 
 OK, EINVAL, ENODEV, EHIP, ERCCL, EABORT, ECOMMS = 0, -1, -2, -3, -4, -5, -12
 # dirs_mask of dlesm_halo_exchange_f64: bit d-1 per edge direction; 0 exchanges nothing
+PEER_BLOB_BYTES = 1024
 DIRS_ALL, DIRS_NO_DIAGONALS = 0xF, 0x10
 DIRS_EDGES_ONLY = DIRS_ALL | DIRS_NO_DIAGONALS
 
@@ -165,6 +166,10 @@ PROTOTYPES = {
     "dlesm_jacobi5_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_jacobi5_step_dm_pipelined": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_halo_plan_join": (_i, [_vp, _vp]),
+    "dlesm_halo_plan_peer_export": (_i, [_vp, _i, _i, _vp]),
+    "dlesm_halo_plan_peer_connect": (_i, [_vp, _i, _i, _vp]),
+    "dlesm_halo_plan_peer_connect_rccl": (_i, [_vp, _i]),
+    "dlesm_halo_plan_peer_connected": (_i, [_vp]),
     "dlesm_wait_timed_out": (_i, [_i]),
     "dlesm_probe_stream_concurrency": (_i, [_vp]),
     "dlesm_jacobi5_multi_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -207,6 +212,11 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+def last_error():
+    """the message of the last failed call on this thread"""
+    return lib().dlesm_last_error().decode(errors="replace")
 
 
 def check(rc):

@@ -24,6 +24,8 @@
 // sending and on the receiving side of a message.
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -124,6 +126,25 @@ struct dlesm_halo_plan {
     // pipelined step's frame workgroups read them; whoever joins instead unpacks them into this field
     double *pending_field = nullptr;
     unsigned pending_mask = 0;
+    // ---- peer transport (dlesm_halo_plan_peer_export / _connect) -------------------------
+    // This rank's MAILBOX: one fine-grained allocation the neighbours store into over xGMI --
+    //   [0, 256)      arrival flags, one 8-byte word per receive message (index = position in `recvs`)
+    //   [4096, ...)   two payload parities of peer_par_len doubles: message m of an nf-field step at nf * ragg[m]
+    // and, per SEND message, where its strip goes in the neighbour's mailbox (peer-mapped addresses).
+    int peer_fcap = 0;                         // fields a payload parity has room for (0: no mailbox)
+    void *peer_box = nullptr;
+    unsigned long long *peer_flags = nullptr;
+    double *peer_rx = nullptr;
+    long peer_par_len = 0;
+    bool peer_on = false;                      // connected
+    std::vector<double *> peer_tx;             // per send: the neighbour's payload parity 0
+    std::vector<long> peer_tx_par, peer_tx_off;   // its parity length; per-field offset of the matching slot
+    std::vector<unsigned long long *> peer_txflag;
+    std::vector<void *> peer_mapped;           // hipIpcOpenMemHandle results, closed with the plan
+    unsigned *peer_counter = nullptr;
+    unsigned long long peer_seq = 0;           // steps taken through the mailboxes (the same number on every rank)
+    bool peer_pending = false;                 // halos of pending_field are still in the mailbox (parity peer_seq & 1)
+    hipEvent_t ev_peer = nullptr;
 };
 
 // edge directions follow their bit; diagonals follow their two edges (parallel_comms_mod.f90:
@@ -344,6 +365,7 @@ extern "C" int dlesm_comm_rank(void) { return g_rank; }
 extern "C" int dlesm_comm_size(void) { return g_size; }
 
 static int ensure_buffers(dlesm_halo_plan *p, int nfields, hipStream_t s = nullptr);
+static int peer_join(dlesm_halo_plan *p, hipStream_t s);
 
 extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny, dlesm_halo_plan **out)
 {
@@ -415,6 +437,9 @@ extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny
 extern "C" int dlesm_halo_plan_destroy(dlesm_halo_plan *p)
 {
     if (!p) return DLESM_OK;
+    // a peer-transport step still pending: its join is also what tells that the neighbours are done storing into this
+    // rank's mailbox, which is about to be freed
+    if (p->peer_pending && p->pending_field) (void)peer_join(p, p->pending_stream);
     (void)hipDeviceSynchronize();
     if (p->d_spack) (void)hipFree(p->d_spack);
     if (p->d_rpack) (void)hipFree(p->d_rpack);
@@ -425,6 +450,10 @@ extern "C" int dlesm_halo_plan_destroy(dlesm_halo_plan *p)
     if (p->sendbuf) (void)hipFree(p->sendbuf);
     if (p->recvbuf) (void)hipFree(p->recvbuf);
     if (p->frame_flag) (void)hipFree(p->frame_flag);
+    for (void *m : p->peer_mapped) (void)hipIpcCloseMemHandle(m);
+    if (p->peer_box) (void)hipFree(p->peer_box);
+    if (p->peer_counter) (void)hipFree(p->peer_counter);
+    if (p->ev_peer) (void)hipEventDestroy(p->ev_peer);
     if (p->ev_frame) (void)hipEventDestroy(p->ev_frame);
     if (p->ev_comm) (void)hipEventDestroy(p->ev_comm);
     delete p;
@@ -501,6 +530,8 @@ static int capture_ok(const dlesm_halo_plan *p, hipStream_t s)
 // stream `s` is ordered behind it first.
 static int join_pending(dlesm_halo_plan *p, hipStream_t s)
 {
+    if (p->peer_pending)
+        if (int rc = peer_join(p, s)) return rc;
     if (!p->pending) return DLESM_OK;
     DLESM_REQUIRE(!capturing(s), "a pipelined step is in flight: call dlesm_halo_plan_join before capturing a graph");
     DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_comm, 0));
@@ -653,6 +684,229 @@ extern "C" int dlesm_halo_exchange_f64(dlesm_halo_plan *p, double *field, unsign
     return exchange_on(p, field, dirs_mask & 0x1Fu, (hipStream_t)stream);
 }
 
+// ---- peer transport ------------------------------------------------------------------------------------------------
+// What one rank tells the others (dlesm_halo_plan_peer_export), DLESM_PEER_BLOB_BYTES per rank, all-gathered by the host
+// program or by dlesm_halo_plan_peer_connect_rccl: where its mailbox is (an IPC handle) and which slot and flag each of
+// its receive messages has, in the plan's (peer, direction) order -- the k-th message a rank sends to a neighbour is the
+// k-th that neighbour receives from it, the matching rule of the RCCL path.
+namespace {
+struct PeerBlob {
+    char magic[8];
+    int rank, nrecv, fcap, has_handle;
+    long par_len;
+    long pid;
+    hipIpcMemHandle_t handle;
+    struct R { int peer, dir; long count, off; } r[16];
+};
+static_assert(sizeof(PeerBlob) <= DLESM_PEER_BLOB_BYTES, "peer blob size");
+constexpr char PEER_MAGIC[8] = {'D', 'L', 'E', 'S', 'M', 'P', 'B', '1'};
+constexpr size_t PEER_PAYLOAD_AT = 4096;
+} // namespace
+
+extern "C" int dlesm_halo_plan_peer_export(dlesm_halo_plan *p, int my_rank, int nfields, void *blob)
+{
+    DLESM_REQUIRE(p != nullptr && blob != nullptr, "null pointer");
+    DLESM_REQUIRE(nfields >= 1 && nfields <= 16, "%d fields", nfields);
+    DLESM_REQUIRE(p->recvs.size() <= 16 && p->sends.size() <= 16, "more than 16 messages");
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(!p->peer_on, "the plan is already connected to its peers");
+    if (!p->peer_box) {
+        p->peer_fcap = nfields;
+        p->peer_par_len = ((long)nfields * p->ragg_len + 15) & ~15L;
+        const size_t bytes = PEER_PAYLOAD_AT + 2 * (size_t)p->peer_par_len * sizeof(double) + 256;
+        // fine-grained: stores arriving over xGMI and this GPU's own system-scope loads meet in memory, not in an L2
+        DLESM_HIP_TRY(hipExtMallocWithFlags(&p->peer_box, bytes, hipDeviceMallocFinegrained));
+        DLESM_HIP_TRY(hipMemset(p->peer_box, 0, bytes));
+        DLESM_HIP_TRY(hipMalloc((void **)&p->peer_counter, 64));
+        DLESM_HIP_TRY(hipMemset(p->peer_counter, 0, 64));
+        DLESM_HIP_TRY(hipDeviceSynchronize());
+        p->peer_flags = (unsigned long long *)p->peer_box;
+        p->peer_rx = (double *)((char *)p->peer_box + PEER_PAYLOAD_AT);
+        DLESM_HIP_TRY(hipEventCreateWithFlags(&p->ev_peer, hipEventDisableTiming));
+    }
+    DLESM_REQUIRE(nfields == p->peer_fcap, "mailbox was made for %d field(s)", p->peer_fcap);
+    PeerBlob b;
+    memset(&b, 0, sizeof b);
+    memcpy(b.magic, PEER_MAGIC, 8);
+    b.rank = my_rank;
+    b.nrecv = (int)p->recvs.size();
+    b.fcap = p->peer_fcap;
+    b.par_len = p->peer_par_len;
+    b.pid = (long)getpid();
+    // (a process cannot open its own handle: a rank that is its own neighbour -- loop-back -- uses the pointer)
+    b.has_handle = hipIpcGetMemHandle(&b.handle, p->peer_box) == hipSuccess ? 1 : 0;
+    if (!b.has_handle) (void)hipGetLastError();
+    for (size_t m = 0; m < p->recvs.size(); m++)
+        b.r[m] = PeerBlob::R{p->recvs[m].peer, p->recvs[m].dir, p->recvs[m].count, p->ragg[m]};
+    memset(blob, 0, DLESM_PEER_BLOB_BYTES);
+    memcpy(blob, &b, sizeof b);
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_halo_plan_peer_connect(dlesm_halo_plan *p, int my_rank, int nranks, const void *blobs)
+{
+    DLESM_REQUIRE(p != nullptr && blobs != nullptr, "null pointer");
+    DLESM_REQUIRE(p->peer_box != nullptr, "call dlesm_halo_plan_peer_export first");
+    DLESM_REQUIRE(!p->peer_on, "the plan is already connected to its peers");
+    DLESM_REQUIRE(my_rank >= 0 && my_rank < nranks, "rank %d of %d", my_rank, nranks);
+    if (int rc = ensure_device()) return rc;
+    auto blob_of = [&](int r) { PeerBlob b; memcpy(&b, (const char *)blobs + (size_t)r * DLESM_PEER_BLOB_BYTES, sizeof b); return b; };
+    std::vector<void *> base(nranks, nullptr);
+    const size_t ns = p->sends.size();
+    std::vector<double *> tx(ns);
+    std::vector<long> par(ns), off(ns);
+    std::vector<unsigned long long *> txf(ns);
+    std::vector<void *> mapped;
+    int rc = DLESM_OK;
+    for (size_t m = 0; m < ns && !rc; m++) {
+        const Msg &sm = p->sends[m];
+        if (sm.peer < 0 || sm.peer >= nranks) { rc = fail(DLESM_EINVAL, "send %zu goes to rank %d of %d", m, sm.peer, nranks); break; }
+        const PeerBlob b = blob_of(sm.peer);
+        if (memcmp(b.magic, PEER_MAGIC, 8) != 0 || b.rank != sm.peer || b.nrecv < 0 || b.nrecv > 16) {
+            rc = fail(DLESM_EINVAL, "peer blob of rank %d is not valid", sm.peer);
+            break;
+        }
+        if (b.fcap != p->peer_fcap) { rc = fail(DLESM_EINVAL, "rank %d made its mailbox for %d field(s), this rank for %d", sm.peer, b.fcap, p->peer_fcap); break; }
+        int k = 0;                                      // this is my k-th message to that neighbour ...
+        for (size_t q = 0; q < m; q++) k += p->sends[q].peer == sm.peer;
+        int j = -1;                                     // ... and meets its k-th receive from me
+        for (int q = 0, seen = 0; q < b.nrecv; q++)
+            if (b.r[q].peer == my_rank && seen++ == k) { j = q; break; }
+        if (j < 0 || b.r[j].count != sm.count) {
+            rc = fail(DLESM_EINVAL, "send %zu (to rank %d, direction %d, %ld cells) has no matching receive there", m, sm.peer, sm.dir, sm.count);
+            break;
+        }
+        if (!base[sm.peer]) {
+            if (sm.peer == my_rank) {
+                base[sm.peer] = p->peer_box;
+            } else {
+                if (!b.has_handle) { rc = fail(DLESM_EHIP, "rank %d could not export its mailbox (hipIpcGetMemHandle failed there)", sm.peer); break; }
+                void *ptr = nullptr;
+                const hipError_t e = hipIpcOpenMemHandle(&ptr, b.handle, hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) { rc = fail(DLESM_EHIP, "hipIpcOpenMemHandle(mailbox of rank %d): %s", sm.peer, hipGetErrorString(e)); break; }
+                mapped.push_back(ptr);
+                base[sm.peer] = ptr;
+            }
+        }
+        tx[m] = (double *)((char *)base[sm.peer] + PEER_PAYLOAD_AT);
+        par[m] = b.par_len;
+        off[m] = b.r[j].off;
+        txf[m] = (unsigned long long *)base[sm.peer] + j;
+    }
+    if (rc) {
+        for (void *q : mapped) (void)hipIpcCloseMemHandle(q);
+        return rc;
+    }
+    p->peer_tx = tx, p->peer_tx_par = par, p->peer_tx_off = off, p->peer_txflag = txf, p->peer_mapped = mapped;
+    p->peer_on = true;
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_halo_plan_peer_connect_rccl(dlesm_halo_plan *p, int nfields)
+{
+    DLESM_REQUIRE(p != nullptr, "null plan");
+    DLESM_REQUIRE(g_comm != nullptr && g_size >= 1, "no communicator (dlesm_comm_init)");
+    char mine[DLESM_PEER_BLOB_BYTES];
+    if (int rc = dlesm_halo_plan_peer_export(p, g_rank, nfields, mine)) return rc;
+    char *d_in = nullptr, *d_all = nullptr;
+    std::vector<char> all((size_t)g_size * DLESM_PEER_BLOB_BYTES);
+    DLESM_HIP_TRY(hipMalloc((void **)&d_in, DLESM_PEER_BLOB_BYTES));
+    DLESM_HIP_TRY(hipMalloc((void **)&d_all, all.size()));
+    DLESM_HIP_TRY(hipMemcpy(d_in, mine, DLESM_PEER_BLOB_BYTES, hipMemcpyHostToDevice));
+    const ncclResult_t r = ncclAllGather(d_in, d_all, DLESM_PEER_BLOB_BYTES, ncclChar, g_comm, nullptr);
+    int rc = DLESM_OK;
+    if (r != ncclSuccess) rc = fail(DLESM_ERCCL, "ncclAllGather of the peer blobs: %s", ncclGetErrorString(r));
+    if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(DLESM_EHIP, "all-gather of the peer blobs failed");
+    if (!rc && hipMemcpy(all.data(), d_all, all.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(DLESM_EHIP, "copy of the peer blobs failed");
+    (void)hipFree(d_in);
+    (void)hipFree(d_all);
+    if (rc) return rc;
+    return dlesm_halo_plan_peer_connect(p, g_rank, g_size, all.data());
+}
+
+extern "C" int dlesm_halo_plan_peer_connected(const dlesm_halo_plan *p) { return p && p->peer_on ? 1 : 0; }
+
+// the receive strips of the step that is pending, as they sit in the mailbox (parity of that step)
+static int peer_in_strips(const dlesm_halo_plan *p, unsigned mask, unsigned long long seq, int nf, PeerJob::In *in, int *n)
+{
+    *n = 0;
+    const double *par = p->peer_rx + (seq & 1) * p->peer_par_len;
+    for (size_t m = 0; m < p->recvs.size(); m++) {
+        const Msg &r = p->recvs[m];
+        if (!dir_enabled(mask, r.dir)) continue;
+        DLESM_REQUIRE(*n < PeerJob::MAXM, "more than %d receive messages in one peer step", PeerJob::MAXM);
+        in[(*n)++] = PeerJob::In{r.i0, r.j0, r.nx, r.ny, par + (long)nf * p->ragg[m], p->peer_flags + m};
+    }
+    return DLESM_OK;
+}
+
+static int peer_join(dlesm_halo_plan *p, hipStream_t s)
+{
+    DLESM_REQUIRE(!capturing(s), "a peer-transport step is in flight: call dlesm_halo_plan_join before capturing a graph");
+    PeerStrips st{};
+    if (int rc = peer_in_strips(p, p->pending_mask, p->peer_seq, 1, st.s, &st.n)) return rc;
+    if (s != p->pending_stream) {      // the step itself ran elsewhere: order this stream behind it
+        DLESM_HIP_TRY(hipEventRecord(p->ev_peer, p->pending_stream));
+        DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_peer, 0));
+    }
+    if (int rc = launch_peer_unpack(st, p->peer_seq, p->pending_field, p->ld, p->frame_timed_out, s)) return rc;
+    p->peer_pending = false;
+    p->pending_field = nullptr;
+    return DLESM_OK;
+}
+
+// The distributed Jacobi step over the mailboxes: ONE launch on the caller's stream (frame workgroups that store into the
+// neighbours' mailboxes + the interior sweep), and in the joined form one small launch behind it that waits for the
+// arrival flags and copies the strips into the halos.  No side stream, no RCCL kernel, no pack, no event.
+static int jacobi5_step_peer(dlesm_halo_plan *p, const double *in, double *out, int ld, int ny, int xstart, int xstop,
+                             int ystart, int ystop, hipStream_t s, bool pipelined)
+{
+    DLESM_REQUIRE(!capturing(s), "the peer transport hands over through sequence numbers: it cannot be captured into a graph");
+    DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
+                  "an earlier distributed step gave up waiting for a flag (frame or halo wait timed out)");
+    const unsigned mask = tuning("j5_dm_corners", 0) ? DLESM_DIRS_ALL : (DLESM_DIRS_ALL | DLESM_DIRS_NO_DIAGONALS);
+    const bool chain = pipelined && p->peer_pending && p->pending_stream == s && p->pending_field == in &&
+                       p->pending_mask == mask && tuning("j5_dm_chain", 1);
+    if (!chain)
+        if (int rc = join_pending(p, s)) return rc;
+    PeerJob job{};
+    const unsigned long long seq = p->peer_seq + 1;
+    const int fx0 = xstart - 1, fx1 = xstop - 1, fy0 = ystart - 1, fy1 = ystop - 1;
+    for (size_t m = 0; m < p->sends.size(); m++) {
+        const Msg &sm = p->sends[m];
+        if (!dir_enabled(mask, sm.dir)) continue;
+        DLESM_REQUIRE(job.nout < PeerJob::MAXM, "more than %d send messages in one peer step", PeerJob::MAXM);
+        const bool col = sm.nx == 1 && (sm.i0 == fx0 || sm.i0 == fx1) && sm.j0 >= fy0 && sm.j0 + sm.ny - 1 <= fy1;
+        const bool row = sm.ny == 1 && (sm.j0 == fy0 || sm.j0 == fy1) && sm.i0 >= fx0 && sm.i0 + sm.nx - 1 <= fx1;
+        DLESM_REQUIRE(col || row, "peer transport: send strip (%d:%d,%d:%d) is not part of the one-cell frame of the box "
+                      "(plans of halo depth 1 stepped over their internal region only)", sm.i0 + 1, sm.i0 + sm.nx, sm.j0 + 1, sm.j0 + sm.ny);
+        job.out[job.nout++] = PeerJob::Out{sm.i0, sm.j0, sm.nx, sm.ny,
+                                           p->peer_tx[m] + (seq & 1) * p->peer_tx_par[m] + p->peer_tx_off[m], p->peer_txflag[m]};
+    }
+    if (chain) {      // the halos of `in` are still in the mailbox: read them there, once they have arrived
+        if (int rc = peer_in_strips(p, mask, seq - 1, 1, job.in, &job.nin)) return rc;
+        job.wait_seq = seq - 1;
+        job.virt = 1;
+    }
+    job.seq = seq;
+    job.counter = p->peer_counter;
+    job.wait_ticks = remote_wait_ticks();
+    job.timed_out = p->frame_timed_out;
+    bool fused = false;
+    if (int rc = launch_stencil5_peer(in, out, ld, ny, xstart, xstop, ystart, ystop, job, s, &fused)) return rc;
+    if (!fused) {     // arrays or box the tile kernel does not take: the frame workgroups alone, then the plain interior sweep
+        if (int rc = launch_stencil5_peer_frame(in, out, ld, ny, xstart, xstop, ystart, ystop, job, s)) return rc;
+        if (int rc = launch_stencil5(in, out, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, s)) return rc;
+    }
+    p->peer_seq = seq;
+    p->peer_pending = true;
+    p->pending_field = out;
+    p->pending_mask = mask;
+    p->pending_stream = s;
+    if (!pipelined) return join_pending(p, s);
+    return DLESM_OK;
+}
+
 static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *out, int ld, int ny, int xstart,
                                 int xstop, int ystart, int ystop, hipStream_t s, bool pipelined)
 {
@@ -664,6 +918,8 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) // single tile: one launch over the whole box
         return launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s);
+    if (p->peer_on && tuning("dm_peer", 1))      // connected mailboxes: the frame workgroups are the exchange
+        return jacobi5_step_peer(p, in, out, ld, ny, xstart, xstop, ystart, ystop, s, pipelined);
     // The previous step of a pipelined sequence left its exchange in flight.  If this step can take
     // the one-launch form on the same stream, its frame workgroups wait for that exchange on the
     // device (halo_flag) and the caller's stream needs no event wait at all; otherwise join now.

@@ -172,6 +172,37 @@ bool streams_run_concurrently(hipStream_t callers);
 // *flag = seq, stream ordered (one thread): publishes "the exchange before this point has landed"
 int launch_flag_set(unsigned long long *flag, unsigned long long seq, hipStream_t s);
 
+// ---- peer transport (dlesm_halo_plan_peer_connect): no RCCL kernel, no side stream.  The frame workgroups of the step
+// launch store every cell a neighbour needs STRAIGHT INTO THAT NEIGHBOUR'S receive mailbox (peer-mapped memory: xGMI
+// stores) and then raise the neighbour's arrival flag; they read their own halo operands from the local mailbox once its
+// arrival flags are up.  Mailboxes are double-buffered on the step's sequence number.
+struct PeerJob {
+    static constexpr int MAXM = 8;
+    int fx0, fx1, fy0, fy1;       // 0-based frame box (filled in by launch_stencil5_peer)
+    int nblocks;                  // workgroups that do frame cells (filled in by the launcher)
+    unsigned *counter;            // device word, 0 between launches
+    // halo operands of this step: strips of the LOCAL mailbox (parity of the previous step), each with its arrival flag
+    struct In { int i0, j0, ni, nj; const double *src; const unsigned long long *flag; } in[MAXM];
+    int nin;
+    unsigned long long wait_seq;  // the frame workgroups wait until every in[k].flag >= wait_seq; 0: no wait
+    int virt;                     // != 0: halo operands are read from the strips; 0: from the field (already unpacked)
+    // what the neighbours get: strips of the frame, each into a PEER's mailbox (parity of this step) + that peer's flag
+    struct Out { int i0, j0, ni, nj; double *dst; unsigned long long *flag; } out[MAXM];
+    int nout;
+    unsigned long long seq;       // stored to every out[k].flag when the last frame workgroup is done
+    unsigned long long wait_ticks;   // bound of the wait (remote_wait_ticks(); 0 = none)
+    int *timed_out;
+};
+// frame (peer stores) + interior sweep in ONE launch; *fused = false (nothing launched) when the arrays do not qualify
+int launch_stencil5_peer(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                         PeerJob job, hipStream_t s, bool *fused);
+// the frame workgroups alone (any alignment, boxes without an interior); the caller sweeps the interior itself
+int launch_stencil5_peer_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                               PeerJob job, hipStream_t s);
+// wait for the arrival flags of n strips (>= seq), then copy them from the mailbox into the halo cells of `field`
+struct PeerStrips { PeerJob::In s[PeerJob::MAXM]; int n; };
+int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *field, int ld, int *timed_out, hipStream_t s);
+
 // nsteps fused Jacobi steps (dlesm_jacobi_x2.hip); 1-based inclusive output box, last stage box,
 // grow flags -- see dlesm_stencil5_multi_f64
 int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nsteps, int xstart, int xstop,

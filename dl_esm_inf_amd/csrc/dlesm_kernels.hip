@@ -4,6 +4,7 @@
 // All of them are memory bound (<= 0.25 flop/byte): no MFMA, no GEMM reshaping.
 // What matters is that every cell is fetched from HBM once, in 16-byte-per-lane
 // coalesced requests, with enough requests in flight per CU.
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -392,6 +393,96 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_framed(const double *__rest
     }
 }
 
+// ---- peer transport: the frame workgroups ARE the exchange (PeerJob, dlesm_internal.h) ----------------------------
+// Payload and flags cross GPUs: every access to a mailbox is a relaxed SYSTEM-scope atomic (`global_load/store ... sc0
+// sc1`: nothing of it stays in an L1 or L2 on either side), the mailboxes are fine-grained allocations, and the order
+// payload -> flag is the one of jacobi5_tile_framed: every storing wave drains (`s_waitcnt vmcnt(0)`: the stores have
+// been acknowledged by the memory they went to), the workgroup's barrier, one device-scope counter increment per
+// workgroup, and the LAST arriver stores the flags.
+__device__ __forceinline__ void peer_frame_cell(long t, const double *__restrict__ in, double *__restrict__ out, int ld,
+                                                const PeerJob &pj)
+{
+    int i, j;
+    frame_index(t, pj.fx0, pj.fx1, pj.fy0, pj.fy1, i, j);
+    const size_t o = (size_t)j * ld + i;
+    auto operand = [&](int oi, int oj, bool outside) {
+        if (outside && pj.virt)
+            for (int k = 0; k < pj.nin; k++) {
+                const PeerJob::In &m = pj.in[k];
+                if (oi >= m.i0 && oi < m.i0 + m.ni && oj >= m.j0 && oj < m.j0 + m.nj)
+                    return __hip_atomic_load(m.src + (size_t)(oj - m.j0) * m.ni + (oi - m.i0), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        return in[(size_t)oj * ld + oi];          // inside the box, a fixed boundary cell, or halos already unpacked
+    };
+    const double r = 0.25 * ((operand(i - 1, j, i == pj.fx0) + operand(i + 1, j, i == pj.fx1)) +
+                             (operand(i, j - 1, j == pj.fy0) + operand(i, j + 1, j == pj.fy1)));
+    out[o] = r;                                   // read by the next launch: an ordinary store
+    for (int k = 0; k < pj.nout; k++) {
+        const PeerJob::Out &m = pj.out[k];
+        if (i >= m.i0 && i < m.i0 + m.ni && j >= m.j0 && j < m.j0 + m.nj)     // the pack loop's order: j outer, i inner
+            __hip_atomic_store(m.dst + (size_t)(j - m.j0) * m.ni + (i - m.i0), r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// bounded wait of ONE thread for n arrival flags (system scope: they are stored by other GPUs)
+__device__ __forceinline__ void peer_wait_flags(const PeerJob::In *in, int n, unsigned long long seq,
+                                                unsigned long long ticks, int *timed_out)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int k = 0; k < n; k++)
+        while (__hip_atomic_load(in[k].flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(32);
+            if (ticks && __builtin_amdgcn_s_memrealtime() - t0 > ticks) {                   // 100 MHz counter
+                __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+        }
+}
+
+template <int VEC, int R, int NT>
+__global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restrict__ in, double *__restrict__ out, int ld,
+                                                         int x0, int x1, int y0, int y1, int c_first, int nxw, int flags,
+                                                         PeerJob pj)
+{
+    if (blockIdx.x >= (unsigned)pj.nblocks) {
+        jacobi5_tile_body<VEC, R, NT>(in, out, ld, x0, x1, y0, y1, c_first, nxw, flags, blockIdx.x - pj.nblocks);
+        return;
+    }
+    if (pj.wait_seq) {      // the neighbours' frames of the previous step: in steady state long since there (one load each)
+        if (threadIdx.x == 0) peer_wait_flags(pj.in, pj.nin, pj.wait_seq, pj.wait_ticks, pj.timed_out);
+        __syncthreads();
+    }
+    const long total = frame_cells(pj.fx1 - pj.fx0 + 1, pj.fy1 - pj.fy0 + 1);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)pj.nblocks * blockDim.x)
+        peer_frame_cell(t, in, out, ld, pj);
+    __builtin_amdgcn_s_waitcnt(0);        // this wave's stores have been acknowledged ...
+    __syncthreads();                      // ... and those of every wave of the group ...
+    if (threadIdx.x == 0) {               // ... before the group is counted as done
+        const unsigned done = __hip_atomic_fetch_add(pj.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (unsigned)pj.nblocks - 1) {
+            __hip_atomic_store(pj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < pj.nout; k++)
+                __hip_atomic_store(pj.out[k].flag, pj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// Joins of the peer transport: wait for the strips' arrival flags, then copy them from the mailbox into the halo cells
+// of the field (ordinary stores: the readers are later launches on this stream).  grid = (parts, strips).
+__global__ __launch_bounds__(256) void peer_unpack_k(PeerStrips st, unsigned long long seq, double *__restrict__ field, int ld,
+                                                     unsigned long long ticks, int *timed_out)
+{
+    const PeerJob::In m = st.s[blockIdx.y];
+    if (threadIdx.x == 0) peer_wait_flags(&m, 1, seq, ticks, timed_out);
+    __syncthreads();
+    const long n = (long)m.ni * m.nj;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int jj = (int)(t / m.ni), ii = (int)(t - (long)jj * m.ni);
+        field[(size_t)(m.j0 + jj) * ld + (m.i0 + ii)] = __hip_atomic_load(m.src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // LDS-staged form (j5_kernel = 2, the comparison point for "stage the tile and its halo ring in
 // LDS"): a workgroup of 64*T lanes stages rows jb-1..je+1 of a 128*T-column tile, plus the two
 // ring columns, in LDS (row pitch 2*blockDim+4 doubles, interior chunks 16-byte aligned at
@@ -519,7 +610,7 @@ int nt_stores_for(int ld, int y0, int y1)
 
 template <int VEC, bool NT>
 static void launch_tile(const double *in, double *out, int ld, int x0, int x1, int y0, int y1, int R,
-                        int flags, hipStream_t s, FrameJob *fj = nullptr)
+                        int flags, hipStream_t s, FrameJob *fj = nullptr, PeerJob *pj = nullptr)
 {
     if (R != 1 && R != 2 && R != 3 && R != 4 && R != 6 && R != 12 && R != 16) R = 8;
     // tiles are anchored on a 128-byte line of the row (not on the first interior column), so
@@ -535,14 +626,14 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
     {
         std::lock_guard<std::mutex> lk(g_shape_mu);
         // (the framed launch is built for 2-row tiles: it takes the best 2-row shape, kept under VEC + 100)
-        auto it = g_shape_cache.find(ShapeKey{ld, x0, x1, y0, y1, fj ? VEC + 100 : VEC});
+        auto it = g_shape_cache.find(ShapeKey{ld, x0, x1, y0, y1, (fj || pj) ? VEC + 100 : VEC});
         int rows = 0;
         if (g_shape_override.tpb) { tpb = g_shape_override.tpb; nxw = g_shape_override.nxw; rows = g_shape_override.rows; }
         else if (it != g_shape_cache.end() && tuning("j5_use_tuned", 1)) { tpb = it->second.tpb; nxw = it->second.nxw; rows = it->second.rows; }
         else choose_block_shape(&nxw, &tpb);
         // a measured tile height (2 or 3 rows: which streams better depends on the row pitch) -- not for the
         // framed launch, whose kernel is built for 2, and not against an explicit j5_tile_rows
-        if (rows > 0 && !fj && tuning("j5_tile_rows", 0) < 1) R = rows;
+        if (rows > 0 && !fj && !pj && tuning("j5_tile_rows", 0) < 1) R = rows;
     }
     const int strips = (y1 - y0 + R) / R;
     const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
@@ -551,6 +642,20 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
     // 0.729 against 0.747-0.761 -- two 134 MB arrays ping-pong through the 256 MB Infinity Cache, and a store
     // that bypasses it takes the next step's input away.  So: on from 150 MB per array (nt_stores_for).
     const int nts = nt_stores_for(ld, y0, y1);
+    if (pj) {   // the peer transport's launch: as the framed one below
+        if constexpr (VEC == 2 && !NT) {
+            const long cells = 2L * (pj->fx1 - pj->fx0 + 1) + 2L * (pj->fy1 - pj->fy0 + 1);
+            long nb = ((cells + 64 * tpb - 1) / (64 * tpb) + 7) & ~7L;
+            pj->nblocks = (int)(nb < 8 ? 8 : nb > 256 ? 256 : nb);
+            if (nts)
+                hipLaunchKernelGGL((jacobi5_tile_peer<2, 2, 2>), dim3(grid + pj->nblocks), dim3(64 * tpb), 0, s, in, out, ld,
+                                   x0, x1, y0, y1, c_first, nxw, flags, *pj);
+            else
+                hipLaunchKernelGGL((jacobi5_tile_peer<2, 2, 0>), dim3(grid + pj->nblocks), dim3(64 * tpb), 0, s, in, out, ld,
+                                   x0, x1, y0, y1, c_first, nxw, flags, *pj);
+        }
+        return;
+    }
     if (fj) {
         // frame workgroups first (they are dispatched first): a multiple of 8 of them, so that the tile
         // workgroups keep the XCD each would have had in the plain launch (round-robin dealing)
@@ -855,6 +960,56 @@ int launch_stencil5_framed(const double *in, double *out, int ld, int ny, int xs
     launch_tile<2, false>(in, out, ld, xstart, xstop - 2, ystart, ystop - 2, 2, (variant >> 3) & 1, s, &job);
     DLESM_HIP_TRY(hipGetLastError());
     *fused = true;
+    return DLESM_OK;
+}
+
+int launch_stencil5_peer(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                         PeerJob job, hipStream_t s, bool *fused)
+{
+    *fused = false;
+    if (xstop - xstart < 2 || ystop - ystart < 2) return DLESM_OK;          // no interior
+    if (int rc = check_box("dlesm_jacobi5_step_dm", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    DLESM_REQUIRE(in != nullptr && out != nullptr && in != out, "stencil5: null or aliased arrays");
+    DLESM_REQUIRE(job.counter != nullptr && job.nin <= PeerJob::MAXM && job.nout <= PeerJob::MAXM, "stencil5 peer: bad job");
+    const int variant = tuning("j5_variant", 0);
+    const int x1i = xstop - 2;
+    const bool odd_ok = !(variant & 16) && x1i + 1 <= 2 * (ld / 2) - 1;
+    const bool vec2 = !(variant & 4) && ((ld % 2 == 0) || odd_ok) && ((uintptr_t)in % 16 == 0) &&
+                      ((uintptr_t)out % 16 == 0);
+    int R = tuning("j5_tile_rows", 0);
+    if (R < 1) R = 2;
+    if (!vec2 || (variant & 1) || tuning("j5_kernel", 0) != 0 || R != 2) return DLESM_OK;
+    job.fx0 = xstart - 1, job.fx1 = xstop - 1, job.fy0 = ystart - 1, job.fy1 = ystop - 1;
+    launch_tile<2, false>(in, out, ld, xstart, xstop - 2, ystart, ystop - 2, 2, (variant >> 3) & 1, s, nullptr, &job);
+    DLESM_HIP_TRY(hipGetLastError());
+    *fused = true;
+    return DLESM_OK;
+}
+
+int launch_stencil5_peer_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                               PeerJob job, hipStream_t s)
+{
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("dlesm_jacobi5_step_dm", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    job.fx0 = xstart - 1, job.fx1 = xstop - 1, job.fy0 = ystart - 1, job.fy1 = ystop - 1;
+    const long cells = 2L * (xstop - xstart + 1) + 2L * (ystop - ystart + 1);
+    long nb = (cells + 255) / 256;
+    job.nblocks = (int)(nb < 1 ? 1 : nb > 256 ? 256 : nb);
+    // the frame workgroups of the one-launch kernel with no tile workgroup behind them
+    hipLaunchKernelGGL((jacobi5_tile_peer<2, 2, 0>), dim3(job.nblocks), dim3(256), 0, s, in, out, ld, 0, 0, 0, 0, 0, 1, 0, job);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *field, int ld, int *timed_out, hipStream_t s)
+{
+    if (st.n == 0) return DLESM_OK;
+    long longest = 1;
+    for (int k = 0; k < st.n; k++) longest = std::max(longest, (long)st.s[k].ni * st.s[k].nj);
+    int parts = (int)((longest + 255) / 256);
+    if (parts > 16) parts = 16;
+    hipLaunchKernelGGL(peer_unpack_k, dim3(parts, st.n), dim3(256), 0, s, st, seq, field, ld, remote_wait_ticks(), timed_out);
+    DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
 

@@ -133,3 +133,25 @@ def halo_plan(grid):
                                                  C.byref(p)))
         grid._halo_plan = p
     return grid._halo_plan
+
+
+def connect_peers(grid, nfields=1):
+    """Connect the grid's message plan to its neighbours' mailboxes (dlesm_halo_plan_peer_*): from then on
+    dlesm_jacobi5_step_dm[_pipelined] on this grid exchanges by storing straight into the neighbours' memory instead of
+    through an RCCL group.  COLLECTIVE: every rank calls it, at the same point.  The blobs travel through the
+    torch.distributed group when there is more than one rank (any backend), so no RCCL communicator is needed."""
+    L = _cabi.lib()
+    plan = halo_plan(grid)
+    if L.dlesm_halo_plan_peer_connected(plan):
+        return
+    rank, n = parallel_mod.get_rank() - 1, parallel_mod.get_num_ranks()
+    blob = C.create_string_buffer(_cabi.PEER_BLOB_BYTES)
+    check(L.dlesm_halo_plan_peer_export(plan, rank, nfields, blob))
+    every = blob.raw
+    if n > 1:
+        import torch.distributed as dist
+        got = [None] * n
+        dist.all_gather_object(got, blob.raw)
+        every = b"".join(got)
+    check(L.dlesm_halo_plan_peer_connect(plan, rank, n, C.create_string_buffer(every, n * _cabi.PEER_BLOB_BYTES)))
+

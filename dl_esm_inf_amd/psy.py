@@ -124,6 +124,12 @@ def invoke_jacobi5_dm_pipelined(out_fld, in_fld, stream=None):
                                                       _stream_ptr(stream)))
 
 
+def halo_connect_peers(grid, nfields=1):
+    """collective: connect the grid's plan to the neighbours' mailboxes (grid_mod.connect_peers) -- the distributed
+    Jacobi steps then exchange with stores over xGMI instead of an RCCL group"""
+    grid_mod.connect_peers(grid, nfields)
+
+
 def halo_join(grid, stream=None):
     """order `stream` behind the exchange a pipelined step left in flight"""
     check(_cabi.lib().dlesm_halo_plan_join(grid_mod.halo_plan(grid), _stream_ptr(stream)))

@@ -539,6 +539,33 @@ int dlesm_jacobi5_step_dm_pipelined(dlesm_halo_plan *plan, const double *in, dou
 /* order `stream` behind the exchange a pipelined step left in flight (no-op when there is none) */
 int dlesm_halo_plan_join(dlesm_halo_plan *plan, void *stream);
 
+/* ---- Peer transport of the distributed Jacobi step: the stencil kernel itself is the exchange. ----------------------
+ * What the reference does with MPI_Isend / MPI_Irecv / MPI_Waitany per strip (parallel_comms_mod.f90:1601-1750,
+ * parallel_utils_mod.f90:148-211) and the default path here with one RCCL group per step, a connected plan does with
+ * stores: the frame workgroups of the step launch write every cell a neighbour needs straight into that neighbour's
+ * receive MAILBOX (peer-mapped fine-grained memory: xGMI stores) and then raise the neighbour's arrival flag; they read
+ * their own halo operands from the local mailbox once its arrival flags are up.  No RCCL kernel, no side stream, no
+ * pack, no event.  Mailboxes are double-buffered on the step number, which therefore has to advance on every rank alike
+ * (each rank takes the same sequence of distributed steps on its plan -- what a halo exchange asks for anyway).
+ * Results are bit for bit those of the RCCL path.  Only dlesm_jacobi5_step_dm / _pipelined use the mailboxes (plans of
+ * halo depth 1, stepped over the internal region); every other entry keeps RCCL.  dm_peer = 0 (dlesm_set_tuning)
+ * switches a connected plan back to RCCL -- on every rank or on none.
+ *
+ * Connecting is collective over the ranks that share neighbours:
+ *   1. dlesm_halo_plan_peer_export(plan, my_rank, nfields = 1, blob): allocates this rank's mailbox and writes
+ *      DLESM_PEER_BLOB_BYTES describing it (an IPC handle + the slot of each receive message);
+ *   2. the host program all-gathers the blobs in rank order (MPI_Allgather, torch.distributed.all_gather, a file ...);
+ *   3. dlesm_halo_plan_peer_connect(plan, my_rank, nranks, blobs): maps the neighbours' mailboxes
+ *      (hipIpcOpenMemHandle; a rank that is its own neighbour uses the pointer) and matches every send with the receive
+ *      it meets -- the k-th message to a neighbour is the k-th that neighbour receives from this rank.
+ * dlesm_halo_plan_peer_connect_rccl does 1-3 with ncclAllGather on the library's communicator.
+ * my_rank / the peers in the plan's tables are 0-based ranks, as everywhere in this header. */
+#define DLESM_PEER_BLOB_BYTES 1024
+int dlesm_halo_plan_peer_export(dlesm_halo_plan *plan, int my_rank, int nfields, void *blob);
+int dlesm_halo_plan_peer_connect(dlesm_halo_plan *plan, int my_rank, int nranks, const void *blobs);
+int dlesm_halo_plan_peer_connect_rccl(dlesm_halo_plan *plan, int nfields);
+int dlesm_halo_plan_peer_connected(const dlesm_halo_plan *plan);   /* 1 / 0 */
+
 /* Device-side waits of the distributed steps are bounded: 30 s for this GPU's own frame workgroups, and
  * dm_wait_seconds (dlesm_set_tuning; default 600, 0 = no limit, as the reference waits in MPI_Waitany,
  * parallel_comms_mod.f90:1773-1798) wherever the wait is for an EXCHANGE, i.e. for the slowest neighbour.  A wait

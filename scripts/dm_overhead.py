@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--out", default="gpurun_out/dm_overhead.json")
     ap.add_argument("--fused", type=int, default=1, help="T > 1: the fused T-step forms, depth-T halos")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="dlesm_set_tuning before init")
+    ap.add_argument("--peer", action="store_true", help="connect the plan's mailboxes: the distributed steps use the peer "
+                    "transport (frame workgroups store into the neighbour's mailbox; no RCCL kernel)")
     args = ap.parse_args()
     import torch
     import dl_esm_inf_amd as D
@@ -69,6 +71,8 @@ def main():
     tables = loopback_tables(D, it, T)
     plan = C.c_void_p()
     D._cabi.check(L.dlesm_halo_plan_create(C.byref(tables), g.nx, g.ny, C.byref(plan)))
+    if args.peer:
+        D._cabi.check(L.dlesm_halo_plan_peer_connect_rccl(plan, 1))
     s = torch.cuda.Stream()
     sp = C.c_void_p(s.cuda_stream)
     box = it.box()

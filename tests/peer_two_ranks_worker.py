@@ -1,0 +1,113 @@
+"""One rank of the N-process test of the PEER TRANSPORT on ONE GPU (tests/test_a_peer_two_ranks_gpu.py): the ranks are
+separate processes that share device 0, so a neighbour's mailbox is reached through a real hipIpcMemHandle, arrival flags
+are raised by ANOTHER process's kernel, and the ranks run skewed against each other -- everything the loop-back tests
+cannot show except the xGMI hop itself.  No RCCL anywhere (it refuses two ranks on one device): the blobs travel through
+a gloo group, the decomposition and the message tables are the product's own (go_decompose / map_comms).
+
+Check: N time steps (joined form, then the time-loop form + one join) against the oracle's steps on the UNDIVIDED domain,
+every internal cell and every edge halo of this rank's tile, bit for bit.
+
+    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/peer_two_ranks_worker.py NX NY [STEPS]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+NX, NY = int(sys.argv[1]), int(sys.argv[2])
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+ALIGN = sys.argv[4] if len(sys.argv) > 4 else "64"
+SEED = 20261004 + 3
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+dist.init_process_group("gloo", rank=rank, world_size=world)
+import dl_esm_inf_amd as D  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+torch.cuda.set_device(0)
+L = D._cabi.lib()
+L.dlesm_set_tuning(b"dm_wait_seconds", 30)         # a protocol error must end in words, not in a hung box
+D.parallel_init(rank, world, use_rccl=False)
+if ALIGN == "none":
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+else:
+    os.environ["DL_ESM_ALIGNMENT"] = ALIGN
+g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
+g.decompose(NX, NY)
+D.grid_init(g, 1.0, 1.0)
+x, y = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+it = x.internal
+sub = g.subdomain
+gx0 = sub.glob.xstart - sub.internal.xstart + 1     # global index of local cell 1 (psy.hash_init)
+gy0 = sub.glob.ystart - sub.internal.ystart + 1
+ring = D._cabi.Region(0, 0, it.xstart - 1, it.xstop + 1, it.ystart - 1, it.ystop + 1)
+
+# the undivided domain on the host: global cells 0 .. N+1 (0 and N+1 = the fixed boundary ring)
+gld, gny = NX + 2, NY + 2
+G = O.hash_field(SEED, gny, gld, 0, 0, 1, NX + 2, 1, NY + 2)
+H = G.copy()
+history = [G.copy()]
+for _ in range(2 * STEPS):
+    O.jacobi5(G, H, gld, 2, NX + 1, 2, NY + 1)
+    G, H = H, G
+    history.append(G.copy())
+
+
+def check(fld, nsteps, what):
+    got = fld.get_data()
+    want = history[nsteps]
+    bad = 0
+    # internal region + the four edge halos (a 5-point step exchanges no corner)
+    for (x0, x1, y0, y1) in ((it.xstart, it.xstop, it.ystart - 1, it.ystop + 1), (it.xstart - 1, it.xstop + 1, it.ystart, it.ystop)):
+        loc = got[y0 - 1:y1, x0 - 1:x1]
+        glo = want[gy0 + y0 - 1:gy0 + y1, gx0 + x0 - 1:gx0 + x1]
+        bad += int(np.count_nonzero(loc != glo))
+    if bad:
+        print(f"ERROR rank {rank}: {what}: {bad} cells differ from the undivided oracle after {nsteps} steps", flush=True)
+    return bad
+
+
+D.psy.hash_init(x, SEED, box=ring)
+D.psy.hash_init(y, SEED, box=ring)
+D.psy.halo_connect_peers(g)
+errors = 0
+s = torch.cuda.Stream()
+a, b = x, y
+n = 0
+# joined form
+for k in range(STEPS):
+    D.psy.invoke_jacobi5_dm(b, a, stream=s)
+    a, b = b, a
+    n += 1
+    if k in (0, STEPS - 1):
+        s.synchronize()
+        errors += check(a, n, "joined step")
+# time-loop form: ranks deliberately skewed (rank r sleeps r x 50 ms in the middle)
+for k in range(STEPS):
+    D.psy.invoke_jacobi5_dm_pipelined(b, a, stream=s)
+    a, b = b, a
+    n += 1
+    if k == STEPS // 2:
+        s.synchronize()
+        import time
+        time.sleep(0.05 * rank)
+D.psy.halo_join(g, stream=s)
+s.synchronize()
+errors += check(a, n, "time-loop form")
+if L.dlesm_wait_timed_out(0):
+    print(f"ERROR rank {rank}: a device-side wait gave up", flush=True)
+    errors += 1
+t = torch.tensor([errors])
+dist.all_reduce(t)
+dist.barrier()
+print(f"rank {rank}: tile {it.nx}x{it.ny} of {NX}x{NY}, {n} steps, errors {errors} (all ranks {int(t.item())})", flush=True)
+dist.destroy_process_group()
+sys.exit(1 if int(t.item()) else 0)

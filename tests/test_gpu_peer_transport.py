@@ -1,0 +1,199 @@
+"""GPU tests (-m gpu) of the PEER TRANSPORT of the distributed Jacobi step (dlesm_halo_plan_peer_*):
+the frame workgroups of the step launch store into the neighbours' mailboxes and raise their arrival flags -- no RCCL
+kernel.  One GPU: rank 0 is its own four (or eight) neighbours, so mailbox addressing, the matching of sends with
+receives, the double buffering on the step number, the chained waits and the joins all run as they do between GPUs, minus
+the IPC mapping (tests/peer_two_ranks_worker.py covers that with two processes) and the xGMI hop.
+
+Oracle: steps x (orc_jacobi5 + the oracle's edge exchange on the same tables), every bit, halos included."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+SEED = 20261004
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+
+
+@pytest.fixture(scope="module")
+def D():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    import dl_esm_inf_amd as d
+    torch.cuda.set_device(0)
+    d.parallel_init(0, 1, use_rccl=True)
+    return d
+
+
+def _grid(D, nx, ny, alignment):
+    if alignment is None:
+        os.environ.pop("DL_ESM_ALIGNMENT", None)
+    else:
+        os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    g.decompose(nx, ny)
+    D.grid_init(g, 1.0, 1.0)
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+    return g
+
+
+def _setup(D, nx, ny, alignment, connect="rccl"):
+    from dm_overhead import loopback_tables
+    L = D._cabi.lib()
+    g = _grid(D, nx, ny, alignment)
+    x, y = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+    t = loopback_tables(D, x.internal)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    assert L.dlesm_halo_plan_peer_connected(plan) == 0
+    if connect == "rccl":          # export + ncclAllGather + connect inside the library
+        D._cabi.check(L.dlesm_halo_plan_peer_connect_rccl(plan, 1))
+    elif connect == "host":        # the three-step form a host program with its own all-gather uses
+        blob = C.create_string_buffer(D._cabi.PEER_BLOB_BYTES)
+        D._cabi.check(L.dlesm_halo_plan_peer_export(plan, 0, 1, blob))
+        D._cabi.check(L.dlesm_halo_plan_peer_connect(plan, 0, 1, blob))
+    if connect:
+        assert L.dlesm_halo_plan_peer_connected(plan) == 1
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    return L, g, x, y, plan, oc
+
+
+@pytest.mark.parametrize("nx,ny,alignment", [(300, 41, 64), (64, 64, 2), (1500, 700, 64), (130, 5, 2), (37, 29, None),
+                                             (3, 3, 64), (8, 3, None), (2048, 2048, 64)])
+@pytest.mark.parametrize("connect", ["rccl", "host"])
+def test_joined_steps_over_the_mailboxes(D, nx, ny, alignment, connect):
+    """dlesm_jacobi5_step_dm on a connected plan: after every step the output (edge halos included) equals the oracle's
+    stencil + edge exchange; odd leading dimensions and boxes without an interior take the frame-only launch"""
+    import torch
+    L, g, x, y, plan, oc = _setup(D, nx, ny, alignment, connect)
+    it = x.internal
+    D.psy.hash_init(x, SEED + 31)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+    D.copy_field(x, y)
+    for _ in range(5):
+        hx, want = x.get_data(), y.get_data()
+        O.jacobi5(hx, want, g.nx, *it.box())
+        assert O.exchange_dirs([want], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+        D._cabi.check(L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(y.get_data(), want)
+        x, y = y, x
+    assert L.dlesm_wait_timed_out(0) == 0
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+@pytest.mark.parametrize("nx,ny,alignment,nsteps", [(300, 41, 64, 7), (64, 64, 2, 12), (1500, 700, 64, 9), (130, 5, 2, 4),
+                                                    (37, 29, None, 6), (3, 3, 64, 5), (4096, 4096, 64, 6)])
+@pytest.mark.parametrize("chain", [1, 0])
+def test_time_loop_over_the_mailboxes(D, nx, ny, alignment, nsteps, chain):
+    """dlesm_jacobi5_step_dm_pipelined on a connected plan: one launch per step, the frame workgroups wait for the
+    neighbours' arrival flags and read their halo operands in the mailbox (parity of the previous step); ONE join at the
+    end unpacks.  Then the mixtures: an RCCL exchange behind a pending step, a joined step behind a pipelined one, dm_peer=0
+    (back to RCCL) and on again -- the sequence numbers of the two transports are independent"""
+    import torch
+    L, g, x, y, plan, oc = _setup(D, nx, ny, alignment)
+    L.dlesm_set_tuning(b"j5_dm_chain", chain)
+    it = x.internal
+    D.psy.hash_init(x, SEED + 13)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+    D.copy_field(x, y)
+    torch.cuda.synchronize()
+    hx, hy = x.get_data(), y.get_data()
+    s = torch.cuda.Stream()
+    sp = C.c_void_p(s.cuda_stream)
+    a, b = x, y
+
+    def oracle_step():
+        nonlocal hx, hy
+        O.jacobi5(hx, hy, g.nx, *it.box())
+        assert O.exchange_dirs([hy], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+        hx, hy = hy, hx
+
+    try:
+        for _ in range(nsteps):
+            D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), sp))
+            a, b = b, a
+            oracle_step()
+        D._cabi.check(L.dlesm_halo_plan_join(plan, sp))
+        s.synchronize()
+        assert np.array_equal(a.get_data(), hx)
+        # a plain (RCCL) exchange after a pending peer step joins by itself
+        D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), sp))
+        D._cabi.check(L.dlesm_halo_exchange_f64(plan, b.device_ptr, D._cabi.DIRS_ALL, sp))
+        s.synchronize()
+        O.jacobi5(hx, hy, g.nx, *it.box())
+        assert O.exchange_all([hy], [g.nx], [oc]) == 0
+        assert np.array_equal(b.get_data(), hy)
+        hx, hy = hy, hx
+        a, b = b, a
+        # a joined step behind a pipelined one; then the RCCL transport for two steps, then the mailboxes again
+        D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), sp))
+        D._cabi.check(L.dlesm_jacobi5_step_dm(plan, b.device_ptr, a.device_ptr, g.nx, g.ny, *it.box(), sp))
+        oracle_step(), oracle_step()
+        s.synchronize()
+        assert np.array_equal(a.get_data(), hx)
+        L.dlesm_set_tuning(b"dm_peer", 0)
+        for _ in range(2):
+            D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), sp))
+            a, b = b, a
+            oracle_step()
+        L.dlesm_set_tuning(b"dm_peer", 1)
+        for _ in range(3):
+            D._cabi.check(L.dlesm_jacobi5_step_dm_pipelined(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), sp))
+            a, b = b, a
+            oracle_step()
+        # joining on ANOTHER stream than the one the steps ran on
+        D._cabi.check(L.dlesm_halo_plan_join(plan, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(a.get_data(), hx)
+        assert L.dlesm_wait_timed_out(0) == 0
+    finally:
+        L.dlesm_set_tuning(b"dm_peer", 1)
+        L.dlesm_set_tuning(b"j5_dm_chain", 1)
+        D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+def test_eight_direction_steps_and_refusals(D):
+    """j5_dm_corners=1: the four corner messages travel through the mailboxes too (halos then equal a full exchange);
+    what the transport does not take is refused in words: a second connect, a mailbox for another field count, a
+    capture into a graph"""
+    import torch
+    L, g, x, y, plan, oc = _setup(D, 257, 63, 64)
+    it = x.internal
+    L.dlesm_set_tuning(b"j5_dm_corners", 1)
+    try:
+        D.psy.hash_init(x, SEED + 5)
+        D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+        D.copy_field(x, y)
+        for _ in range(4):
+            hx, want = x.get_data(), y.get_data()
+            O.jacobi5(hx, want, g.nx, *it.box())
+            assert O.exchange_all([want], [g.nx], [oc]) == 0
+            D._cabi.check(L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), None))
+            torch.cuda.synchronize()
+            assert np.array_equal(y.get_data(), want)
+            x, y = y, x
+    finally:
+        L.dlesm_set_tuning(b"j5_dm_corners", 0)
+    blob = C.create_string_buffer(D._cabi.PEER_BLOB_BYTES)
+    assert L.dlesm_halo_plan_peer_export(plan, 0, 1, blob) != 0 and "already connected" in D._cabi.last_error()
+    assert L.dlesm_halo_plan_peer_connect_rccl(plan, 1) != 0
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+    # a blob that does not describe the receive this rank's send expects
+    L, g, x, y, plan, oc = _setup(D, 40, 30, 64, connect=None)
+    D._cabi.check(L.dlesm_halo_plan_peer_export(plan, 0, 1, blob))
+    bad = C.create_string_buffer(blob.raw, D._cabi.PEER_BLOB_BYTES)
+    bad[0] = b"X"
+    assert L.dlesm_halo_plan_peer_connect(plan, 0, 1, bad) != 0 and "not valid" in D._cabi.last_error()
+    two = C.create_string_buffer(blob.raw + blob.raw, 2 * D._cabi.PEER_BLOB_BYTES)
+    assert L.dlesm_halo_plan_peer_connect(plan, 1, 2, two) != 0      # rank 1 of 2: nobody sends to rank 1's slots
+    assert L.dlesm_halo_plan_peer_connected(plan) == 0
+    D._cabi.check(L.dlesm_halo_plan_peer_connect(plan, 0, 1, blob))
+    assert L.dlesm_halo_plan_peer_connected(plan) == 1
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
