@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE Jacobi configurations")
     ap.add_argument("--no-weak-tile", action="store_true",
                     help="skip the 8192^2-per-GPU weak-scaling object (BASELINE configs[4]'s tile)")
+    ap.add_argument("--no-peer", action="store_true", help="skip the peer-transport object (N > 1: beside RCCL on the "
+                    "weak-scaling tile; N = 1: 4096^2 loop-back)")
     ap.add_argument("--force-dm-leg", action="store_true",
                     help="rehearsal on 1 GPU: run the N>1 secondary leg with a 1-rank process group")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
@@ -808,6 +810,170 @@ def shallow_water_dm(D, torch, dist, tile, alignment, world, P, Q, stream, steps
 _STAGE = {"name": "start", "t0": time.time()}
 
 
+def _time_loop(D, torch, dist, world, g, a, b, stream, steps, warmup, step):
+    """warm-up, barrier, `steps` x step + ONE join, barrier; max over ranks; returns (seconds, a, b)"""
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            step(b, a, stream=stream)
+            a, b = b, a
+        D.psy.halo_join(g, stream=stream)
+    barrier()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(steps):
+            step(b, a, stream=stream)
+            a, b = b, a
+        D.psy.halo_join(g, stream=stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt[0])
+    return wall, a, b
+
+
+def peer_transport_dm(D, torch, dist, tile, alignment, world, P, Q, stream, steps, tables=None):
+    """Secondary object: the distributed Jacobi step over the PEER TRANSPORT -- the frame
+    workgroups of the step launch store into the neighbours' mailboxes over xGMI and raise their arrival flags; no RCCL
+    kernel, no side stream -- next to the RCCL form on the SAME grid, same process, same loop.  N > 1: the decomposition of
+    the weak-scaling leg; N = 1 with `tables`: one GPU that is its own four neighbours (loop-back), which prices
+    everything but the xGMI hop.  Checked first: three steps over the mailboxes == three x (stencil + RCCL edge exchange),
+    every bit on every rank; a mismatch, a failed connect or a wait that gave up is reported, not timed."""
+    steps = max(steps, MIN_SECONDARY_LAUNCHES)
+    L = D._cabi.lib()
+    g = make_grid(D, tile * P, tile * Q, alignment)
+    a, b, x, y = (D.r2d_field(g, D.GO_T_POINTS) for _ in range(4))
+    it = a.internal
+    if tables is not None:                                   # loop-back: the plan is made from these tables
+        plan = C.c_void_p()
+        t = tables(D, it)
+        D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+        g._halo_plan = plan
+    old_wait = L.dlesm_set_tuning(b"dm_wait_seconds", 60)   # a neighbour that never answers: words after a minute
+
+    def agree(flag):
+        if world == 1:
+            return bool(flag)
+        ok = torch.tensor([1 if flag else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return bool(int(ok[0]))
+
+    def leave(obj):
+        L.dlesm_set_tuning(b"dm_wait_seconds", old_wait or 600)      # (0 = the key was unset: the default)
+        L.dlesm_set_tuning(b"dm_peer", 1)
+        return obj
+
+    err = None
+    try:
+        D.psy.halo_connect_peers(g)                          # collective
+    except Exception as e:                                   # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if not agree(err is None):
+        return leave({"error": "mailboxes not connected on every rank" + (f" (this rank: {err})" if err else "")})
+    sp = C.c_void_p(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        D.psy.hash_init(a, SEED, stream=stream)
+        a.halo_exchange(1, stream=stream)
+        for f in (b, x, y):
+            D.copy_field(a, f, stream=stream)
+        D._cabi.check(L.dlesm_stencil5_autotune_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, it.xstart + 1, it.xstop - 1,
+                                                    it.ystart + 1, it.ystop - 1, sp))
+        D.copy_field(a, b, stream=stream)
+        x1, y1, x2, y2 = a, b, x, y
+        for k in range(3):
+            (D.psy.invoke_jacobi5_dm_pipelined if k < 2 else D.psy.invoke_jacobi5_dm)(y1, x1, stream=stream)
+            x1, y1 = y1, x1
+            D.psy.invoke_jacobi5(y2, x2, stream=stream)
+            y2.halo_exchange(1, stream=stream, dirs=D._cabi.DIRS_EDGES_ONLY)
+            x2, y2 = y2, x2
+    stream.synchronize()
+    gave_up = bool(L.dlesm_wait_timed_out(0))
+    same = (not gave_up) and bool(torch.equal(x1.data, x2.data))
+    if not agree(same):
+        if gave_up:      # acknowledge, so that the rest of the run still has a library to talk to
+            D._cabi.check(L.dlesm_halo_plan_destroy(g._halo_plan))
+            g._halo_plan = None
+            L.dlesm_wait_timed_out(1)
+        return leave({"error": "a wait for a neighbour's arrival flag gave up" if gave_up else
+                      "steps over the mailboxes differ from stencil + RCCL exchange on some rank",
+                      "equals_stencil_plus_rccl_exchange": False})
+    res = {}
+    for name, peer in (("rccl", 0), ("peer", 1), ("rccl2", 0), ("peer2", 1)):
+        L.dlesm_set_tuning(b"dm_peer", peer)
+        wall, a, b = _time_loop(D, torch, dist, world, g, a, b, stream, steps, 5, D.psy.invoke_jacobi5_dm_pipelined)
+        res[name] = wall / steps * 1e3
+    L.dlesm_set_tuning(b"dm_peer", 1)
+    with torch.cuda.stream(stream):                          # the plain sweep of one tile, no exchange: the yardstick
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            D.psy.invoke_jacobi5(b, a, stream=stream)
+        e0.record(stream)
+        for _ in range(steps):
+            D.psy.invoke_jacobi5(b, a, stream=stream)
+            a, b = b, a
+        e1.record(stream)
+    stream.synchronize()
+    plain = e0.elapsed_time(e1) / steps
+    rccl, peer = min(res["rccl"], res["rccl2"]), min(res["peer"], res["peer2"])
+    cells = tile * tile * world
+    out = {"workload": f"jacobi5 {tile}x{tile} fp64 per GPU, {P}x{Q} decomposition, time-loop form of the distributed step: "
+                       "RCCL send/recv group per step vs stores into the neighbours' mailboxes by the frame workgroups",
+           "tile": tile, "n_gpus": world, "neighbours": "itself (loop-back: no xGMI hop)" if tables is not None else "xGMI peers",
+           "steps": steps, "equals_stencil_plus_rccl_exchange": True,
+           "plain_sweep_ms": round(plain, 5),
+           "rccl": {"ms_per_step": round(rccl, 5), "value": round(cells / rccl / 1e3, 1), "frac_of_plain_sweep": round(plain / rccl, 4)},
+           "peer": {"ms_per_step": round(peer, 5), "value": round(cells / peer / 1e3, 1), "frac_of_plain_sweep": round(plain / peer, 4)},
+           "unit": "Mcells/s", "speedup": round(rccl / peer, 3)}
+    if L.dlesm_wait_timed_out(0):
+        out["error"] = "a wait gave up during the timed loops"
+    D._cabi.check(L.dlesm_halo_plan_destroy(g._halo_plan))
+    g._halo_plan = None
+    del a, b, x, y, x1, y1, x2, y2
+    torch.cuda.empty_cache()
+    return leave(out)
+
+
+def loopback_tables(D, it):
+    """message tables of a depth-1 exchange in which rank 0 is its own eight neighbours (a periodic wrap onto itself)"""
+    t = D._cabi.CommTables()
+    xl, xh, yl, yh = it.xstart, it.xstop, it.ystart, it.ystop
+    msgs = [(2, xh, yl, it.xstart - 1, yl, 1, it.ny), (1, xl, yl, it.xstop + 1, yl, 1, it.ny),
+            (4, xl, yh, xl, it.ystart - 1, it.nx, 1), (3, xl, yl, xl, it.ystop + 1, it.nx, 1),
+            (6, xh, yh, it.xstart - 1, it.ystart - 1, 1, 1), (5, xl, yl, it.xstop + 1, it.ystop + 1, 1, 1),
+            (7, xl, yh, it.xstop + 1, it.ystart - 1, 1, 1), (8, xh, yl, it.xstart - 1, it.ystop + 1, 1, 1)]
+    t.nsend = t.nrecv = len(msgs)
+    for k, (d, isrc, jsrc, ides, jdes, nx, ny) in enumerate(msgs):
+        t.dirsend[k] = t.dirrecv[k] = d
+        t.destination[k] = t.source[k] = 0
+        t.isrcsend[k], t.jsrcsend[k], t.idessend[k], t.jdessend[k] = isrc, jsrc, ides, jdes
+        t.nxsend[k], t.nysend[k] = nx, ny
+        t.isrcrecv[k], t.jsrcrecv[k], t.idesrecv[k], t.jdesrecv[k] = isrc, jsrc, ides, jdes
+        t.nxrecv[k], t.nyrecv[k] = nx, ny
+    return t
+
+
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; this program's stdout carries ONE JSON line.
+    File-descriptor level, because the banner comes from C."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def stage(rank, world, name):
     """N > 1 only: one stderr line per stage and rank, so that a failed or hung multi-GPU run (which
     cannot be rehearsed on the one-GPU development box) says where it stopped"""
@@ -846,8 +1012,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+            dist.barrier()                       # torch creates its communicator at the first collective
 
     import dl_esm_inf_amd as D
     L = D._cabi.lib()
@@ -861,7 +1029,8 @@ def main():
     D._cabi.check(L.dlesm_init(local))             # after the knobs: the side stream's priority is one of them
     os.environ["DL_ESM_ALIGNMENT"] = str(args.alignment)
     stage(rank, world, "RCCL communicator (dlesm_comm_init)")
-    D.parallel_init(rank, world)
+    with stdout_to_stderr():
+        D.parallel_init(rank, world)
     stage(rank, world, "grid + fields + first halo exchange")
 
     # global domain: what go_decompose will cut into `world` tiles of tile x tile
@@ -1071,6 +1240,11 @@ def main():
                 stage(rank, world, "secondary leg: distributed shallow-water step, 8192^2 per GPU")
                 out["shallow_water_dm"] = shallow_water_dm(D, torch, dist, min(WEAK_TILE, args.tile), args.alignment, world,
                                                            P, Q, stream, args.steps)
+            if not args.no_peer and not os.environ.get("DLESM_BENCH_NO_PEER"):
+                # LAST: the one leg whose transport no earlier run has exercised between GPUs
+                stage(rank, world, "secondary leg: peer transport (mailboxes) next to RCCL, 8192^2 per GPU")
+                out["peer_transport"] = peer_transport_dm(D, torch, dist, min(WEAK_TILE, args.tile), args.alignment, world,
+                                                          P, Q, stream, args.steps)
         except Exception as e:                               # noqa: BLE001
             dog.cancel()
             bail(f"{type(e).__name__}: {e}", 4)              # the other ranks may be stuck in a collective
@@ -1092,6 +1266,17 @@ def main():
         if not args.no_weak_tile and args.tile != WEAK_TILE:
             guarded("weak_scaling_tile", lambda: weak_scaling_tile(D, torch, None, WEAK_TILE, args.alignment, 1, 1, 1,
                                                                    stream, args.steps))
+        if not args.no_peer and not os.environ.get("DLESM_BENCH_NO_PEER"):
+            def dm_loopback():
+                # one GPU that is its own four neighbours: the small tile the exchange is hardest to hide behind
+                with stdout_to_stderr():
+                    D.parallel_init(0, 1, use_rccl=True)
+                try:
+                    return peer_transport_dm(D, torch, None, min(4096, args.tile), args.alignment, 1, 1, 1, stream,
+                                             max(args.steps, 100), tables=loopback_tables)
+                finally:
+                    D.parallel_finalise()
+            guarded("dm_loopback", dm_loopback)
         if not args.no_configs:
             # the other BASELINE Jacobi configurations, timed in the same process
             legs = [(4096, 64), (16384, 1), (4096, 1)]

@@ -714,8 +714,16 @@ extern "C" int dlesm_halo_plan_peer_export(dlesm_halo_plan *p, int my_rank, int 
         p->peer_fcap = nfields;
         p->peer_par_len = ((long)nfields * p->ragg_len + 15) & ~15L;
         const size_t bytes = PEER_PAYLOAD_AT + 2 * (size_t)p->peer_par_len * sizeof(double) + 256;
-        // fine-grained: stores arriving over xGMI and this GPU's own system-scope loads meet in memory, not in an L2
-        DLESM_HIP_TRY(hipExtMallocWithFlags(&p->peer_box, bytes, hipDeviceMallocFinegrained));
+        // UNCACHED device memory (MTYPE UC, what RCCL takes for its own flags and FIFOs): no line of it ever sits in an L2
+        // on either side, so stores arriving over xGMI and this GPU's own loads meet in memory while kernels run --
+        // ordinary (coarse-grained) memory is only coherent across GPUs at kernel boundaries.  mailbox_finegrained = 1
+        // asks for the fine-grained pool instead.
+        if (tuning("mailbox_finegrained", 0) ||
+            hipExtMallocWithFlags(&p->peer_box, bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            p->peer_box = nullptr;
+            DLESM_HIP_TRY(hipExtMallocWithFlags(&p->peer_box, bytes, hipDeviceMallocFinegrained));
+        }
         DLESM_HIP_TRY(hipMemset(p->peer_box, 0, bytes));
         DLESM_HIP_TRY(hipMalloc((void **)&p->peer_counter, 64));
         DLESM_HIP_TRY(hipMemset(p->peer_counter, 0, 64));

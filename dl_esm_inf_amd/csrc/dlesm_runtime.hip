@@ -36,7 +36,7 @@ static std::map<std::string, int> g_tuning;
 // when a first run on new hardware (several GPUs over xGMI) fails its self-check: it relies on kernel boundaries and
 // stream-ordered events only.
 static const char *const kSafeOff[] = {"j5_dm_fused", "sw_dm_fused", "s9_dm_fused", "dm_flag_join", "j5_dm_lazy_unpack",
-                                       "j5_dm_chain", "sw_dm_chain"};
+                                       "j5_dm_chain", "sw_dm_chain", "dm_peer"};
 static bool dm_safe_nolock()
 {
     static const bool env = [] { const char *e = getenv("DLESM_DM_SAFE"); return e && *e && strcmp(e, "0") != 0; }();

@@ -482,6 +482,18 @@ module dlesm_hip_mod
        type(c_ptr), value :: plan, stream
        integer(c_int) :: rc
      end function
+     ! peer transport: connect the plan to the neighbours' mailboxes (collective; the blobs travel by ncclAllGather)
+     function dlesm_halo_plan_peer_connect_rccl(plan, nfields) bind(C, name="dlesm_halo_plan_peer_connect_rccl") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: plan
+       integer(c_int), value :: nfields
+       integer(c_int) :: rc
+     end function
+     function dlesm_halo_plan_peer_connected(plan) bind(C, name="dlesm_halo_plan_peer_connected") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: plan
+       integer(c_int) :: rc
+     end function
      function dlesm_jacobi5_multi_step_dm(plan, in, out, ld, ny, nsteps, xstart, xstop, ystart, ystop, &
           stream) bind(C, name="dlesm_jacobi5_multi_step_dm") result(rc)
        import :: c_int, c_ptr

@@ -47,7 +47,7 @@ module dlesm_psy_mod
   implicit none
   private
 
-  public :: invoke_jacobi5_masked, invoke_jacobi5_dm_pipelined, halo_join
+  public :: invoke_jacobi5_masked, invoke_jacobi5_dm_pipelined, halo_join, halo_connect_peers
   public :: invoke_shallow_step_sw, invoke_periodic_halos, invoke_stencil9, invoke_stencil9_dm
   public :: invoke_jacobi5, invoke_jacobi5_dm, invoke_shallow_step, invoke_copy, invoke_hash_init
   public :: invoke_shallow_step_dm_pipelined, invoke_continuity
@@ -230,6 +230,21 @@ contains
                                          int(out%internal%ystop, c_int), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_jacobi5_dm_pipelined: ' // dlesm_error_text())
   end subroutine invoke_jacobi5_dm_pipelined
+
+  !> COLLECTIVE, once per grid: connect the grid's message plan to the neighbours' mailboxes.  From then on
+  !! invoke_jacobi5_dm / invoke_jacobi5_dm_pipelined exchange by storing straight into the neighbours' memory over
+  !! xGMI (the frame workgroups of the step launch are the exchange) instead of through an RCCL group per step --
+  !! what MPI_Isend/Irecv/Waitany do per strip in the reference (parallel_comms_mod.f90:1601-1750).  Same results.
+  subroutine halo_connect_peers(grid)
+    use parallel_comms_mod, only: halo_plan_for
+    use parallel_utils_mod, only: DIST_MEM_ENABLED
+    type(grid_type), intent(in) :: grid
+    integer(c_int) :: rc
+    if (.not. DIST_MEM_ENABLED) return
+    if (dlesm_halo_plan_peer_connected(halo_plan_for(grid%nx, grid%ny)) /= 0) return
+    rc = dlesm_halo_plan_peer_connect_rccl(halo_plan_for(grid%nx, grid%ny), 1_c_int)
+    if (rc /= 0) call gocean_stop('halo_connect_peers: ' // dlesm_error_text())
+  end subroutine halo_connect_peers
 
   subroutine halo_join(grid)
     use parallel_comms_mod, only: halo_plan_for

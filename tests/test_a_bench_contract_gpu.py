@@ -26,8 +26,8 @@ def _bench(*flags):
                         "--warmup", "2", "--cpu-seconds", "0.5", *flags], env=env, capture_output=True,
                        text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]       # ONE line on stdout, and it is the JSON
     return json.loads(lines[0])
 
 
@@ -50,6 +50,9 @@ def test_bench_line_and_secondary_legs():
     assert sw["copy_ceiling"]["best_gbs"] > 0 and 0 < sw["roofline"]["frac_of_copy_ceiling"] < 2, sw
     assert sw["sw_offset_periodic"]["one_launch_equals_step_plus_halo_copies"] is True, sw["sw_offset_periodic"]
     assert d["copy_ceiling"]["best_gbs"] > 0 and 0 < d["roofline"]["frac_of_copy_ceiling"] < 2, d["copy_ceiling"]
+    lb = d["dm_loopback"]        # round 3: the distributed step over the peer transport beside the RCCL form, loop-back
+    assert "error" not in lb and lb["equals_stencil_plus_rccl_exchange"] is True, lb
+    assert lb["peer"]["value"] > 0 and lb["rccl"]["value"] > 0 and 0.3 < lb["peer"]["frac_of_plain_sweep"] < 1.2, lb
     tb = d["temporal_blocking"]
     assert tb["fused_steps"] == 8 and tb["bit_identical_to_single_steps"] is True and tb["value"] > 0
     assert tb["steps"] >= 24 * 8                       # secondary legs time >= 24 launches whatever --steps is
@@ -70,5 +73,7 @@ def test_rehearsal_of_the_multi_gpu_secondary_leg():
     assert tb["halo_depth"] == 8 and tb["bit_identical_to_single_steps_plus_exchange"] is True
     w = d["weak_scaling_tile"]                          # the 8192^2 object every N > 1 line carries
     assert w["tile"] == 8192 and w["value"] > 0 and "secondary_legs_error" not in d, d
+    pt = d["peer_transport"]                            # ... and the mailbox transport next to RCCL (no messages at 1 rank)
+    assert "error" not in pt and pt["equals_stencil_plus_rccl_exchange"] is True and pt["peer"]["value"] > 0, pt
     sw = d["shallow_water_dm"]                          # the distributed shallow-water leg of the N > 1 lines
     assert sw["value"] > 0 and sw["dm_step_equals_step_plus_exchange"] is True, sw
