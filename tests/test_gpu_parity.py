@@ -665,7 +665,8 @@ def test_join_and_single_field_exchange_variants(D, flag_join, aggregate_single)
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
-@pytest.mark.parametrize("nx,ny,alignment,nsteps", [(300, 41, 64, 7), (64, 64, 2, 12), (1500, 700, 64, 9), (130, 5, 2, 4)])
+@pytest.mark.parametrize("nx,ny,alignment,nsteps", [(300, 41, 64, 7), (64, 64, 2, 12), (1500, 700, 64, 9), (130, 5, 2, 4),
+                                                    (2049, 1031, None, 5)])    # odd ld: in-place rows share lines with the sweep
 @pytest.mark.parametrize("chain,lazy", [(1, 1), (1, 0), (0, 1)])
 def test_pipelined_distributed_steps(D, nx, ny, alignment, nsteps, chain, lazy):
     """dlesm_jacobi5_step_dm_pipelined: a time loop of steps that never joins the exchange on the
@@ -727,9 +728,10 @@ def test_pipelined_distributed_steps(D, nx, ny, alignment, nsteps, chain, lazy):
 
 
 def test_distributed_steps_at_the_weak_scaling_tile(D):
-    """BASELINE configs[4]'s per-GPU tile (8192^2, DL_ESM_ALIGNMENT=64) in RCCL loop-back: six steps in the
-    joined form, in the time-loop form (+ one join) and as plain stencil + edge exchange end in the same
-    field, every bit, halos included"""
+    """BASELINE configs[4]'s per-GPU tile (8192^2, DL_ESM_ALIGNMENT=64) in loop-back: six steps in the joined form, in the
+    time-loop form (+ one join), in the time-loop form over the peer transport (mailboxes, no RCCL kernel) and as plain
+    stencil + edge exchange end in the same field, every bit, halos included -- and that field is the ORACLE's: six x
+    (orc_jacobi5 + the oracle's edge exchange) on the host from the same state"""
     import sys
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
@@ -737,7 +739,7 @@ def test_distributed_steps_at_the_weak_scaling_tile(D):
     D.parallel_init(0, 1, use_rccl=True)
     L = D._cabi.lib()
     g = _grid(D, 8192, 8192, 64)
-    F = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(6)]
+    F = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(8)]
     it = F[0].internal
     t = loopback_tables(D, it)
     plan = C.c_void_p()
@@ -746,9 +748,13 @@ def test_distributed_steps_at_the_weak_scaling_tile(D):
     D._cabi.check(L.dlesm_halo_exchange_f64(plan, F[0].device_ptr, D._cabi.DIRS_ALL, None))
     for f in F[1:]:
         D.copy_field(F[0], f)
+    torch.cuda.synchronize()
+    hx = F[0].get_data()
     finals = []
-    for k, form in enumerate(("plain", "joined", "pipelined")):
+    for k, form in enumerate(("plain", "joined", "pipelined", "mailboxes")):
         a, b = F[2 * k], F[2 * k + 1]
+        if form == "mailboxes":
+            D._cabi.check(L.dlesm_halo_plan_peer_connect_rccl(plan, 1))
         for _ in range(6):
             if form == "plain":
                 D.psy.invoke_jacobi5(b, a)
@@ -763,8 +769,20 @@ def test_distributed_steps_at_the_weak_scaling_tile(D):
         finals.append(a)
     assert bool(torch.equal(finals[0].data, finals[1].data))
     assert bool(torch.equal(finals[0].data, finals[2].data))
+    assert bool(torch.equal(finals[0].data, finals[3].data))
     assert abs(D.field_checksum(finals[0]) - D.field_checksum(finals[2])) == 0.0
+    got = finals[3].get_data()
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+    del F, finals
+    torch.cuda.empty_cache()
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    hy = hx.copy()
+    for _ in range(6):
+        O.jacobi5(hx, hy, g.nx, *it.box())
+        assert O.exchange_dirs([hy], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+        hx, hy = hy, hx
+    assert np.array_equal(got, hx)
 
 
 # --------------------------------------------------------------------------- grid properties (f.4)

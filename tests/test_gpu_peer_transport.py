@@ -65,7 +65,7 @@ def _setup(D, nx, ny, alignment, connect="rccl"):
 
 
 @pytest.mark.parametrize("nx,ny,alignment", [(300, 41, 64), (64, 64, 2), (1500, 700, 64), (130, 5, 2), (37, 29, None),
-                                             (3, 3, 64), (8, 3, None), (2048, 2048, 64)])
+                                             (3, 3, 64), (8, 3, None), (2048, 2048, 64), (2049, 1031, None)])
 @pytest.mark.parametrize("connect", ["rccl", "host"])
 def test_joined_steps_over_the_mailboxes(D, nx, ny, alignment, connect):
     """dlesm_jacobi5_step_dm on a connected plan: after every step the output (edge halos included) equals the oracle's
@@ -89,7 +89,7 @@ def test_joined_steps_over_the_mailboxes(D, nx, ny, alignment, connect):
 
 
 @pytest.mark.parametrize("nx,ny,alignment,nsteps", [(300, 41, 64, 7), (64, 64, 2, 12), (1500, 700, 64, 9), (130, 5, 2, 4),
-                                                    (37, 29, None, 6), (3, 3, 64, 5), (4096, 4096, 64, 6)])
+                                                    (37, 29, None, 6), (3, 3, 64, 5), (4096, 4096, 64, 6), (2049, 1031, None, 5)])
 @pytest.mark.parametrize("chain", [1, 0])
 def test_time_loop_over_the_mailboxes(D, nx, ny, alignment, nsteps, chain):
     """dlesm_jacobi5_step_dm_pipelined on a connected plan: one launch per step, the frame workgroups wait for the
