@@ -857,7 +857,8 @@ static int peer_join(dlesm_halo_plan *p, hipStream_t s)
         DLESM_HIP_TRY(hipEventRecord(p->ev_peer, p->pending_stream));
         DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_peer, 0));
     }
-    if (int rc = launch_peer_unpack(st, p->peer_seq, p->pending_field, p->ld, p->frame_timed_out, s)) return rc;
+    double *one[1] = {p->pending_field};
+    if (int rc = launch_peer_unpack(st, p->peer_seq, one, 1, p->ld, p->frame_timed_out, s)) return rc;
     p->peer_pending = false;
     p->pending_field = nullptr;
     return DLESM_OK;
@@ -1180,6 +1181,72 @@ extern "C" int dlesm_jacobi5_multi_step_dm(dlesm_halo_plan *p, const double *in,
     return DLESM_OK;
 }
 
+// The distributed shallow-water step over the mailboxes (a plan connected for >= 3 fields): ONE launch whose ring
+// workgroups store unew, vnew, pnew of every cell a neighbour needs -- rows, columns and corners, the three fields of a
+// message one after the other as in the aggregated exchange -- into that neighbour's mailbox and raise its arrival flags;
+// behind it one small launch that waits for this rank's own arrival flags and copies the received strips into the halos of
+// the three new fields.  No RCCL kernel, no side stream.  (The time-loop entry takes the same route: the wait sits behind
+// the whole sweep in stream order, by which time the neighbours' rings have long arrived.)
+static int shallow_step_peer(dlesm_halo_plan *p, const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop, int ystart,
+                             int ystop, const double *u, const double *v, const double *pf, const double *uold,
+                             const double *vold, const double *pold, double *unew, double *vnew, double *pnew, hipStream_t s,
+                             const double *smooth_alpha)
+{
+    DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
+                  "an earlier distributed step gave up waiting for a flag (frame or halo wait timed out)");
+    if (int rc = join_pending(p, s)) return rc;
+    const unsigned long long seq = p->peer_seq + 1;
+    const int fx0 = xstart - 1, fx1 = xstop - 1, fy0 = ystart - 1, fy1 = ystop - 1;
+    SwFrameJob job{};
+    FramePack3 &fp = job.pk;
+    DLESM_REQUIRE(p->sends.size() <= (size_t)FramePack3::MAXS && p->recvs.size() <= (size_t)PeerJob::MAXM,
+                  "more than %d messages in one peer step", FramePack3::MAXS);
+    for (size_t k = 0; k < p->sends.size(); k++) {
+        const Msg &m = p->sends[k];
+        const bool in_box = m.i0 >= fx0 && m.i0 + m.nx - 1 <= fx1 && m.j0 >= fy0 && m.j0 + m.ny - 1 <= fy1;
+        const bool on_ring = in_box && ((m.ny == 1 && (m.j0 == fy0 || m.j0 == fy1)) || (m.nx == 1 && (m.i0 == fx0 || m.i0 == fx1)));
+        DLESM_REQUIRE(on_ring, "peer transport: send strip (%d:%d,%d:%d) is not part of the one-cell ring of the box (plans of "
+                      "halo depth 1 stepped over their internal region only)", m.i0 + 1, m.i0 + m.nx, m.j0 + 1, m.j0 + m.ny);
+        fp.s[fp.n] = FramePack3::S{m.i0, m.j0, m.nx, m.ny, 0};
+        fp.base[fp.n] = p->peer_tx[k] + (seq & 1) * p->peer_tx_par[k] + 3 * p->peer_tx_off[k];
+        job.peer_flag[fp.n] = p->peer_txflag[k];
+        fp.n++;
+    }
+    job.npeer = fp.n;
+    fp.buf = p->peer_rx;                                  // (never used: every strip has its own base)
+    job.counter = p->peer_counter;
+    job.flag = p->frame_flag;
+    job.seq = seq;
+    job.timed_out = p->frame_timed_out;
+    bool fused = false;
+    if (fp.n && tuning("sw_dm_fused", 1))
+        if (int rc = launch_shallow_framed(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew,
+                                           job, s, &fused, smooth_alpha))
+            return rc;
+    if (!fused) {     // arrays or boxes the tile kernel does not take: the ring in its own launch, its flags behind it, the interior
+        if (int rc = launch_shallow_frame(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew,
+                                          &fp, s, smooth_alpha))
+            return rc;
+        if (int rc = launch_peer_flags_set(job.peer_flag, job.npeer, seq, s)) return rc;
+        if (xstop - xstart >= 2 && ystop - ystart >= 2) {
+            int rc;
+            if (smooth_alpha)
+                rc = dlesm_shallow_step_smooth_f64(q, *smooth_alpha, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, u, v, pf,
+                                                   const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold),
+                                                   unew, vnew, pnew, s);
+            else
+                rc = dlesm_shallow_step_f64(q, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, u, v, pf, uold, vold, pold, unew,
+                                            vnew, pnew, s);
+            if (rc) return rc;
+        }
+    }
+    p->peer_seq = seq;
+    PeerStrips st{};
+    if (int rc = peer_in_strips(p, DLESM_DIRS_ALL, seq, 3, st.s, &st.n)) return rc;
+    double *fields[3] = {unew, vnew, pnew};
+    return launch_peer_unpack(st, seq, fields, 3, ld, p->frame_timed_out, s);
+}
+
 // Distributed shallow-water step: the one-cell frame of unew/vnew/pnew first (four thin boxes),
 // then ONE grouped exchange of the three new fields on the side stream while the interior is
 // computed on the caller's stream; join.  The new fields leave with valid depth-1 halos
@@ -1212,6 +1279,9 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
     };
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) return box(xstart, xstop, ystart, ystop);
+    if (p->peer_on && p->peer_fcap >= 3 && !graph && tuning("dm_peer", 1))      // mailboxes connected for three fields
+        return shallow_step_peer(p, q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew, s,
+                                 smooth_alpha);
     // 1. frame: the one-cell ring of the box, one cell per thread, all four sides, its west/east columns
     //    written straight into the send buffers of the three new fields -- no pack launches.
     //    sw_dm_frame=0: the round-1 form (four thin boxes + pack kernels).

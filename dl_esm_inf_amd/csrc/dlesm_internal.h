@@ -119,6 +119,8 @@ struct FramePack3 {
     struct S { int i0, j0, ni, nj; long off; } s[MAXS];   // 0-based strip; off = offset of the message's slot
     int n;
     double *buf;                  // aggregated send buffer; field k of strip q at off + k*ni*nj
+    double *base[MAXS];           // peer transport: strip q goes to base[q] + slot (off = 0) -- a neighbour's mailbox; null: buf
+    __host__ __device__ double *at(int q) const { return base[q] ? base[q] : buf; }
     __host__ __device__ long slot(int q, int k, int i, int j) const
     {
         return s[q].off + (long)k * s[q].ni * s[q].nj + (long)(j - s[q].j0) * s[q].ni + (i - s[q].i0);
@@ -201,7 +203,11 @@ int launch_stencil5_peer_frame(const double *in, double *out, int ld, int ny, in
                                PeerJob job, hipStream_t s);
 // wait for the arrival flags of n strips (>= seq), then copy them from the mailbox into the halo cells of `field`
 struct PeerStrips { PeerJob::In s[PeerJob::MAXM]; int n; };
-int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *field, int ld, int *timed_out, hipStream_t s);
+// nf fields: field k of a strip sits k*ni*nj doubles behind its first (the aggregated layout)
+int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *const *fields, int nf, int ld, int *timed_out,
+                       hipStream_t s);
+// *flag[k] = seq for n flags in peer memory (system scope), stream ordered: behind a frame launch that is not the fused one
+int launch_peer_flags_set(unsigned long long *const *flags, int n, unsigned long long seq, hipStream_t s);
 
 // nsteps fused Jacobi steps (dlesm_jacobi_x2.hip); 1-based inclusive output box, last stage box,
 // grow flags -- see dlesm_stencil5_multi_f64
@@ -228,6 +234,10 @@ struct SwFrameJob {
     int *timed_out;
     int smooth;                   // != 0: the Asselin filter of the old level folded in (time_smooth, coefficient alpha)
     double alpha;
+    // peer transport: the pack strips are the neighbours' mailboxes (system-scope stores) and the last frame workgroup
+    // raises THEIR arrival flags with `seq` instead of the local frame flag
+    int npeer;
+    unsigned long long *peer_flag[FramePack3::MAXS];
     int diag;                     // profiling only (results wrong): 1 = no frame cells, 2 = south/north rows only
 };
 // shallow-water step, register-tiled linear sweep (dlesm_shallow.hip); 0-based inclusive box

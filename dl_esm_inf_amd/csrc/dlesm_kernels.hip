@@ -470,17 +470,26 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
 
 // Joins of the peer transport: wait for the strips' arrival flags, then copy them from the mailbox into the halo cells
 // of the field (ordinary stores: the readers are later launches on this stream).  grid = (parts, strips).
-__global__ __launch_bounds__(256) void peer_unpack_k(PeerStrips st, unsigned long long seq, double *__restrict__ field, int ld,
+struct PeerFields { double *f[4]; };
+__global__ __launch_bounds__(256) void peer_unpack_k(PeerStrips st, unsigned long long seq, PeerFields fields, int ld,
                                                      unsigned long long ticks, int *timed_out)
 {
     const PeerJob::In m = st.s[blockIdx.y];
     if (threadIdx.x == 0) peer_wait_flags(&m, 1, seq, ticks, timed_out);
     __syncthreads();
     const long n = (long)m.ni * m.nj;
+    double *__restrict__ field = fields.f[blockIdx.z];
+    const double *src = m.src + (long)blockIdx.z * n;            // field after field inside a message
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
         const int jj = (int)(t / m.ni), ii = (int)(t - (long)jj * m.ni);
-        field[(size_t)(m.j0 + jj) * ld + (m.i0 + ii)] = __hip_atomic_load(m.src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        field[(size_t)(m.j0 + jj) * ld + (m.i0 + ii)] = __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+struct PeerFlagList { unsigned long long *f[PeerJob::MAXM]; };
+__global__ void peer_flags_set_k(PeerFlagList fl, int n, unsigned long long seq)
+{
+    if (threadIdx.x < (unsigned)n) __hip_atomic_store(fl.f[threadIdx.x], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // LDS-staged form (j5_kernel = 2, the comparison point for "stage the tile and its halo ring in
@@ -1001,14 +1010,29 @@ int launch_stencil5_peer_frame(const double *in, double *out, int ld, int ny, in
     return DLESM_OK;
 }
 
-int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *field, int ld, int *timed_out, hipStream_t s)
+int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *const *fields, int nf, int ld, int *timed_out,
+                       hipStream_t s)
 {
     if (st.n == 0) return DLESM_OK;
+    DLESM_REQUIRE(nf >= 1 && nf <= 4, "peer unpack of %d fields", nf);
     long longest = 1;
     for (int k = 0; k < st.n; k++) longest = std::max(longest, (long)st.s[k].ni * st.s[k].nj);
     int parts = (int)((longest + 255) / 256);
     if (parts > 16) parts = 16;
-    hipLaunchKernelGGL(peer_unpack_k, dim3(parts, st.n), dim3(256), 0, s, st, seq, field, ld, remote_wait_ticks(), timed_out);
+    PeerFields pf{};
+    for (int k = 0; k < nf; k++) pf.f[k] = fields[k];
+    hipLaunchKernelGGL(peer_unpack_k, dim3(parts, st.n, nf), dim3(256), 0, s, st, seq, pf, ld, remote_wait_ticks(), timed_out);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+int launch_peer_flags_set(unsigned long long *const *flags, int n, unsigned long long seq, hipStream_t s)
+{
+    if (n == 0) return DLESM_OK;
+    DLESM_REQUIRE(n <= PeerJob::MAXM, "%d peer flags", n);
+    PeerFlagList fl{};
+    for (int k = 0; k < n; k++) fl.f[k] = flags[k];
+    hipLaunchKernelGGL(peer_flags_set_k, dim3(1), dim3(64), 0, s, fl, n, seq);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -1081,9 +1105,10 @@ __global__ __launch_bounds__(256) void shallow_frame_k(
         if (smooth) smooth_old_level(alpha, o, u, v, p, r, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold));
         for (int k = 0; k < pk.n; k++)
             if (pk.holds(k, i, j)) {
-                pk.buf[pk.slot(k, 0, i, j)] = r.un;
-                pk.buf[pk.slot(k, 1, i, j)] = r.vn;
-                pk.buf[pk.slot(k, 2, i, j)] = r.pn;
+                double *b = pk.at(k);          // (a neighbour's mailbox with the peer transport: uncached memory, the
+                b[pk.slot(k, 0, i, j)] = r.un; //  stores have left by the end of the kernel; its flags are raised by a
+                b[pk.slot(k, 1, i, j)] = r.vn; //  launch behind this one)
+                b[pk.slot(k, 2, i, j)] = r.pn;
             }
     }
 }

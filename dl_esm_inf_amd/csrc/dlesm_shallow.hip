@@ -300,9 +300,16 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
         if constexpr (SM) smooth_old_level(fj.alpha, o, u, v, p, r, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold));
         for (int k = 0; k < fj.pk.n; k++)
             if (fj.pk.holds(k, i, j)) {
-                put(fj.pk.buf + fj.pk.slot(k, 0, i, j), r.un);
-                put(fj.pk.buf + fj.pk.slot(k, 1, i, j), r.vn);
-                put(fj.pk.buf + fj.pk.slot(k, 2, i, j), r.pn);
+                double *b = fj.pk.at(k);
+                if (fj.npeer) {       // a neighbour's mailbox: system scope (the bytes cross xGMI)
+                    __hip_atomic_store(b + fj.pk.slot(k, 0, i, j), r.un, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(b + fj.pk.slot(k, 1, i, j), r.vn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(b + fj.pk.slot(k, 2, i, j), r.pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    put(b + fj.pk.slot(k, 0, i, j), r.un);
+                    put(b + fj.pk.slot(k, 1, i, j), r.vn);
+                    put(b + fj.pk.slot(k, 2, i, j), r.pn);
+                }
             }
     }
     __builtin_amdgcn_s_waitcnt(0);        // this wave's stores have been acknowledged ...
@@ -311,7 +318,11 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
         const unsigned done = __hip_atomic_fetch_add(fj.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (unsigned)fj.nblocks - 1) {
             __hip_atomic_store(fj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(fj.flag, fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fj.npeer)         // peer transport: the neighbours' arrival flags
+                for (int k = 0; k < fj.npeer; k++)
+                    __hip_atomic_store(fj.peer_flag[k], fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else
+                __hip_atomic_store(fj.flag, fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -547,8 +547,9 @@ int dlesm_halo_plan_join(dlesm_halo_plan *plan, void *stream);
  * their own halo operands from the local mailbox once its arrival flags are up.  No RCCL kernel, no side stream, no
  * pack, no event.  Mailboxes are double-buffered on the step number, which therefore has to advance on every rank alike
  * (each rank takes the same sequence of distributed steps on its plan -- what a halo exchange asks for anyway).
- * Results are bit for bit those of the RCCL path.  Only dlesm_jacobi5_step_dm / _pipelined use the mailboxes (plans of
- * halo depth 1, stepped over the internal region); every other entry keeps RCCL.  dm_peer = 0 (dlesm_set_tuning)
+ * Results are bit for bit those of the RCCL path.  dlesm_jacobi5_step_dm / _pipelined use the mailboxes (nfields >= 1), and
+ * so do dlesm_shallow_step_dm / _pipelined / _smooth_dm* when the plan was connected with nfields >= 3 (plans of halo depth 1,
+ * stepped over the internal region); every other entry keeps RCCL.  dm_peer = 0 (dlesm_set_tuning)
  * switches a connected plan back to RCCL -- on every rank or on none.
  *
  * Connecting is collective over the ranks that share neighbours:

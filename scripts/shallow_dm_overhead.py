@@ -2,7 +2,7 @@
 """Price the distributed shallow-water step on ONE GPU with RCCL in loop-back (rank 0 is its own eight
 neighbours): plain fused step / step then grouped exchange of unew, vnew, pnew / dlesm_shallow_step_dm /
 its time-loop form dlesm_shallow_step_dm_pipelined (+ one join at the end, inside the timed region).
-    python scripts/shallow_dm_overhead.py [tile]"""
+    python scripts/shallow_dm_overhead.py [tile] [peer]      peer: the plan connected to the mailboxes"""
 import ctypes as C
 import json
 import os
@@ -16,6 +16,7 @@ import dl_esm_inf_amd as D  # noqa: E402
 from dm_overhead import loopback_tables  # noqa: E402
 
 tile = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+PEER = len(sys.argv) > 2 and sys.argv[2] == "peer"
 steps = 30
 L = D._cabi.lib()
 torch.cuda.set_device(0)
@@ -32,6 +33,8 @@ t = loopback_tables(D, it)
 plan = C.c_void_p()
 D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
 g._halo_plan = plan
+if PEER:
+    D.psy.halo_connect_peers(g, 3)
 s = torch.cuda.Stream()
 prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
 
@@ -76,7 +79,7 @@ w = F["p"].whole      # compare the field proper (the padding beyond `whole` acc
 cut = lambda t_: t_[w.ystart - 1:w.ystop, w.xstart - 1:w.xstop]      # noqa: E731
 same = bool(torch.equal(cut(res["serial"][1]), cut(res["overlapped"][1])) and
             torch.equal(cut(res["serial"][1]), cut(res["pipelined"][1])))
-out = {"tile": tile, "ms_per_step": {k: v[0] for k, v in res.items()}, "overlapped_equals_serial_bitwise": same,
+out = {"tile": tile, "transport": "mailboxes" if PEER else "rccl", "ms_per_step": {k: v[0] for k, v in res.items()}, "overlapped_equals_serial_bitwise": same,
        "overlapped_over_plain": res["plain"][0] / res["overlapped"][0],
        "pipelined_over_plain": res["plain"][0] / res["pipelined"][0]}
 print(json.dumps(out, indent=1))

@@ -28,9 +28,11 @@ def D():
 
 @pytest.mark.parametrize("nx,ny,alignment", [(1, 1, 2), (2, 3, 2), (5, 1, 2), (1, 7, 2), (40, 33, 8), (257, 66, 64),
                                              (130, 9, None), (700, 300, 64)])
-@pytest.mark.parametrize("one_launch_frame,fused,aggregate", [(1, 1, 1), (1, 0, 1), (0, 0, 1), (1, 1, 0), (0, 0, 0)])
-def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, fused, aggregate):
-    """fused: the ring as the first workgroups of the interior launch + device flag (default) /
+@pytest.mark.parametrize("one_launch_frame,fused,aggregate,peer", [(1, 1, 1, 0), (1, 0, 1, 0), (0, 0, 1, 0), (1, 1, 0, 0),
+                                                                   (0, 0, 0, 0), (1, 1, 1, 1), (1, 0, 1, 1)])
+def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, fused, aggregate, peer):
+    """peer=1: the plan connected to the mailboxes for three fields -- the ring workgroups store into the
+    neighbour's mailbox, no RCCL kernel in the step (fused=0: the ring in its own launch, its flags behind it).  fused: the ring as the first workgroups of the interior launch + device flag (default) /
     one_launch_frame: the ring in its own launch that also fills the send buffer / the round-1 form,
     four thin boxes + pack kernels.  aggregate=0: one message per field and direction (24 instead of 8),
     the form before the aggregated exchange, kept as the comparison point."""
@@ -57,6 +59,8 @@ def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, 
     plan = C.c_void_p()
     D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
     g._halo_plan = plan
+    if peer:
+        D.psy.halo_connect_peers(g, 3)
     for k, n in enumerate(names[:6]):
         D.psy.hash_init(F[n], 100 + k)
         F[n].data.add_(1.0 if n[0] == "p" else -0.5)
@@ -98,9 +102,9 @@ def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, 
 
 @pytest.mark.parametrize("nx,ny,alignment,nsteps", [(40, 33, 8, 7), (257, 66, 64, 5), (130, 9, None, 6), (700, 300, 64, 9),
                                                     (2, 3, 2, 4)])
-@pytest.mark.parametrize("chain", [1, 0])
-def test_pipelined_shallow_time_loop(D, nx, ny, alignment, nsteps, chain):
-    """a leapfrog time loop of dlesm_shallow_step_dm_pipelined (three time levels rotated by pointer,
+@pytest.mark.parametrize("chain,peer", [(1, 0), (0, 0), (1, 1)])
+def test_pipelined_shallow_time_loop(D, nx, ny, alignment, nsteps, chain, peer):
+    """peer=1: the same loop over the mailboxes (plan connected for three fields).  a leapfrog time loop of dlesm_shallow_step_dm_pipelined (three time levels rotated by pointer,
     the exchange of step k joined on the device by step k+1's frame workgroups, one join at the end)
     against the oracle's step + exchange, every field and halo, bit for bit.  chain=0: the same calls
     with the device-side join switched off (event join at the start of each step)."""
@@ -124,6 +128,8 @@ def test_pipelined_shallow_time_loop(D, nx, ny, alignment, nsteps, chain):
     plan = C.c_void_p()
     D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
     g._halo_plan = plan
+    if peer:
+        D.psy.halo_connect_peers(g, 3)
     for k, n in enumerate(names[:6]):
         D.psy.hash_init(F[n], 200 + k)
         F[n].data.mul_(0.01)
@@ -219,8 +225,9 @@ def test_shallow_dm_at_the_weak_scaling_tile(D):
     g._halo_plan = None
 
 
-def test_time_loop_forms_of_both_steps_share_a_plan(D):
-    """a pipelined shallow-water step, then a pipelined Jacobi step on its pnew (chained on the device to the
+@pytest.mark.parametrize("peer", [0, 1])
+def test_time_loop_forms_of_both_steps_share_a_plan(D, peer):
+    """(peer=1: both kinds of step over the same mailboxes, one sequence number.)  a pipelined shallow-water step, then a pipelined Jacobi step on its pnew (chained on the device to the
     shallow step's exchange), then a pipelined shallow step again (which must first join the Jacobi step's
     un-unpacked exchange): one plan, one stream, every hand-over between the two kinds of step"""
     import torch
@@ -241,6 +248,8 @@ def test_time_loop_forms_of_both_steps_share_a_plan(D):
     plan = C.c_void_p()
     D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
     g._halo_plan = plan
+    if peer:
+        D.psy.halo_connect_peers(g, 3)
     for k, n in enumerate(names[:6]):
         D.psy.hash_init(F[n], 400 + k)
         F[n].data.mul_(0.01)
@@ -280,9 +289,10 @@ def test_time_loop_forms_of_both_steps_share_a_plan(D):
 
 
 @pytest.mark.parametrize("nx,ny,alignment", [(2, 3, 2), (40, 33, 8), (257, 66, 64), (130, 9, None), (700, 300, 64)])
-@pytest.mark.parametrize("one_launch_frame,fused,pipelined", [(1, 1, True), (1, 1, False), (1, 0, False), (0, 0, False)])
-def test_distributed_step_with_the_filter_folded_in(D, nx, ny, alignment, one_launch_frame, fused, pipelined):
-    """dlesm_shallow_step_smooth_dm[_pipelined] -- the distributed step that also filters the old level in place (Asselin,
+@pytest.mark.parametrize("one_launch_frame,fused,pipelined,peer", [(1, 1, True, 0), (1, 1, False, 0), (1, 0, False, 0),
+                                                                   (0, 0, False, 0), (1, 1, True, 1), (1, 0, False, 1)])
+def test_distributed_step_with_the_filter_folded_in(D, nx, ny, alignment, one_launch_frame, fused, pipelined, peer):
+    """(peer=1: over the mailboxes.)  dlesm_shallow_step_smooth_dm[_pipelined] -- the distributed step that also filters the old level in place (Asselin,
     time_smooth) -- in a four-step time loop with the benchmark's rotation, RCCL in loop-back, against the oracle's step +
     exchange of the new level + time_smooth of the old level, every field and halo, bit for bit; in the one-launch,
     own-frame-launch and four-thin-boxes forms"""
@@ -308,6 +318,8 @@ def test_distributed_step_with_the_filter_folded_in(D, nx, ny, alignment, one_la
         plan = C.c_void_p()
         D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
         g._halo_plan = plan
+        if peer:
+            D.psy.halo_connect_peers(g, 3)
         for k, n in enumerate(names[:6]):
             D.psy.hash_init(F[n], 300 + k)
             F[n].data.mul_(0.01)
