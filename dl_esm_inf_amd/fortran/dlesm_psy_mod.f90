@@ -235,14 +235,18 @@ contains
   !! invoke_jacobi5_dm / invoke_jacobi5_dm_pipelined exchange by storing straight into the neighbours' memory over
   !! xGMI (the frame workgroups of the step launch are the exchange) instead of through an RCCL group per step --
   !! what MPI_Isend/Irecv/Waitany do per strip in the reference (parallel_comms_mod.f90:1601-1750).  Same results.
-  subroutine halo_connect_peers(grid)
+  !! nfields (default 1): 3 also takes the distributed shallow-water steps through the mailboxes.
+  subroutine halo_connect_peers(grid, nfields)
     use parallel_comms_mod, only: halo_plan_for
     use parallel_utils_mod, only: DIST_MEM_ENABLED
     type(grid_type), intent(in) :: grid
-    integer(c_int) :: rc
+    integer, intent(in), optional :: nfields
+    integer(c_int) :: rc, nf
     if (.not. DIST_MEM_ENABLED) return
     if (dlesm_halo_plan_peer_connected(halo_plan_for(grid%nx, grid%ny)) /= 0) return
-    rc = dlesm_halo_plan_peer_connect_rccl(halo_plan_for(grid%nx, grid%ny), 1_c_int)
+    nf = 1
+    if (present(nfields)) nf = int(nfields, c_int)
+    rc = dlesm_halo_plan_peer_connect_rccl(halo_plan_for(grid%nx, grid%ny), nf)
     if (rc /= 0) call gocean_stop('halo_connect_peers: ' // dlesm_error_text())
   end subroutine halo_connect_peers
 

@@ -2,8 +2,9 @@
 !! the dl_esm_inf API (grid_type, r2d_field, halo_exchange, field_checksum), PSy layer =
 !! the HIP launch wrappers of dlesm_psy_mod.  5-point Jacobi ping-pong on a T field.
 !!
-!!   jacobi_app.exe [N] [NSTEPS] [FUSE] [PLAN]  (default 4096 100 1 1; DL_ESM_ALIGNMENT honoured; PLAN = 0 skips the
-!!                                               optional planning call; ten untimed warm-up steps precede the timed loop)
+!!   jacobi_app.exe [N] [NSTEPS] [FUSE] [PLAN] [PEER]  (default 4096 100 1 1 0; DL_ESM_ALIGNMENT honoured; PLAN = 0 skips
+!!                        the optional planning call; PEER = 1 connects the ranks' mailboxes, the distributed steps then
+!!                        exchange with stores over xGMI instead of an RCCL group; ten untimed warm-up steps precede the loop)
 !! One process per GPU: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT in the environment (e.g.
 !!   for r in 0 1; do RANK=$r WORLD_SIZE=2 LOCAL_RANK=$r MASTER_PORT=29400 ./jacobi_app.exe & done).
 !! With more than one rank the global domain is (N*P) x (N*Q) so that every rank owns N x N.
@@ -46,7 +47,7 @@ program jacobi_app
   use dlesm_psy_mod
   implicit none
   character(len=32) :: arg
-  integer :: n, nsteps, i, p, q, nr, fuse, ncalls, plan, i0
+  integer :: n, nsteps, i, p, q, nr, fuse, ncalls, plan, i0, peer
   integer(8) :: t0, t1, rate
   type(grid_type), target :: model_grid
   type(r2d_field), target :: a, b
@@ -67,6 +68,10 @@ program jacobi_app
   plan = 1
   if (command_argument_count() >= 4) then
      call get_command_argument(4, arg);  read(arg, *) plan
+  end if
+  peer = 0
+  if (command_argument_count() >= 5) then
+     call get_command_argument(5, arg);  read(arg, *) peer
   end if
   if (fuse < 1 .or. fuse > 8) stop 'jacobi_app: fuse must be 1..8'
   nsteps = (nsteps / fuse) * fuse
@@ -92,6 +97,7 @@ program jacobi_app
   call a%halo_exchange(1)
   call model_write_log("('initial checksum = ',E24.16)", field_checksum(a))
 
+  if (fuse == 1 .and. peer /= 0) call halo_connect_peers(model_grid)     ! collective; no-op on one rank
   if (fuse == 1 .and. plan /= 0) then
      call plan_jacobi5(b, a)            ! optional: the library times its launch shapes once
      call invoke_copy(b, a)
