@@ -857,6 +857,7 @@ def peer_transport_dm(D, torch, dist, tile, alignment, world, P, Q, stream, step
         D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
         g._halo_plan = plan
     old_wait = L.dlesm_set_tuning(b"dm_wait_seconds", 60)   # a neighbour that never answers: words after a minute
+    L.dlesm_set_tuning(b"dm_peer_exchange", 0)              # the reference exchanges of the self-check go through RCCL
 
     def agree(flag):
         if world == 1:
@@ -868,6 +869,7 @@ def peer_transport_dm(D, torch, dist, tile, alignment, world, P, Q, stream, step
     def leave(obj):
         L.dlesm_set_tuning(b"dm_wait_seconds", old_wait or 600)      # (0 = the key was unset: the default)
         L.dlesm_set_tuning(b"dm_peer", 1)
+        L.dlesm_set_tuning(b"dm_peer_exchange", 1)
         return obj
 
     err = None
@@ -921,6 +923,23 @@ def peer_transport_dm(D, torch, dist, tile, alignment, world, P, Q, stream, step
         e1.record(stream)
     stream.synchronize()
     plain = e0.elapsed_time(e1) / steps
+    # r2d_field%halo_exchange on its own (all eight directions), back to back: RCCL group against the two mailbox launches
+    xus = {}
+    for name, px in (("rccl", 0), ("peer", 1)):
+        L.dlesm_set_tuning(b"dm_peer_exchange", px)
+        with torch.cuda.stream(stream):
+            for _ in range(5):
+                a.halo_exchange(1, stream=stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for _ in range(50):
+                a.halo_exchange(1, stream=stream)
+        torch.cuda.synchronize()
+        xus[name] = (time.perf_counter() - t0) / 50 * 1e6
+    L.dlesm_set_tuning(b"dm_peer_exchange", 0)
     rccl, peer = min(res["rccl"], res["rccl2"]), min(res["peer"], res["peer2"])
     cells = tile * tile * world
     out = {"workload": f"jacobi5 {tile}x{tile} fp64 per GPU, {P}x{Q} decomposition, time-loop form of the distributed step: "
@@ -930,7 +949,9 @@ def peer_transport_dm(D, torch, dist, tile, alignment, world, P, Q, stream, step
            "plain_sweep_ms": round(plain, 5),
            "rccl": {"ms_per_step": round(rccl, 5), "value": round(cells / rccl / 1e3, 1), "frac_of_plain_sweep": round(plain / rccl, 4)},
            "peer": {"ms_per_step": round(peer, 5), "value": round(cells / peer / 1e3, 1), "frac_of_plain_sweep": round(plain / peer, 4)},
-           "unit": "Mcells/s", "speedup": round(rccl / peer, 3)}
+           "unit": "Mcells/s", "speedup": round(rccl / peer, 3),
+           "halo_exchange_us": {"rccl": round(xus["rccl"], 1), "peer": round(xus["peer"], 1),
+                                "what": "r2d_field%halo_exchange of one field, eight directions, 50 back to back, this rank's wall clock"}}
     if L.dlesm_wait_timed_out(0):
         out["error"] = "a wait gave up during the timed loops"
     D._cabi.check(L.dlesm_halo_plan_destroy(g._halo_plan))

@@ -614,6 +614,33 @@ static int exchange_agg(dlesm_halo_plan *p, double *const *fields, int nf, unsig
 // pair of ranks messages match in issue order, field-major, then ascending direction code, on both sides.
 // `prepacked`: the caller's kernel has already written the enabled strided strips of every field
 // into the send buffer (dlesm_jacobi5_step_dm's frame kernel does), so no pack launch is needed.
+static int peer_in_strips(const dlesm_halo_plan *p, unsigned mask, unsigned long long seq, int nf, PeerJob::In *in, int *n);
+
+// r2d_field%halo_exchange over the mailboxes (a connected plan with room for nf fields): TWO small launches on the caller's
+// stream -- every enabled send strip copied into the neighbours' mailboxes and their arrival flags raised; then the wait
+// for this rank's own flags and the copy of the received strips into the halos -- instead of pack + RCCL group + unpack.
+// What MPI_Isend / MPI_Irecv / MPI_Waitany + the unpack loop do in the reference (parallel_comms_mod.f90:1601-1798).
+// Send strips are read from the internal region only, so no message depends on another one's arrival (any depth).
+static int exchange_peer(dlesm_halo_plan *p, double *const *fields, int nf, unsigned mask, hipStream_t s)
+{
+    DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
+                  "an earlier wait for a neighbour's arrival flag gave up");
+    const unsigned long long seq = p->peer_seq + 1;
+    PeerOuts out{};
+    for (size_t m = 0; m < p->sends.size(); m++) {
+        const Msg &sm = p->sends[m];
+        if (!dir_enabled(mask, sm.dir)) continue;
+        DLESM_REQUIRE(out.n < PeerJob::MAXM, "more than %d send messages in one exchange", PeerJob::MAXM);
+        out.s[out.n++] = PeerJob::Out{sm.i0, sm.j0, sm.nx, sm.ny,
+                                      p->peer_tx[m] + (seq & 1) * p->peer_tx_par[m] + (long)nf * p->peer_tx_off[m], p->peer_txflag[m]};
+    }
+    PeerStrips st{};
+    if (int rc = peer_in_strips(p, mask, seq, nf, st.s, &st.n)) return rc;
+    if (int rc = launch_peer_pack(out, fields, nf, p->ld, p->peer_counter, seq, s)) return rc;
+    p->peer_seq = seq;
+    return launch_peer_unpack(st, seq, fields, nf, p->ld, p->frame_timed_out, s);
+}
+
 static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsigned mask, hipStream_t s,
                        bool prepacked = false, bool skip_unpack = false)
 {
@@ -623,6 +650,9 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
     for (const Msg &m : p->recvs)
         if (dir_enabled(mask, m.dir)) { any = true; any_rpack |= m.off >= 0; }
     if (!any) return DLESM_OK; // serial run, or no direction enabled: nothing to do (pcomms:1546,1557-1571)
+    if (p->peer_on && nf <= p->peer_fcap && !prepacked && !skip_unpack && !capturing(s) && tuning("dm_peer", 1) &&
+        tuning("dm_peer_exchange", 1))
+        return exchange_peer(p, fields, nf, mask, s);
     // (a single field on its own goes the same way: rows staged through the buffer travel faster than rows
     //  sent in place from their 8-byte-aligned position in the field -- 42 against 52 us at 8192^2)
     if ((nf > 1 || (!prepacked && !skip_unpack && tuning("dm_aggregate_single", 1))) && tuning("dm_aggregate", 1))

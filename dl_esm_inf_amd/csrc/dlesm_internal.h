@@ -203,6 +203,11 @@ int launch_stencil5_peer_frame(const double *in, double *out, int ld, int ny, in
                                PeerJob job, hipStream_t s);
 // wait for the arrival flags of n strips (>= seq), then copy them from the mailbox into the halo cells of `field`
 struct PeerStrips { PeerJob::In s[PeerJob::MAXM]; int n; };
+// a halo exchange over the mailboxes, first half: every enabled send strip of nf fields copied into the neighbours'
+// mailboxes (field after field inside a message), then -- by the last workgroup to finish -- `seq` into their arrival flags
+struct PeerOuts { PeerJob::Out s[PeerJob::MAXM]; int n; };
+int launch_peer_pack(const PeerOuts &out, const double *const *fields, int nf, int ld, unsigned *counter, unsigned long long seq,
+                     hipStream_t s);
 // nf fields: field k of a strip sits k*ni*nj doubles behind its first (the aggregated layout)
 int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *const *fields, int nf, int ld, int *timed_out,
                        hipStream_t s);

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
 
 // Joins of the peer transport: wait for the strips' arrival flags, then copy them from the mailbox into the halo cells
 // of the field (ordinary stores: the readers are later launches on this stream).  grid = (parts, strips).
-struct PeerFields { double *f[4]; };
+struct PeerFields { double *f[16]; };
 __global__ __launch_bounds__(256) void peer_unpack_k(PeerStrips st, unsigned long long seq, PeerFields fields, int ld,
                                                      unsigned long long ticks, int *timed_out)
 {
@@ -483,6 +483,33 @@ __global__ __launch_bounds__(256) void peer_unpack_k(PeerStrips st, unsigned lon
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
         const int jj = (int)(t / m.ni), ii = (int)(t - (long)jj * m.ni);
         field[(size_t)(m.j0 + jj) * ld + (m.i0 + ii)] = __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// First half of an exchange over the mailboxes: grid = (parts, strips, fields).  Payload stores and flags as in
+// jacobi5_tile_peer: system-scope write-through stores, drained, barrier, one counter increment per workgroup, the last
+// arriver raises every neighbour's flag.
+__global__ __launch_bounds__(256) void peer_pack_k(PeerOuts out, PeerFields fields, int ld, unsigned *counter,
+                                                   unsigned long long seq)
+{
+    const PeerJob::Out m = out.s[blockIdx.y];
+    const long n = (long)m.ni * m.nj;
+    const double *__restrict__ field = fields.f[blockIdx.z];
+    double *dst = m.dst + (long)blockIdx.z * n;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int jj = (int)(t / m.ni), ii = (int)(t - (long)jj * m.ni);
+        __hip_atomic_store(dst + t, field[(size_t)(m.j0 + jj) * ld + (m.i0 + ii)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == total - 1) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < out.n; k++)
+                __hip_atomic_store(out.s[k].flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1014,7 +1041,7 @@ int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *con
                        hipStream_t s)
 {
     if (st.n == 0) return DLESM_OK;
-    DLESM_REQUIRE(nf >= 1 && nf <= 4, "peer unpack of %d fields", nf);
+    DLESM_REQUIRE(nf >= 1 && nf <= 16, "peer unpack of %d fields", nf);
     long longest = 1;
     for (int k = 0; k < st.n; k++) longest = std::max(longest, (long)st.s[k].ni * st.s[k].nj);
     int parts = (int)((longest + 255) / 256);
@@ -1022,6 +1049,22 @@ int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *con
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = fields[k];
     hipLaunchKernelGGL(peer_unpack_k, dim3(parts, st.n, nf), dim3(256), 0, s, st, seq, pf, ld, remote_wait_ticks(), timed_out);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+int launch_peer_pack(const PeerOuts &out, const double *const *fields, int nf, int ld, unsigned *counter, unsigned long long seq,
+                     hipStream_t s)
+{
+    if (out.n == 0) return DLESM_OK;
+    DLESM_REQUIRE(nf >= 1 && nf <= 16 && counter != nullptr, "peer pack of %d fields", nf);
+    long longest = 1;
+    for (int k = 0; k < out.n; k++) longest = std::max(longest, (long)out.s[k].ni * out.s[k].nj);
+    int parts = (int)((longest + 255) / 256);
+    if (parts > 16) parts = 16;
+    PeerFields pf{};
+    for (int k = 0; k < nf; k++) pf.f[k] = const_cast<double *>(fields[k]);
+    hipLaunchKernelGGL(peer_pack_k, dim3(parts, out.n, nf), dim3(256), 0, s, out, pf, ld, counter, seq);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }

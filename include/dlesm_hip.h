@@ -549,7 +549,10 @@ int dlesm_halo_plan_join(dlesm_halo_plan *plan, void *stream);
  * (each rank takes the same sequence of distributed steps on its plan -- what a halo exchange asks for anyway).
  * Results are bit for bit those of the RCCL path.  dlesm_jacobi5_step_dm / _pipelined use the mailboxes (nfields >= 1), and
  * so do dlesm_shallow_step_dm / _pipelined / _smooth_dm* when the plan was connected with nfields >= 3 (plans of halo depth 1,
- * stepped over the internal region); every other entry keeps RCCL.  dm_peer = 0 (dlesm_set_tuning)
+ * stepped over the internal region), and dlesm_halo_exchange_f64 / _multi_f64 themselves (any depth, nfields <= the
+ * count the plan was connected for: one launch that copies the send strips into the neighbours' mailboxes and raises their
+ * flags, one that waits for this rank's flags and unpacks; dm_peer_exchange = 0 keeps the RCCL group for them).  The
+ * fused multi-step and 3x3 distributed steps keep their RCCL-side machinery.  dm_peer = 0 (dlesm_set_tuning)
  * switches a connected plan back to RCCL -- on every rank or on none.
  *
  * Connecting is collective over the ranks that share neighbours:

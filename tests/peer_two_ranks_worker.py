@@ -75,10 +75,28 @@ def check(fld, nsteps, what):
     return bad
 
 
-D.psy.hash_init(x, SEED, box=ring)
-D.psy.hash_init(y, SEED, box=ring)
 D.psy.halo_connect_peers(g)
 errors = 0
+# r2d_field%halo_exchange between the processes (no RCCL in this job: only the mailboxes can do it).  y: a WRONG field
+# everywhere, the right one on the internal region; after the exchange every halo cell that lies inside the global domain
+# (edges and corners) must hold the right field, the cells of the global boundary ring keep the wrong one.
+for rnd in range(3):
+    D.psy.hash_init(y, SEED + 1 + rnd, box=ring)
+    D.psy.hash_init(y, SEED + 50 + rnd, box=it)
+    y.halo_exchange(1)
+    torch.cuda.synchronize()
+    got = y.get_data()[it.ystart - 2:it.ystop + 1, it.xstart - 2:it.xstop + 1]
+    right = O.hash_field(SEED + 50 + rnd, NY + 2, NX + 2, 0, 0, 1, NX + 2, 1, NY + 2)
+    wrong = O.hash_field(SEED + 1 + rnd, NY + 2, NX + 2, 0, 0, 1, NX + 2, 1, NY + 2)
+    want = wrong.copy()
+    want[1:NY + 1, 1:NX + 1] = right[1:NY + 1, 1:NX + 1]
+    want = want[gy0 + it.ystart - 2:gy0 + it.ystop + 1, gx0 + it.xstart - 2:gx0 + it.xstop + 1]
+    bad = int(np.count_nonzero(got != want))
+    if bad:
+        print(f"ERROR rank {rank}: halo_exchange over the mailboxes, round {rnd}: {bad} cells differ", flush=True)
+        errors += bad
+D.psy.hash_init(x, SEED, box=ring)
+D.psy.hash_init(y, SEED, box=ring)
 s = torch.cuda.Stream()
 a, b = x, y
 n = 0

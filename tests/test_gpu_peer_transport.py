@@ -197,3 +197,78 @@ def test_eight_direction_steps_and_refusals(D):
     D._cabi.check(L.dlesm_halo_plan_peer_connect(plan, 0, 1, blob))
     assert L.dlesm_halo_plan_peer_connected(plan) == 1
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+@pytest.mark.parametrize("dirs,no_diag", [((), False), ((1,), False), ((1, 4), False), ((1, 2, 3), False), ((1, 2, 3, 4), False),
+                                          ((1, 2, 3, 4), True), ((2, 4), True)])
+@pytest.mark.parametrize("nx,ny,alignment,nf", [(37, 23, 8, 1), (130, 6, None, 3), (700, 300, 64, 2)])
+def test_halo_exchange_over_the_mailboxes(D, nx, ny, alignment, nf, dirs, no_diag):
+    """r2d_field%halo_exchange (exchange_generic with a choice of comm1..comm4, parallel_comms_mod.f90:1557-1571) on a
+    connected plan: two small launches, no RCCL.  dm_skip_parts=1 switches the RCCL group OFF for the duration, so only
+    the mailbox path can produce the oracle's halos; then the same exchange through RCCL (dm_peer_exchange=0) and through
+    the mailboxes again -- the two transports keep separate sequence numbers"""
+    import torch
+    from dm_overhead import loopback_tables
+    L = D._cabi.lib()
+    g = _grid(D, nx, ny, alignment)
+    F = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(nf)]
+    t = loopback_tables(D, F[0].internal)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    D._cabi.check(L.dlesm_halo_plan_peer_connect_rccl(plan, 3))
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    mask = sum(1 << (d - 1) for d in dirs) | (D._cabi.DIRS_NO_DIAGONALS if no_diag else 0)
+    ptrs = (C.c_void_p * nf)(*[f.device_ptr for f in F])
+    try:
+        for rnd, (skip, peer_x) in enumerate(((1, 1), (0, 0), (1, 1), (1, 1))):
+            for k, f in enumerate(F):
+                D.psy.hash_init(f, SEED + 100 * rnd + k)
+            torch.cuda.synchronize()
+            want = [f.get_data() for f in F]
+            for w in want:
+                assert O.exchange_dirs([w], [g.nx], [oc], dirs, no_diagonals=no_diag) == 0
+            L.dlesm_set_tuning(b"dm_skip_parts", skip)
+            L.dlesm_set_tuning(b"dm_peer_exchange", peer_x)
+            D._cabi.check(L.dlesm_halo_exchange_multi_f64(plan, ptrs, nf, mask, None))
+            torch.cuda.synchronize()
+            for f, w in zip(F, want):
+                assert np.array_equal(f.get_data(), w), (rnd, skip, peer_x)
+        assert L.dlesm_wait_timed_out(0) == 0
+    finally:
+        L.dlesm_set_tuning(b"dm_skip_parts", 0)
+        L.dlesm_set_tuning(b"dm_peer_exchange", 1)
+        D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+def test_deep_halo_exchange_over_the_mailboxes(D):
+    """a depth-3 plan (the tables of the fused multi-step forms): strips three cells deep, 3 x 3 corners -- the mailbox
+    exchange has no one-cell-ring condition"""
+    import torch
+    from dm_overhead import loopback_tables
+    L = D._cabi.lib()
+    os.environ["DL_ESM_ALIGNMENT"] = "64"
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    g.decompose(200, 90, halo_width=3)
+    D.grid_init(g, 1.0, 1.0)
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+    f = D.r2d_field(g, D.GO_T_POINTS)
+    t = loopback_tables(D, f.internal, 3)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    D._cabi.check(L.dlesm_halo_plan_peer_connect_rccl(plan, 1))
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    L.dlesm_set_tuning(b"dm_skip_parts", 1)
+    try:
+        for rnd in range(3):
+            D.psy.hash_init(f, SEED + rnd, box=D._cabi.Region(0, 0, 1, g.nx, 1, g.ny))
+            torch.cuda.synchronize()
+            want = f.get_data()
+            assert O.exchange_all([want], [g.nx], [oc]) == 0
+            D._cabi.check(L.dlesm_halo_exchange_f64(plan, f.device_ptr, D._cabi.DIRS_ALL, None))
+            torch.cuda.synchronize()
+            assert np.array_equal(f.get_data(), want)
+    finally:
+        L.dlesm_set_tuning(b"dm_skip_parts", 0)
+        D._cabi.check(L.dlesm_halo_plan_destroy(plan))
