@@ -145,6 +145,10 @@ struct dlesm_halo_plan {
     unsigned long long peer_seq = 0;           // steps taken through the mailboxes (the same number on every rank)
     bool peer_pending = false;                 // halos of pending_field are still in the mailbox (parity peer_seq & 1)
     hipEvent_t ev_peer = nullptr;
+    // the mailboxes, their counter and the sequence number are ONE resource: an operation issued on another stream than
+    // the previous one is ordered behind it (peer_order)
+    bool peer_used = false;
+    hipStream_t peer_last_stream = nullptr;
 };
 
 // edge directions follow their bit; diagonals follow their two edges (parallel_comms_mod.f90:
@@ -615,6 +619,7 @@ static int exchange_agg(dlesm_halo_plan *p, double *const *fields, int nf, unsig
 // `prepacked`: the caller's kernel has already written the enabled strided strips of every field
 // into the send buffer (dlesm_jacobi5_step_dm's frame kernel does), so no pack launch is needed.
 static int peer_in_strips(const dlesm_halo_plan *p, unsigned mask, unsigned long long seq, int nf, PeerJob::In *in, int *n);
+static int peer_order(dlesm_halo_plan *p, hipStream_t s);
 
 // r2d_field%halo_exchange over the mailboxes (a connected plan with room for nf fields): TWO small launches on the caller's
 // stream -- every enabled send strip copied into the neighbours' mailboxes and their arrival flags raised; then the wait
@@ -625,6 +630,7 @@ static int exchange_peer(dlesm_halo_plan *p, double *const *fields, int nf, unsi
 {
     DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
                   "an earlier wait for a neighbour's arrival flag gave up");
+    if (int rc = peer_order(p, s)) return rc;
     const unsigned long long seq = p->peer_seq + 1;
     PeerOuts out{};
     for (size_t m = 0; m < p->sends.size(); m++) {
@@ -864,6 +870,18 @@ extern "C" int dlesm_halo_plan_peer_connect_rccl(dlesm_halo_plan *p, int nfields
 
 extern "C" int dlesm_halo_plan_peer_connected(const dlesm_halo_plan *p) { return p && p->peer_on ? 1 : 0; }
 
+// Mailbox operations of one plan run one after the other: on one stream that is stream order; across streams, an event.
+static int peer_order(dlesm_halo_plan *p, hipStream_t s)
+{
+    if (p->peer_used && p->peer_last_stream != s) {
+        DLESM_HIP_TRY(hipEventRecord(p->ev_peer, p->peer_last_stream));
+        DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_peer, 0));
+    }
+    p->peer_used = true;
+    p->peer_last_stream = s;
+    return DLESM_OK;
+}
+
 // the receive strips of the step that is pending, as they sit in the mailbox (parity of that step)
 static int peer_in_strips(const dlesm_halo_plan *p, unsigned mask, unsigned long long seq, int nf, PeerJob::In *in, int *n)
 {
@@ -883,10 +901,7 @@ static int peer_join(dlesm_halo_plan *p, hipStream_t s)
     DLESM_REQUIRE(!capturing(s), "a peer-transport step is in flight: call dlesm_halo_plan_join before capturing a graph");
     PeerStrips st{};
     if (int rc = peer_in_strips(p, p->pending_mask, p->peer_seq, 1, st.s, &st.n)) return rc;
-    if (s != p->pending_stream) {      // the step itself ran elsewhere: order this stream behind it
-        DLESM_HIP_TRY(hipEventRecord(p->ev_peer, p->pending_stream));
-        DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_peer, 0));
-    }
+    if (int rc = peer_order(p, s)) return rc;      // the step itself may have run on another stream
     double *one[1] = {p->pending_field};
     if (int rc = launch_peer_unpack(st, p->peer_seq, one, 1, p->ld, p->frame_timed_out, s)) return rc;
     p->peer_pending = false;
@@ -908,6 +923,7 @@ static int jacobi5_step_peer(dlesm_halo_plan *p, const double *in, double *out, 
                        p->pending_mask == mask && tuning("j5_dm_chain", 1);
     if (!chain)
         if (int rc = join_pending(p, s)) return rc;
+    if (int rc = peer_order(p, s)) return rc;
     PeerJob job{};
     const unsigned long long seq = p->peer_seq + 1;
     const int fx0 = xstart - 1, fx1 = xstop - 1, fy0 = ystart - 1, fy1 = ystop - 1;
@@ -1225,6 +1241,7 @@ static int shallow_step_peer(dlesm_halo_plan *p, const dlesm_sw_params *q, int l
     DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
                   "an earlier distributed step gave up waiting for a flag (frame or halo wait timed out)");
     if (int rc = join_pending(p, s)) return rc;
+    if (int rc = peer_order(p, s)) return rc;
     const unsigned long long seq = p->peer_seq + 1;
     const int fx0 = xstart - 1, fx1 = xstop - 1, fy0 = ystart - 1, fy1 = ystop - 1;
     SwFrameJob job{};

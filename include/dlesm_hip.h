@@ -552,7 +552,9 @@ int dlesm_halo_plan_join(dlesm_halo_plan *plan, void *stream);
  * stepped over the internal region), and dlesm_halo_exchange_f64 / _multi_f64 themselves (any depth, nfields <= the
  * count the plan was connected for: one launch that copies the send strips into the neighbours' mailboxes and raises their
  * flags, one that waits for this rank's flags and unpacks; dm_peer_exchange = 0 keeps the RCCL group for them).  The
- * fused multi-step and 3x3 distributed steps keep their RCCL-side machinery.  dm_peer = 0 (dlesm_set_tuning)
+ * fused multi-step and 3x3 distributed steps keep their RCCL-side machinery.  The mailboxes of a plan are one resource:
+ * operations on it issued on different streams are ordered one behind the other by the library (an event); ordering the
+ * FIELDS between streams stays the caller's business, as with any other entry.  dm_peer = 0 (dlesm_set_tuning)
  * switches a connected plan back to RCCL -- on every rank or on none.
  *
  * Connecting is collective over the ranks that share neighbours:

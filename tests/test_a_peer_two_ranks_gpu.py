@@ -20,7 +20,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("nx,ny,world,steps,align", [(96, 64, 2, 6, "64"), (64, 96, 2, 5, "none"), (640, 512, 4, 8, "64"),
-                                                    (2048, 4096, 2, 6, "64")])
+                                                    (2048, 4096, 2, 6, "64"), (300, 200, 6, 5, "64")])    # 6 ranks: a 2 x 3 mesh, up to five neighbours per rank
 def test_peer_transport_between_processes(nx, ny, world, steps, align):
     import torch
     assert not torch.cuda.is_initialized(), "run this file before any in-process GPU test"

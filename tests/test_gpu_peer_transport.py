@@ -272,3 +272,42 @@ def test_deep_halo_exchange_over_the_mailboxes(D):
     finally:
         L.dlesm_set_tuning(b"dm_skip_parts", 0)
         D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+def test_mailbox_operations_issued_on_alternating_streams(D):
+    """the mailboxes, their counter and the sequence number are one resource per plan: exchanges and steps issued on two
+    non-blocking streams in turn, with no host synchronisation in between, are ordered by the library (peer_order)"""
+    import torch
+    L, g, x, y, plan, oc = _setup(D, 1500, 700, 64)
+    it = x.internal
+    D.psy.hash_init(x, SEED + 77)
+    D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+    D.copy_field(x, y)
+    torch.cuda.synchronize()
+    hx, hy = x.get_data(), y.get_data()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    a, b = x, y
+    ev = torch.cuda.Event()
+    for k in range(12):
+        s = (s1, s2)[k % 2]
+        o = (s2, s1)[k % 2]
+        s.wait_event(ev)                       # the FIELDS are the caller's to order; the mailboxes are the library's
+        sp = C.c_void_p(s.cuda_stream)
+        if k % 3 == 2:
+            D._cabi.check(L.dlesm_halo_exchange_f64(plan, a.device_ptr, D._cabi.DIRS_ALL, sp))
+            assert O.exchange_all([hx], [g.nx], [oc]) == 0
+        else:
+            fn = L.dlesm_jacobi5_step_dm_pipelined if k % 3 == 0 else L.dlesm_jacobi5_step_dm
+            D._cabi.check(fn(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), sp))
+            a, b = b, a
+            O.jacobi5(hx, hy, g.nx, *it.box())
+            assert O.exchange_dirs([hy], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+            hx, hy = hy, hx
+        ev = torch.cuda.Event()
+        ev.record(s)
+        del o
+    D._cabi.check(L.dlesm_halo_plan_join(plan, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(a.get_data(), hx)
+    assert L.dlesm_wait_timed_out(0) == 0
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
