@@ -79,20 +79,32 @@ __global__ __launch_bounds__(1024) void continuity_tile(ContFields f, double rdt
         hv[k] = *(const d2 *)(f.hv + o);
         vn[k] = *(const d2 *)(f.vn + o);
     }
+    // every load of the tile first (rows beyond je clamped: loaded again, never used), the west column of lane 0 among
+    // them -- an edge load behind a branch in the row loop is one more dependent round trip per row
+    constexpr bool N1 = (NTM & 1) != 0;
+    d2 st[R], ar[R], su[R], hu[R], un[R];
+    double esu[R], ehu[R], eun[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        int jj = jb + k;
+        if (jj > je) jj = je;
+        const size_t row = (size_t)jj * ld, o = row + (size_t)cl * 2;
+        st[k] = ldv<N1>(f.sshn_t + o), ar[k] = ldv<N1>(f.area_t + o);
+        su[k] = ldv<N1>(f.sshn_u + o), hu[k] = ldv<N1>(f.hu + o), un[k] = ldv<N1>(f.un + o);
+        const size_t eo = ecol >= 0 ? row + ecol : o;        // other lanes: a cell they have just loaded
+        esu[k] = f.sshn_u[eo], ehu[k] = f.hu[eo], eun[k] = f.un[eo];
+    }
 #pragma unroll
     for (int k = 0; k < R; k++) {
         const int jj = jb + k;
         if (jj > je) break;
-        const size_t row = (size_t)jj * ld, o = row + (size_t)cl * 2;
-        constexpr bool N1 = (NTM & 1) != 0;
-        const d2 st = ldv<N1>(f.sshn_t + o), ar = ldv<N1>(f.area_t + o);
-        const d2 su = ldv<N1>(f.sshn_u + o), hu = ldv<N1>(f.hu + o), un = ldv<N1>(f.un + o);
-        double su_w = from_lower<true>(su.y), hu_w = from_lower<true>(hu.y), un_w = from_lower<true>(un.y);
-        if (ecol >= 0) { su_w = f.sshn_u[row + ecol]; hu_w = f.hu[row + ecol]; un_w = f.un[row + ecol]; }
-        const double o0 = cont_point(rdt, st.x, su.x, su_w, sv[k + 1].x, sv[k].x, hu.x, hu_w, hv[k + 1].x, hv[k].x, un.x,
-                                     un_w, vn[k + 1].x, vn[k].x, ar.x);
-        const double o1 = cont_point(rdt, st.y, su.y, su.x, sv[k + 1].y, sv[k].y, hu.y, hu.x, hv[k + 1].y, hv[k].y, un.y,
-                                     un.x, vn[k + 1].y, vn[k].y, ar.y);
+        const size_t row = (size_t)jj * ld;
+        double su_w = from_lower<true>(su[k].y), hu_w = from_lower<true>(hu[k].y), un_w = from_lower<true>(un[k].y);
+        if (ecol >= 0) { su_w = esu[k]; hu_w = ehu[k]; un_w = eun[k]; }
+        const double o0 = cont_point(rdt, st[k].x, su[k].x, su_w, sv[k + 1].x, sv[k].x, hu[k].x, hu_w, hv[k + 1].x, hv[k].x,
+                                     un[k].x, un_w, vn[k + 1].x, vn[k].x, ar[k].x);
+        const double o1 = cont_point(rdt, st[k].y, su[k].y, su[k].x, sv[k + 1].y, sv[k].y, hu[k].y, hu[k].x, hv[k + 1].y,
+                                     hv[k].y, un[k].y, un[k].x, vn[k + 1].y, vn[k].y, ar[k].y);
         double *po = f.ssha + row + (size_t)c * 2;
         if (m0 && m1) {
             if (NTM & 2) __builtin_nontemporal_store(d2{o0, o1}, (d2 *)po);

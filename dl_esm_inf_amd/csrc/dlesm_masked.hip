@@ -73,8 +73,9 @@ __global__ __launch_bounds__(1024) void jacobi5_masked_tile(const double *__rest
 #pragma unroll
     for (int k = 1; k <= R; k++) {
         if (jb + k - 1 > je) break;
-        double vw = __shfl_up(v[k].y, 1), ve = __shfl_down(v[k].x, 1);
-        int mw = __shfl_up(m[k].y, 1), me = __shfl_down(m[k].x, 1);
+        // whole-wave shifts on the VALU (DPP), not through the LDS pipe: lanes 0 / 63 take the edge loads below
+        double vw = from_lower<true>(v[k].y), ve = from_upper<true>(v[k].x);
+        int mw = __builtin_amdgcn_mov_dpp(m[k].y, 0x138, 0xf, 0xf, true), me = __builtin_amdgcn_mov_dpp(m[k].x, 0x130, 0xf, 0xf, true);
         if (lane == 0) { vw = ev[k]; mw = em[k]; }
         if (lane == 63) { ve = ev[k]; me = em[k]; }
         const double o0 = masked_point(v[k].x, vw, v[k].y, v[k - 1].x, v[k + 1].x, m[k].x, mw, m[k].y, m[k - 1].x, m[k + 1].x);

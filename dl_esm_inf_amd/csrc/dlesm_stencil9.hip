@@ -71,8 +71,8 @@ __device__ __forceinline__ void stencil9_tile_body(const double *__restrict__ in
     double vw[R + 2], ve[R + 2];
 #pragma unroll
     for (int r = 0; r < R + 2; r++) {
-        vw[r] = __shfl_up(v[r].y, 1);
-        ve[r] = __shfl_down(v[r].x, 1);
+        vw[r] = from_lower<true>(v[r].y);        // whole-wave shifts on the VALU (DPP), not through the LDS pipe
+        ve[r] = from_upper<true>(v[r].x);
         if (lane == 0) vw[r] = ev[r];
         if (lane == 63) ve[r] = ev[r];
     }
