@@ -954,6 +954,9 @@ def peer_transport_dm(D, torch, dist, tile, alignment, world, P, Q, stream, step
                                 "what": "r2d_field%halo_exchange of one field, eight directions, 50 back to back, this rank's wall clock"}}
     if L.dlesm_wait_timed_out(0):
         out["error"] = "a wait gave up during the timed loops"
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()                                       # nobody frees a mailbox a neighbour may still be mapping
     D._cabi.check(L.dlesm_halo_plan_destroy(g._halo_plan))
     g._halo_plan = None
     del a, b, x, y, x1, y1, x2, y2
