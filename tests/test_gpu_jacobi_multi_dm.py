@@ -31,8 +31,11 @@ CASES = [(4, 4, 2, 2), (2, 5, 2, 2), (9, 7, 3, 2), (40, 33, 2, 8), (257, 66, 4, 
          (64, 70, 5, 8), (33, 9, 7, 2), (1200, 64, 8, 64)]
 
 
+@pytest.mark.parametrize("peer", [0, 1])
 @pytest.mark.parametrize("nx,ny,nsteps,alignment", CASES)
-def test_fused_distributed_step_in_loopback(D, nx, ny, nsteps, alignment):
+def test_fused_distributed_step_in_loopback(D, nx, ny, nsteps, alignment, peer):
+    """peer=1: the plan connected to the mailboxes -- the depth-nsteps exchanges (the initial one and the one inside the
+    fused step) are the two-launch mailbox exchange, with the RCCL group switched off underneath"""
     import torch
     from dm_overhead import loopback_tables
     L = D._cabi.lib()
@@ -51,6 +54,9 @@ def test_fused_distributed_step_in_loopback(D, nx, ny, nsteps, alignment):
     plan = C.c_void_p()
     D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
     g._halo_plan = plan
+    if peer:
+        D.psy.halo_connect_peers(g)
+        L.dlesm_set_tuning(b"dm_skip_parts", 1)        # no RCCL group: only the mailboxes can move the halos
     try:
         D.psy.hash_init(a, 77, box=D._cabi.Region(0, 0, 1, g.nx, 1, g.ny))
         before = a.get_data()
@@ -76,5 +82,6 @@ def test_fused_distributed_step_in_loopback(D, nx, ny, nsteps, alignment):
             rc = L.dlesm_jacobi5_multi_step_dm(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, 3, *it.box(), None)
             assert rc == D._cabi.EINVAL
     finally:
+        L.dlesm_set_tuning(b"dm_skip_parts", 0)
         D._cabi.check(L.dlesm_halo_plan_destroy(plan))
         g._halo_plan = None
