@@ -203,10 +203,7 @@ def lib():
     except ImportError:
         pass
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    lenient = bool(os.environ.get("DLESM_HIP_LIB")) and os.environ.get("DLESM_HIP_LIB_LENIENT") == "1"
     for name, (res, args) in PROTOTYPES.items():
-        if lenient and not hasattr(L, name):      # A/B measurements against an OLDER build of the library only
-            continue
         fn = getattr(L, name)         # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
