@@ -22,6 +22,8 @@ ap.add_argument("--sw", type=int, default=0)
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--what", default="step")
 ap.add_argument("--staggers", default="")
+ap.add_argument("--align2m", action="store_true", help="array-to-array distance = the size rounded up to 2 MiB (what an "
+                "allocator that hands out 2 MiB-aligned blocks gives) + the stagger")
 args = ap.parse_args()
 
 import torch  # noqa: E402
@@ -43,10 +45,13 @@ it = t.internal
 box = (it.xstart, it.xstop, it.ystart, it.ystop)
 del t
 size = ld * ny * 8
+SIZE_BYTES = size
+if args.align2m:
+    size = (size + (2 << 20) - 1) & ~((2 << 20) - 1)
 prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
 s = torch.cuda.Stream()
 sp = C.c_void_p(s.cuda_stream)
-narr = 9 if args.what == "step" else 2
+narr = 9 if args.what in ("step", "smooth") else 2
 staggers = [int(x) for x in args.staggers.split(",")] if args.staggers else \
     [0, 256, 512, 1024, 2048, 4096, 4096 + 256, 8192, 8192 + 512, 16384, 32768, 65536, 65536 + 4096, 1 << 20, (1 << 20) + 4096 + 256]
 maxst = max(staggers)
@@ -61,7 +66,12 @@ s.synchronize()
 
 def run(stagger):
     ptrs = [C.c_void_p(base + k * (size + stagger)) for k in range(narr)]
-    if args.what == "step":
+    if args.what == "smooth":      # the whole filtered step: cur <-> new alternate, old stays (and is updated in place)
+        def once(rot):
+            p = ptrs if rot % 2 == 0 else ptrs[6:] + ptrs[3:6] + ptrs[:3]
+            rc = L.dlesm_shallow_step_smooth_f64(C.byref(prm), C.c_double(0.001), ld, ny, *box, *p, sp)
+            assert rc == 0, D._cabi.last_error()
+    elif args.what == "step":
         fn = L.dlesm_shallow_step_sw_f64 if args.sw else L.dlesm_shallow_step_f64
 
         def once(rot):
@@ -79,7 +89,7 @@ def run(stagger):
         with torch.cuda.stream(s):
             e0.record(s)
             for i in range(args.reps):
-                once(i % 3 if args.what == "step" else i)
+                once(i % 3 if args.what == "step" else i)      # (smooth: i % 2 inside)
             e1.record(s)
         s.synchronize()
         if r:
@@ -87,8 +97,24 @@ def run(stagger):
     return best
 
 
-bpc = 72 if args.what == "step" else 16
+bpc = {"step": 72, "smooth": 96}.get(args.what, 16)
 for st in staggers + staggers[:3]:
     ms = run(st)
+    if args.what == "smooth":      # the two rotations separately: is one role assignment slower?
+        save = args.reps
+        both = []
+        for par in (0, 1):
+            ptrs_ = None
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pp = [C.c_void_p(base + k * (size + st)) for k in range(narr)]
+            q = pp if par == 0 else pp[6:] + pp[3:6] + pp[:3]
+            with torch.cuda.stream(s):
+                e0.record(s)
+                for _ in range(10):
+                    L.dlesm_shallow_step_smooth_f64(C.byref(prm), C.c_double(0.001), ld, ny, *box, *q, sp)
+                e1.record(s)
+            s.synchronize()
+            both.append(e0.elapsed_time(e1) / 10)
+        print(f"      rotation 0: {both[0]:.4f} ms   rotation 1: {both[1]:.4f} ms", flush=True)
     print(f"stagger {st:8d} B  (array-to-array distance % 64 KiB = {(size + st) % 65536:6d}, % 4 KiB = {(size + st) % 4096:4d})  "
           f"{ms:.4f} ms  {bpc * N * N / ms / 1e6:7.1f} GB/s  frac {bpc * N * N / ms / 1e6 / 8000:.4f}", flush=True)
