@@ -166,6 +166,13 @@ PROTOTYPES = {
     "dlesm_jacobi5_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_jacobi5_step_dm_pipelined": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_halo_plan_join": (_i, [_vp, _vp]),
+    "dlesm_comm_init_mailbox": (_i, [_vp, _i, _i]),
+    "dlesm_comm_is_mailbox": (_i, []),
+    "dlesm_board_nonce": (_i, [_vp]),
+    "dlesm_board_open": (_i, [_vp, _i, _i]),
+    "dlesm_board_is_open": (_i, []),
+    "dlesm_board_allgather": (_i, [_vp, C.c_size_t, _vp]),
+    "dlesm_board_close": (_i, []),
     "dlesm_halo_plan_peer_export": (_i, [_vp, _i, _i, _vp]),
     "dlesm_halo_plan_peer_connect": (_i, [_vp, _i, _i, _vp]),
     "dlesm_halo_plan_peer_connect_rccl": (_i, [_vp, _i]),

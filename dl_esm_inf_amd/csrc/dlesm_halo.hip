@@ -57,6 +57,12 @@ namespace {
 
 ncclComm_t g_comm = nullptr;
 int g_rank = -1, g_size = 0;
+// MAILBOX MODE (dlesm_comm_init_mailbox): no RCCL communicator at all.  Every plan connects its mailboxes when it is
+// created (the descriptors travel over the host-side board, dlesm_rendezvous.cpp), exchanges and distributed steps go
+// through them, a global sum is eight bytes over the board, a gather is every rank copying its block straight into the
+// root's buffer through an IPC mapping.  What a job of one process per GPU needs from MPI in the reference, without a
+// communication library underneath.
+bool g_mailbox = false;
 
 struct Strip { // one packed (strided) message
     int i0, j0, nx, ny; // 0-based origin and extent inside the field
@@ -353,8 +359,30 @@ extern "C" int dlesm_comm_init(const void *id, int nranks, int rank0)
     return DLESM_OK;
 }
 
+extern "C" int dlesm_comm_init_mailbox(const void *id, int nranks, int rank0)
+{
+    DLESM_REQUIRE(id != nullptr, "null id buffer");
+    DLESM_REQUIRE(nranks >= 1 && rank0 >= 0 && rank0 < nranks, "rank %d of %d", rank0, nranks);
+    DLESM_REQUIRE(g_comm == nullptr && !g_mailbox, "communicator already initialised");
+    if (int rc = ensure_device()) return rc;
+    if (int rc = dlesm_board_open(id, nranks, rank0)) return rc;
+    g_rank = rank0;
+    g_size = nranks;
+    g_mailbox = true;
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_comm_is_mailbox(void) { return g_mailbox ? 1 : 0; }
+
 extern "C" int dlesm_comm_finalize(void)
 {
+    if (g_mailbox) {
+        (void)hipDeviceSynchronize();
+        g_mailbox = false;
+        g_rank = -1;
+        g_size = 0;
+        return dlesm_board_close();
+    }
     if (g_comm) {
         (void)hipDeviceSynchronize();
         DLESM_NCCL_TRY(ncclCommDestroy(g_comm));
@@ -433,6 +461,18 @@ extern "C" int dlesm_halo_plan_create(const dlesm_comm_tables *t, int ld, int ny
         // the probe the one-launch forms rest on (kernels of two streams side by side), once, here, for the stream most
         // programs use -- not inside somebody's first time step
         (void)streams_run_concurrently(nullptr);
+    }
+    if (g_mailbox && g_size > 1) {      // COLLECTIVE in mailbox mode: every rank creates its plans at the same points
+        int fcap = tuning("mailbox_fields", 3);
+        if (const char *e = getenv("DLESM_MAILBOX_FIELDS")) fcap = atoi(e);
+        if (fcap < 1 || fcap > 16) fcap = 3;
+        std::vector<char> all((size_t)g_size * DLESM_PEER_BLOB_BYTES);
+        char mine[DLESM_PEER_BLOB_BYTES];
+        if ((rc = dlesm_halo_plan_peer_export(p, g_rank, fcap, mine)) || (rc = dlesm_board_allgather(mine, sizeof mine, all.data())) ||
+            (rc = dlesm_halo_plan_peer_connect(p, g_rank, g_size, all.data()))) {
+            dlesm_halo_plan_destroy(p);
+            return rc;
+        }
     }
     *out = p;
     return DLESM_OK;
@@ -709,6 +749,13 @@ extern "C" int dlesm_halo_exchange_multi_f64(dlesm_halo_plan *p, double *const *
     for (int k = 0; k < nfields; k++) DLESM_REQUIRE(fields[k] != nullptr, "null field %d", k);
     if (int rc = ensure_device()) return rc;
     if (int rc = join_pending(p, (hipStream_t)stream)) return rc;
+    if (g_mailbox && p->peer_on && nfields > p->peer_fcap) {      // more fields than a mailbox has room for: in turns
+        for (int k = 0; k < nfields; k += p->peer_fcap) {
+            const int nf = std::min(p->peer_fcap, nfields - k);
+            if (int rc = exchange_on(p, fields + k, nf, dirs_mask & 0x1Fu, (hipStream_t)stream)) return rc;
+        }
+        return DLESM_OK;
+    }
     return exchange_on(p, fields, nfields, dirs_mask & 0x1Fu, (hipStream_t)stream);
 }
 
@@ -1112,6 +1159,11 @@ extern "C" int dlesm_stencil9_step_dm(dlesm_halo_plan *p, const double *in, doub
     if (p->sends.empty() && p->recvs.empty()) return launch_stencil9(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, s);
     const bool corners = coef[0] != 0.0 || coef[2] != 0.0 || coef[6] != 0.0 || coef[8] != 0.0;
     const unsigned mask = corners ? DLESM_DIRS_ALL : (DLESM_DIRS_ALL | DLESM_DIRS_NO_DIAGONALS);
+    if (p->peer_on && tuning("dm_peer", 1) && tuning("dm_peer_exchange", 1) && !capturing(s)) {
+        // mailboxes: the whole box, then the two-launch exchange behind it on the same stream (7 us against an RCCL group's 42)
+        if (int rc = launch_stencil9(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, s)) return rc;
+        return exchange_on(p, out, mask, s);
+    }
     FramePack fp{};
     bool prepacked = true;
     for (const Msg &m : p->sends) {
@@ -1466,6 +1518,14 @@ extern "C" int dlesm_global_sum_f64(double *value)
 {
     DLESM_REQUIRE(value != nullptr, "null pointer");
     if (g_size <= 1) return DLESM_OK; // the stub's no-op (parallel_utils_stub_mod.f90:148-150)
+    if (g_mailbox) {                  // eight bytes per rank over the board, summed in rank order on every rank
+        std::vector<double> all(g_size);
+        if (int rc = dlesm_board_allgather(value, sizeof(double), all.data())) return rc;
+        double sum = 0.0;
+        for (int r = 0; r < g_size; r++) sum += all[r];
+        *value = sum;
+        return DLESM_OK;
+    }
     if (int rc = ensure_device()) return rc;
     static double *d = nullptr;
     if (!d) DLESM_HIP_TRY(hipMalloc((void **)&d, sizeof(double)));
@@ -1474,6 +1534,61 @@ extern "C" int dlesm_global_sum_f64(double *value)
     DLESM_NCCL_TRY(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, g_comm, s));
     DLESM_HIP_TRY(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, s));
     DLESM_HIP_TRY(hipStreamSynchronize(s));
+    return DLESM_OK;
+}
+
+// MPI_Gather in mailbox mode: the root publishes an IPC handle of its receive buffer over the board, every other rank maps
+// it and copies its block STRAIGHT into its slot (one device-to-device copy over xGMI), a second round of the board tells
+// the root that all blocks have landed.  A root buffer that cannot be exported (not a hipMalloc allocation) takes the
+// blocks through the board instead (host memory).
+static int gather_mailbox(const double *send, double *recv, int n)
+{
+    struct Note { hipIpcMemHandle_t h; unsigned long long off; int ok; int pad; };
+    const size_t bytes = (size_t)n * sizeof(double);
+    Note mine;
+    memset(&mine, 0, sizeof mine);
+    if (g_rank == 0 && n > 0) {
+        void *base = nullptr;
+        size_t span = 0;
+        if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &span, (hipDeviceptr_t)recv) == hipSuccess &&
+            hipIpcGetMemHandle(&mine.h, base) == hipSuccess && !tuning("mailbox_gather_host", 0)) {
+            mine.off = (unsigned long long)((char *)recv - (char *)base);
+            mine.ok = 1;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    std::vector<Note> notes(g_size);
+    if (int rc = dlesm_board_allgather(&mine, sizeof mine, notes.data())) return rc;
+    int rc = DLESM_OK;
+    if (n > 0 && notes[0].ok) {
+        if (g_rank == 0) {
+            if (hipMemcpy(recv, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = fail(DLESM_EHIP, "gather: local copy failed");
+        } else {
+            void *rootbuf = nullptr;
+            if (hipIpcOpenMemHandle(&rootbuf, notes[0].h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                rc = fail(DLESM_EHIP, "gather: cannot map the root's receive buffer");
+            } else {
+                if (hipMemcpy((char *)rootbuf + notes[0].off + (size_t)g_rank * bytes, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess ||
+                    hipDeviceSynchronize() != hipSuccess)
+                    rc = fail(DLESM_EHIP, "gather: copy into the root's receive buffer failed");
+                (void)hipIpcCloseMemHandle(rootbuf);
+            }
+        }
+        char done = rc ? 1 : 0;
+        std::vector<char> every(g_size);
+        if (int rc2 = dlesm_board_allgather(&done, 1, every.data())) return rc2;       // all blocks have landed (or not)
+        for (int r = 0; r < g_size && !rc; r++)
+            if (every[r]) rc = fail(DLESM_EHIP, "gather: rank %d could not deliver its block", r);
+        return rc;
+    }
+    // through host memory
+    std::vector<double> block((size_t)n), all;
+    if (n > 0 && hipMemcpy(block.data(), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(DLESM_EHIP, "gather: D2H failed");
+    if (g_rank == 0) all.resize((size_t)n * g_size);
+    if (int rc2 = dlesm_board_allgather(block.data(), bytes, g_rank == 0 ? all.data() : nullptr)) return rc2;
+    if (g_rank == 0 && n > 0 && hipMemcpy(recv, all.data(), bytes * g_size, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(DLESM_EHIP, "gather: H2D failed");
     return DLESM_OK;
 }
 
@@ -1490,6 +1605,8 @@ extern "C" int dlesm_gather_f64(const double *send, double *recv, int n)
     }
     // MPI_Gather to root 0 (parallel_utils_mod.f90:242-255) as grouped send/recv
     DLESM_REQUIRE(g_rank != 0 || recv != nullptr, "null receive buffer on root");
+    if (g_mailbox) return gather_mailbox(send, recv, n);
+    DLESM_REQUIRE(g_comm != nullptr, "gather before dlesm_comm_init");
     DLESM_NCCL_TRY(ncclGroupStart());
     ncclResult_t err = ncclSuccess;
     if (g_rank == 0) {
@@ -1702,7 +1819,7 @@ extern "C" int dlesm_gather_inner_f64(const double *field, int ld, int ny, const
                                   (size_t)w * sizeof(double), (size_t)h, hipMemcpyDeviceToHost));
         return DLESM_OK;
     }
-    DLESM_REQUIRE(g_comm != nullptr && g_size == nranks, "gather over %d ranks, communicator has %d", nranks, g_size);
+    DLESM_REQUIRE((g_comm != nullptr || g_mailbox) && g_size == nranks, "gather over %d ranks, communicator has %d", nranks, g_size);
     const int halo_x = it->xstart - 1, halo_y = it->ystart - 1;                  // field_mod.f90:1348-1349
     const long slot = (long)(d->max_width - 2 * halo_x) * (d->max_height - 2 * halo_y);
     DLESM_REQUIRE(slot > 0, "empty gather slot (max tile %dx%d, halos %d,%d)", d->max_width, d->max_height, halo_x, halo_y);

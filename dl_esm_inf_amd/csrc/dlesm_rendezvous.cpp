@@ -197,3 +197,156 @@ extern "C" int dlesm_rendezvous_wait_acks(const char *path, int nranks, int time
     }
     return DLESM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The BOARD: a host-side all-gather between the processes of one job through files in /dev/shm -- the control plane of
+// the mailbox transport when there is no RCCL communicator (dlesm_comm_init_mailbox): mailbox descriptors at plan
+// creation, the eight bytes of a global sum, the hand-shake of a gather.  What MPI_Allgather on a few bytes is to the
+// reference.  Operation k of rank r is the file <prefix>.<k>.<r>, written whole and published with rename(2); a rank
+// has finished operation k when it has read the n files of k.  A rank writes its file of k+1 only after that, so once
+// a rank has read all files of k+1 nobody needs its file of k any more: it removes it then.  Host code only.
+#include <string>
+
+namespace {
+
+struct Board {
+    std::string prefix;
+    int rank = -1, n = 0;
+    long op = 0;
+} g_board;
+
+int board_write(const std::string &name, const void *data, size_t bytes)
+{
+    const std::string tmp = name + ".tmp";
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    if (fd < 0) return fail(DLESM_EINVAL, "board: cannot create %s: %s", tmp.c_str(), strerror(errno));
+    size_t done = 0;
+    while (done < bytes) {
+        const ssize_t w = write(fd, (const char *)data + done, bytes - done);
+        if (w <= 0) { close(fd); unlink(tmp.c_str()); return fail(DLESM_EINVAL, "board: write to %s: %s", tmp.c_str(), strerror(errno)); }
+        done += (size_t)w;
+    }
+    if (close(fd) != 0 || rename(tmp.c_str(), name.c_str()) != 0) {
+        unlink(tmp.c_str());
+        return fail(DLESM_EINVAL, "board: cannot publish %s: %s", name.c_str(), strerror(errno));
+    }
+    return DLESM_OK;
+}
+
+int board_read(const std::string &name, void *data, size_t bytes, int timeout_ms)
+{
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        const int fd = open(name.c_str(), O_RDONLY);
+        if (fd >= 0) {
+            size_t done = 0;
+            while (done < bytes) {
+                const ssize_t r = read(fd, (char *)data + done, bytes - done);
+                if (r <= 0) break;
+                done += (size_t)r;
+            }
+            close(fd);
+            if (done == bytes) return DLESM_OK;
+            return fail(DLESM_EINVAL, "board: %s holds %zu bytes, %zu expected (ranks out of step?)", name.c_str(), done, bytes);
+        }
+        struct timespec now;
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        const long long waited = (now.tv_sec - t0.tv_sec) * 1000LL + (now.tv_nsec - t0.tv_nsec) / 1000000LL;
+        if (waited >= timeout_ms) return fail(DLESM_EINVAL, "board: %s did not appear within %d ms", name.c_str(), timeout_ms);
+        const struct timespec nap = {0, 200 * 1000};     // 0.2 ms, sleeping
+        nanosleep(&nap, nullptr);
+    }
+}
+
+std::string board_name(long op, int r) { return g_board.prefix + "." + std::to_string(op) + "." + std::to_string(r); }
+
+int board_timeout_ms()
+{
+    if (const char *e = getenv("DLESM_BOARD_TIMEOUT_S")) {
+        const long v = atol(e);
+        if (v > 0) return (int)(v * 1000);
+    }
+    return 600 * 1000;      // a neighbour may be seconds or minutes behind (it waits in MPI without limit in the reference)
+}
+
+} // namespace
+
+// 128 bytes (the size of an RCCL unique id, so that it travels the same way): a name no other job has
+extern "C" int dlesm_board_nonce(void *id)
+{
+    DLESM_REQUIRE(id != nullptr, "null id buffer");
+    char buf[DLESM_UNIQUE_ID_BYTES];
+    memset(buf, 0, sizeof buf);
+    struct timespec now;
+    clock_gettime(CLOCK_REALTIME, &now);
+    snprintf(buf, sizeof buf, "mbx-%lld-%ld-%ld", (long long)now.tv_sec, (long)now.tv_nsec, (long)getpid());
+    memcpy(id, buf, sizeof buf);
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_board_open(const void *id, int nranks, int rank0)
+{
+    DLESM_REQUIRE(id != nullptr && nranks >= 1 && rank0 >= 0 && rank0 < nranks, "board: rank %d of %d", rank0, nranks);
+    DLESM_REQUIRE(g_board.rank < 0, "board: already open");
+    char name[DLESM_UNIQUE_ID_BYTES + 1];
+    memcpy(name, id, DLESM_UNIQUE_ID_BYTES);
+    name[DLESM_UNIQUE_ID_BYTES] = 0;
+    for (const char *c = name; *c; c++)
+        DLESM_REQUIRE((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || *c == '-' || *c == '_',
+                      "board: the session name may hold letters, digits, '-' and '_' only");
+    DLESM_REQUIRE(name[0], "board: empty session name");
+    const char *dir = getenv("DLESM_BOARD_DIR");
+    g_board.prefix = std::string(dir && *dir ? dir : "/dev/shm") + "/dlesm_board_" + name;
+    g_board.rank = rank0;
+    g_board.n = nranks;
+    g_board.op = 0;
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_board_is_open(void) { return g_board.rank >= 0 ? 1 : 0; }
+
+// every rank contributes `bytes`; `all` (nranks x bytes, rank order) may be null on ranks that only contribute
+// (a gather to a root: the others still take part, so that the operation counts stay in step)
+extern "C" int dlesm_board_allgather(const void *mine, size_t bytes, void *all)
+{
+    DLESM_REQUIRE(g_board.rank >= 0, "board: not open (dlesm_comm_init_mailbox)");
+    DLESM_REQUIRE(mine != nullptr || bytes == 0, "board: null contribution");
+    const long op = ++g_board.op;
+    const int to = board_timeout_ms();
+    if (int rc = board_write(board_name(op, g_board.rank), mine, bytes)) return rc;
+    std::string scratch;
+    for (int r = 0; r < g_board.n; r++) {
+        void *dst = all ? (char *)all + (size_t)r * bytes : nullptr;
+        if (!dst) { scratch.resize(bytes); dst = &scratch[0]; }
+        if (int rc = board_read(board_name(op, r), dst, bytes, to)) return rc;
+    }
+    if (op > 1) unlink(board_name(op - 1, g_board.rank).c_str());
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_board_close(void)
+{
+    if (g_board.rank < 0) return DLESM_OK;
+    char c = 0;
+    int rc = dlesm_board_allgather(&c, 1, nullptr);                 // A: after it, nobody needs my files of earlier operations
+    const long a = g_board.op;
+    if (!rc) rc = dlesm_board_allgather(&c, 1, nullptr);            // B: after it, nobody needs my file of A (removed by B itself)
+    const long b = g_board.op;
+    if (!rc) {
+        // the files of B: every rank but 0 says when it has read them all; rank 0 then removes them and the notes
+        if (g_board.rank > 0) {
+            rc = board_write(g_board.prefix + ".done." + std::to_string(g_board.rank), &c, 1);
+        } else {
+            for (int r = 1; r < g_board.n && !rc; r++) {
+                const std::string note = g_board.prefix + ".done." + std::to_string(r);
+                rc = board_read(note, &c, 1, board_timeout_ms());
+                unlink(note.c_str());
+            }
+            for (int r = 0; r < g_board.n; r++) unlink(board_name(b, r).c_str());
+        }
+    }
+    (void)a;
+    g_board = Board{};
+    return rc;
+}

@@ -423,6 +423,18 @@ module dlesm_hip_mod
        integer(c_int), value :: nranks, rank0
        integer(c_int) :: rc
      end function
+     ! mailbox mode: no RCCL communicator (the session name is made by rank 0 and handed round like an RCCL id)
+     function dlesm_board_nonce(id) bind(C, name="dlesm_board_nonce") result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), intent(out) :: id(*)
+       integer(c_int) :: rc
+     end function
+     function dlesm_comm_init_mailbox(id, nranks, rank0) bind(C, name="dlesm_comm_init_mailbox") result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), intent(in) :: id(*)
+       integer(c_int), value :: nranks, rank0
+       integer(c_int) :: rc
+     end function
      function dlesm_comm_finalize() bind(C, name="dlesm_comm_finalize") result(rc)
        import :: c_int
        integer(c_int) :: rc

@@ -132,6 +132,9 @@ contains
        publishing = .true.
        if (env_set('DLESM_DRY_COMMS')) then
           id = c_null_char      ! table-inspection mode: exercise the rendezvous, create no communicator
+       else if (env_is('DLESM_TRANSPORT', 'mailbox')) then
+          rc = dlesm_board_nonce(id)          ! a session name instead of an RCCL id
+          if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
        else
           rc = dlesm_comm_unique_id(id)
           if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
@@ -154,7 +157,13 @@ contains
        if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
        return
     end if
-    rc = dlesm_comm_init(id, int(nranks, c_int), int(rank - 1, c_int))
+    ! DLESM_TRANSPORT=mailbox: no communication library -- message plans connect their mailboxes when they are made and
+    ! every exchange is stores into the neighbours' memory (dlesm_comm_init_mailbox, include/dlesm_hip.h)
+    if (env_is('DLESM_TRANSPORT', 'mailbox')) then
+       rc = dlesm_comm_init_mailbox(id, int(nranks, c_int), int(rank - 1, c_int))
+    else
+       rc = dlesm_comm_init(id, int(nranks, c_int), int(rank - 1, c_int))
+    end if
     if (rc /= 0) call parallel_abort('parallel_init: ' // dlesm_error_text())
     comm_up = .true.
   end subroutine bootstrap_rccl

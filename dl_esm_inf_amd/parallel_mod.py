@@ -31,11 +31,36 @@ class decomposition_type:
         self.proc_subdomains = [[r + 1] for r in range(info.ndomains)]
 
 
-def parallel_init(rank=None, nranks=None, use_rccl=None):
+def parallel_init(rank=None, nranks=None, use_rccl=None, transport=None):
     """parallel_init (parallel_mod.f90:51-63).  rank is 0-based here (RANK env style) and
     stored 1-based.  With more than one rank the RCCL communicator is created; the unique id
-    travels through the already-initialised torch.distributed group."""
+    travels through the already-initialised torch.distributed group.
+    transport="mailbox" (or DLESM_TRANSPORT=mailbox): no RCCL communicator -- every plan connects its mailboxes when it is
+    made, exchanges and distributed steps are stores into the neighbours' memory (dlesm_comm_init_mailbox)."""
     global _rank, _nranks, _rccl_up
+    if transport is None:
+        transport = os.environ.get("DLESM_TRANSPORT", "rccl")
+    if transport == "mailbox":
+        if rank is None:
+            rank = int(os.environ.get("RANK", "0"))
+        if nranks is None:
+            nranks = int(os.environ.get("WORLD_SIZE", "1"))
+        _rank, _nranks = rank + 1, nranks
+        if nranks > 1 and not _rccl_up:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("parallel_init: torch.distributed must be initialised to hand the session name round")
+            L = _cabi.lib()
+            buf = C.create_string_buffer(_cabi.UNIQUE_ID_BYTES)
+            box = [None]
+            if rank == 0:
+                check(L.dlesm_board_nonce(buf))
+                box[0] = buf.raw
+            dist.broadcast_object_list(box, src=0)
+            buf = C.create_string_buffer(box[0], _cabi.UNIQUE_ID_BYTES)
+            check(L.dlesm_comm_init_mailbox(buf, nranks, rank))
+            _rccl_up = True            # (a communicator of the other kind: parallel_finalise closes it)
+        return
     if rank is None:
         rank = int(os.environ.get("RANK", "0"))
     if nranks is None:

@@ -438,6 +438,16 @@ int dlesm_set_tuning(const char *key, int value);
 int dlesm_comm_unique_id(void *id /* DLESM_UNIQUE_ID_BYTES */);
 /* parallel_init, parallel_utils_mod.f90:77-90: rank0 is 0-based here */
 int dlesm_comm_init(const void *id, int nranks, int rank0);
+/* MAILBOX MODE -- the same job without a communication library: no RCCL communicator is created.  Every message plan
+ * connects its mailboxes when it is created (dlesm_halo_plan_create becomes collective; room for mailbox_fields /
+ * DLESM_MAILBOX_FIELDS fields, default 3), halo exchanges and the distributed Jacobi / shallow-water steps go through them
+ * (stores over xGMI, see the peer transport below), dlesm_global_sum_f64 is eight bytes per rank over the host-side board
+ * (summed in rank order, the same bits on every rank), dlesm_gather_f64 / dlesm_gather_inner_f64 copy every rank's
+ * block straight into the root's buffer through an IPC mapping.  `id`: a session name all ranks share, made by rank 0 with
+ * dlesm_board_nonce and handed round like an RCCL id (dlesm_rendezvous_publish / _fetch, a torch store ...).
+ * Replaces MPI_Init + the MPI calls of parallel_utils_mod.f90:77-255 for a job of one process per GPU on one node. */
+int dlesm_comm_init_mailbox(const void *id, int nranks, int rank0);
+int dlesm_comm_is_mailbox(void);
 int dlesm_comm_finalize(void);
 int dlesm_comm_rank(void);   /* 0-based, -1 before init */
 int dlesm_comm_size(void);
@@ -456,6 +466,17 @@ int dlesm_rendezvous_fetch(const char *path, void *id, const char *token, int ti
  * id): readers acknowledge, rank 0 waits for nranks-1 acknowledgements and removes them */
 int dlesm_rendezvous_ack(const char *path, int rank0);
 int dlesm_rendezvous_wait_acks(const char *path, int nranks, int timeout_ms);
+
+/* The BOARD: a host-side all-gather between the processes of one job through files (/dev/shm, or DLESM_BOARD_DIR) -- the
+ * control plane of mailbox mode.  Host only.  nonce: a session name (letters, digits, '-', '_') no other job has;
+ * allgather: every rank contributes `bytes`, `all` receives nranks x bytes in rank order (may be null on ranks that only
+ * contribute); every rank must make the same sequence of calls.  A rank that does not show up within
+ * DLESM_BOARD_TIMEOUT_S (default 600) makes the call fail. */
+int dlesm_board_nonce(void *id /* DLESM_UNIQUE_ID_BYTES */);
+int dlesm_board_open(const void *id, int nranks, int rank0);
+int dlesm_board_is_open(void);
+int dlesm_board_allgather(const void *mine, size_t bytes, void *all);
+int dlesm_board_close(void);
 
 /* Message plan for fields of shape (ld, ny): device copy of the tables, pack
  * buffers for the strided (east/west) strips.  One plan serves every field of

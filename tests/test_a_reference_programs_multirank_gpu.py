@@ -1,0 +1,84 @@
+"""GPU test (-m gpu): the reference's OWN multi-rank test programs -- tests/dist_mem/{test_halos, test_gsum,
+test_reduction}.f90, compiled UNMODIFIED against this library's Fortran API layer (oracle/Makefile target `dropin`, built
+in the container that has /root/reference; the executables travel with the work tree like the library's .so) -- run
+with the rank counts and domain sizes of the reference's own Makefile (tests/dist_mem/Makefile:64-80: 10x4/np 2, 4x10/np 2,
+10x10/np 4 and 6; gsum 4x10/np 4, 6; reduction 10x10/np 4, 6).
+
+One process per rank, all on the box's one GPU, MAILBOX MODE (DLESM_TRANSPORT=mailbox: RCCL refuses two ranks on one
+device, and this mode needs no communication library): the session name travels through the library's file rendezvous as
+an RCCL id would, go_decompose / map_comms build the tables, every halo_exchange is stores into the neighbour process's
+mailbox through a real IPC mapping, global_sum goes over the host-side board, gather_inner_data copies every rank's block
+into the root's buffer through an IPC mapping.  The programs check themselves (the hill() known answers of
+test_halos.f90:188, the cell counts of test_gsum.f90:108-110, scatter/gather of test_reduction.f90) and print ERROR
+lines on a mismatch.  Sorts before the in-process GPU tests: the pytest process has not touched the GPU when it starts
+children."""
+import os
+import socket
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+DROP = os.path.join(ROOT, "oracle", "_dropin")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(exe, world, env_extra, args=()):
+    import torch
+    assert not torch.cuda.is_initialized(), "run this file before any in-process GPU test"
+    path = os.path.join(DROP, exe) if not os.path.isabs(exe) else exe
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not built (make -C oracle dropin, in a container that has /root/reference)")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DLESM_TRANSPORT="mailbox", DLESM_JOB_ID=f"pytest-{port}",
+                   DLESM_BOARD_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        env.pop("DL_ESM_ALIGNMENT", None)
+        env.update({k: str(v) for k, v in env_extra.items()})
+        procs.append(subprocess.Popen([path, *map(str, args)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} of {world} failed:\n{out[-3000:]}"
+        assert "ERROR" not in out, f"rank {r} of {world}:\n{out[-3000:]}"
+    return outs
+
+
+@pytest.mark.parametrize("nx,ny,world", [(10, 4, 2), (4, 10, 2), (10, 10, 4), (10, 10, 6)])
+@pytest.mark.parametrize("alignment", [None, 8])
+def test_reference_test_halos(nx, ny, world, alignment):
+    env = {"JPIGLO": nx, "JPJGLO": ny}
+    if alignment:
+        env["DL_ESM_ALIGNMENT"] = alignment
+    outs = _run_ranks("test_halos.exe", world, env)
+    assert all("Halo exchange for" in o for o in outs), outs[0][-1500:]
+
+
+@pytest.mark.parametrize("world", [4, 6])
+def test_reference_test_gsum(world):
+    outs = _run_ranks("test_gsum.exe", world, {"JPIGLO": 4, "JPJGLO": 10})
+    vals = [float(ln.split(":")[-1]) for o in outs for ln in o.splitlines() if "Global sum" in ln]
+    assert len(vals) == 4 * world and all(v == 40.0 for v in vals), vals
+
+
+@pytest.mark.parametrize("world", [4, 6])
+def test_reference_test_reduction(world):
+    outs = _run_ranks("test_reduction.exe", world, {"JPIGLO": 10, "JPJGLO": 10})
+    assert any("Field gathered correctly" in o for o in outs), outs[0][-1500:]
+    assert all("Field distributed correctly" in o for o in outs), outs[0][-1500:]

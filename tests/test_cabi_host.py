@@ -373,3 +373,29 @@ def test_periodic_halo_regions_match_reference_and_python_fields_carry_them():
         assert all(src[k].nx == dst[k].nx and src[k].ny == dst[k].ny for k in range(n.value))
         n_checked += 1
     assert n_checked >= 100
+
+
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_board_allgather_between_processes(tmp_path, n):
+    """the host-side all-gather of mailbox mode (dlesm_board_*, csrc/dlesm_rendezvous.cpp) between real processes: nine
+    operations of 0 to 100 000 bytes with the ranks out of step, one of them a gather (only the root reads), then the
+    close; every file of the session is gone afterwards.  No GPU, no RCCL."""
+    import subprocess
+    import sys
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "board_worker.py"), f"pytest-{os.getpid()}-{n}", str(r),
+                               str(n), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(n)]
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0 and f"board rank {r} ok" in out, out[-2000:]
+    assert os.listdir(tmp_path) == [], os.listdir(tmp_path)
+
+
+def test_board_refusals(tmp_path):
+    L = _cabi.lib()
+    bad = C.create_string_buffer(b"../etc", _cabi.UNIQUE_ID_BYTES)
+    assert L.dlesm_board_open(bad, 2, 0) != 0 and "letters, digits" in _cabi.last_error()
+    assert L.dlesm_board_allgather(None, 0, None) != 0 and "not open" in _cabi.last_error()
+    nonce = C.create_string_buffer(_cabi.UNIQUE_ID_BYTES)
+    _cabi.check(L.dlesm_board_nonce(nonce))
+    assert nonce.value.startswith(b"mbx-") and L.dlesm_board_is_open() == 0
