@@ -82,3 +82,28 @@ def test_reference_test_reduction(world):
     outs = _run_ranks("test_reduction.exe", world, {"JPIGLO": 10, "JPJGLO": 10})
     assert any("Field gathered correctly" in o for o in outs), outs[0][-1500:]
     assert all("Field distributed correctly" in o for o in outs), outs[0][-1500:]
+
+
+def _checksums(out):
+    vals = {}
+    for ln in out.splitlines():
+        if "checksum" in ln and "=" in ln:
+            vals[ln.split("checksum")[0].strip()] = float(ln.split("=")[-1])
+    return vals
+
+
+@pytest.mark.parametrize("fuse", [1, 4])
+def test_fortran_jacobi_app_on_four_ranks_equals_one_rank(fuse):
+    """examples/jacobi_app.f90 (this repository's GOcean-style application: grid_type, r2d_field, halo_exchange,
+    field_checksum + the PSy launch wrappers) on 4 ranks of 300 x 300 in mailbox mode against ONE rank of 600 x 600: the
+    same global domain, so the initial and the final checksum agree to the rounding of the rank-order sum.  fuse = 1:
+    the time-loop form of the distributed step (frame workgroups store into the neighbours' mailboxes); fuse = 4: four
+    time steps per launch with one depth-4 exchange over the mailboxes."""
+    exe = os.path.join(ROOT, "dl_esm_inf_amd", "fortran", "build", "jacobi_app.exe")
+    four = _run_ranks(exe, 4, {"DL_ESM_ALIGNMENT": 64}, args=(300, 24, fuse, 0))
+    one = _run_ranks(exe, 1, {"DL_ESM_ALIGNMENT": 64}, args=(600, 24, fuse, 0))
+    a, b = _checksums(four[0]), _checksums(one[0])
+    assert set(a) == set(b) == {"initial", "final"}, (four[0][-1500:], one[0][-1500:])
+    for k in a:
+        assert abs(a[k] - b[k]) <= 1e-12 * abs(b[k]), (k, a[k], b[k])
+    assert a["final"] != a["initial"]
