@@ -685,6 +685,10 @@ def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, step
             D.psy.halo_join(g, stream=stream)
         stream.synchronize()
         ok = torch.tensor([1 if torch.equal(b.data, y.data) else 0], device="cuda")
+        if os.environ.get("DLESM_BENCH_DEBUG") and not int(ok[0]):
+            dd = (b.data != y.data).nonzero()
+            print(f"[bench debug] rank {dist.get_rank()}: weak tile self-check: {dd.shape[0]} cells differ, first {dd[:8].tolist()} last "
+                  f"{dd[-4:].tolist()}; internal ({it.xstart}:{it.xstop},{it.ystart}:{it.ystop})", file=sys.stderr, flush=True)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         same = bool(int(ok[0]))
         with torch.cuda.stream(stream):
@@ -1031,14 +1035,22 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    # DLESM_TRANSPORT=mailbox: the library's mode without a communication library -- the ranks may
+    # then share a GPU (RCCL refuses that), which is how the N > 1 path of this program is rehearsed on a one-GPU box;
+    # torch's own group (barriers, the max over ranks) is gloo in that case
+    mailbox = os.environ.get("DLESM_TRANSPORT") == "mailbox"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1 or args.force_dm_leg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         with stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local))
+            if mailbox:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local))
             dist.barrier()                       # torch creates its communicator at the first collective
 
     import dl_esm_inf_amd as D
@@ -1054,7 +1066,7 @@ def main():
     os.environ["DL_ESM_ALIGNMENT"] = str(args.alignment)
     stage(rank, world, "RCCL communicator (dlesm_comm_init)")
     with stdout_to_stderr():
-        D.parallel_init(rank, world)
+        D.parallel_init(rank, world, transport="mailbox" if mailbox else None)
     stage(rank, world, "grid + fields + first halo exchange")
 
     # global domain: what go_decompose will cut into `world` tiles of tile x tile
@@ -1197,7 +1209,9 @@ def main():
                    "tile": args.tile, "decomposition": f"{P}x{Q}",
                    "global": [args.tile * P, args.tile * Q], "DL_ESM_ALIGNMENT": args.alignment,
                    "ld": grid.nx,
-                   "halo_exchange": ("rccl send/recv of the four edges, overlapped; " +
+                   "halo_exchange": (("MAILBOX MODE (DLESM_TRANSPORT=mailbox: no RCCL; the frame workgroups store into the "
+                                      "neighbours' mailboxes) -- a rehearsal when the ranks share one GPU; " if mailbox else
+                                      "rccl send/recv of the four edges, overlapped; ") +
                                      ("CONSERVATIVE form (DLESM_DM_SAFE: own frame launch, event joins) after a failed "
                                       "self-check of the one-launch forms" if dm_safe_fallback else
                                       "time-loop form (device-side join)"))
@@ -1264,7 +1278,7 @@ def main():
                 stage(rank, world, "secondary leg: distributed shallow-water step, 8192^2 per GPU")
                 out["shallow_water_dm"] = shallow_water_dm(D, torch, dist, min(WEAK_TILE, args.tile), args.alignment, world,
                                                            P, Q, stream, args.steps)
-            if not args.no_peer and not os.environ.get("DLESM_BENCH_NO_PEER"):
+            if not args.no_peer and not os.environ.get("DLESM_BENCH_NO_PEER") and not mailbox:
                 # LAST: the one leg whose transport no earlier run has exercised between GPUs
                 stage(rank, world, "secondary leg: peer transport (mailboxes) next to RCCL, 8192^2 per GPU")
                 out["peer_transport"] = peer_transport_dm(D, torch, dist, min(WEAK_TILE, args.tile), args.alignment, world,
@@ -1278,6 +1292,7 @@ def main():
             # one array read + one written, the headline's field shape, same process (two fresh arrays)
             x, y = (torch.empty((grid.ny, grid.nx), dtype=torch.float64, device="cuda") for _ in range(2))
             x.copy_(a.data)
+            torch.cuda.synchronize()                         # (the copy ran on torch's current stream, the sweeps run on `stream`)
             cc = copy_ceiling(D, torch, stream, [x], [y], grid.nx * grid.ny)
             out["roofline"]["frac_of_copy_ceiling"] = round(achieved / cc["best_gbs"], 4)
             return cc

@@ -68,6 +68,11 @@ class r2d_field:
         torch = _torch()
         # data(1:grid%nx, 1:grid%ny), zeroed (field_mod.f90:350,375); row-major (ny, nx) here
         self.data = torch.zeros((grid.ny, grid.nx), dtype=torch.float64, device="cuda")
+        # The constructor returns a ZEROED field, as the reference's does (allocation and zero fill are synchronous
+        # there): the fill above runs on torch's current stream, and a caller that goes on to use the field on another
+        # (non-blocking) stream is not ordered behind it -- seen with two ranks sharing a GPU: the fill of a 540 MB
+        # field landed after the caller's hash_init.
+        torch.cuda.current_stream().synchronize()
         self.data_on_device = True
         self.ntiles = 0
         if init_global_data is not None:                   # field_mod.f90:378-389
@@ -76,7 +81,6 @@ class r2d_field:
             if g.shape != (grid.global_ny, grid.global_nx):
                 raise _cabi.DlesmError(_cabi.EINVAL, f"init_global_data has shape {g.shape}, the domain is "
                                                      f"{(grid.global_ny, grid.global_nx)}")
-            torch.cuda.current_stream().synchronize()      # the zero fill above
             check(_cabi.lib().dlesm_scatter_inner_f64(g.ctypes.data_as(C.c_void_p), grid.global_nx, grid.global_ny,
                                                       C.byref(grid.subdomain), self.device_ptr, grid.nx, grid.ny))
 
@@ -93,6 +97,7 @@ class r2d_field:
         """field_mod.f90:546-559"""
         torch = _torch()
         self.data.copy_(torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64)))
+        torch.cuda.current_stream().synchronize()          # set_data returns with the data in place (field_mod.f90:546-559)
         return 0
 
     # -- halo exchange -----------------------------------------------------

@@ -46,6 +46,7 @@ class grid_type:
             if self.tmask is None:
                 raise _cabi.GoceanStop(_cabi.EABORT, "grid%tmask requested before grid_init")
             self._tmask_device = torch.from_numpy(self.tmask).cuda()
+            torch.cuda.current_stream().synchronize()      # in place before a kernel on another stream reads it
         return self._tmask_device
 
     @property
@@ -61,6 +62,7 @@ class grid_type:
             if not self.nx:
                 raise _cabi.GoceanStop(_cabi.EABORT, "grid%area_t requested before grid_init")
             self._area_t_device = torch.full((self.ny, self.nx), self.dx * self.dy, dtype=torch.float64, device="cuda")
+            torch.cuda.current_stream().synchronize()      # in place before a kernel on another stream reads it
         return self._area_t_device
 
     def decompose(self, domainx, domainy, ndomains=None, ndomainx=None, ndomainy=None, halo_width=1):

@@ -77,3 +77,49 @@ def test_rehearsal_of_the_multi_gpu_secondary_leg():
     assert "error" not in pt and pt["equals_stencil_plus_rccl_exchange"] is True and pt["peer"]["value"] > 0, pt
     sw = d["shallow_water_dm"]                          # the distributed shallow-water leg of the N > 1 lines
     assert sw["value"] > 0 and sw["dm_step_equals_step_plus_exchange"] is True, sw
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_bench_in_mailbox_mode(world):
+    """`bench.py --gpus N` launched as the driver launches it (one process per rank, RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_* in the environment), N = 2 and 4 on the ONE GPU of this box: DLESM_TRANSPORT=mailbox takes the library to its
+    mode without a communication library (RCCL refuses ranks that share a device), torch's group is gloo.  Every N > 1
+    code path of the program runs -- decomposition, the self-check of three distributed steps against stencil + exchange
+    on every rank, the timed time loop with its one join, max over ranks, and the secondary legs (8192^2 weak-scaling
+    tile, fused 8-step form on depth-8 halos, distributed shallow-water step) with their own checks.  The rates mean
+    nothing (the ranks share a GPU); the checks and the line's shape do."""
+    import socket
+    import torch
+    assert not torch.cuda.is_initialized(), "run this file before any in-process GPU test"
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DLESM_TRANSPORT="mailbox", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--tile", "2048",
+                                       "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}:\n{err[-3000:]}"
+    lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), outs[0][0][-2000:]
+    assert all(not o[0].strip() for o in outs[1:]), "only rank 0 prints"
+    d = json.loads(lines[0])
+    assert KEYS - {"cpu_baseline"} <= set(d) and d["n_gpus"] == world and d["scaling"] == "weak" and d["value"] > 0, d
+    assert d["dm_step_equals_stencil_plus_exchange"] is True and d["dm_safe_fallback"] is False, d
+    assert "MAILBOX MODE" in d["config"]["halo_exchange"] and d["config"]["decomposition"] in ("1x2", "2x2"), d["config"]
+    assert "secondary_legs_error" not in d, d.get("secondary_legs_error")
+    w, tb, sw = d["weak_scaling_tile"], d["temporal_blocking"], d["shallow_water_dm"]
+    assert w["n_gpus"] == world and w["dm_step_equals_stencil_plus_exchange"] is True and w["value"] > 0, w
+    assert tb["bit_identical_to_single_steps_plus_exchange"] is True, tb
+    assert sw["dm_step_equals_step_plus_exchange"] is True and sw["value"] > 0, sw
