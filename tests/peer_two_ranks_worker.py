@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 NX, NY = int(sys.argv[1]), int(sys.argv[2])
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 ALIGN = sys.argv[4] if len(sys.argv) > 4 else "64"
+MODE = sys.argv[5] if len(sys.argv) > 5 else "connect"     # "mailbox": the library's mode without a communication library
 SEED = 20261004 + 3
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 
@@ -35,7 +36,10 @@ import oracle_lib as O  # noqa: E402
 torch.cuda.set_device(0)
 L = D._cabi.lib()
 L.dlesm_set_tuning(b"dm_wait_seconds", 30)         # a protocol error must end in words, not in a hung box
-D.parallel_init(rank, world, use_rccl=False)
+if MODE == "mailbox":
+    D.parallel_init(rank, world, transport="mailbox")     # plans connect their own mailboxes (room for 3 fields)
+else:
+    D.parallel_init(rank, world, use_rccl=False)            # the host program connects them (halo_connect_peers below)
 if ALIGN == "none":
     os.environ.pop("DL_ESM_ALIGNMENT", None)
 else:
@@ -75,7 +79,7 @@ def check(fld, nsteps, what):
     return bad
 
 
-D.psy.halo_connect_peers(g)
+D.psy.halo_connect_peers(g)            # (mailbox mode: already connected when the plan was made -- a no-op)
 errors = 0
 # r2d_field%halo_exchange between the processes (no RCCL in this job: only the mailboxes can do it).  y: a WRONG field
 # everywhere, the right one on the internal region; after the exchange every halo cell that lies inside the global domain
@@ -120,6 +124,52 @@ for k in range(STEPS):
 D.psy.halo_join(g, stream=s)
 s.synchronize()
 errors += check(a, n, "time-loop form")
+if MODE == "mailbox":
+    # ---- everything else a multi-rank job needs, with no communication library underneath -------------------------
+    # (1) field_checksum: the local sums travel over the host-side board and are added in rank order
+    cs = D.field_checksum(a)
+    want_cs = float(np.abs(history[n][1:NY + 1, 1:NX + 1]).sum())
+    if abs(cs - want_cs) > 1e-11 * want_cs:
+        print(f"ERROR rank {rank}: field_checksum {cs!r}, the undivided field gives {want_cs!r}", flush=True)
+        errors += 1
+    # (2) gather_inner_data: every rank copies its block straight into the root's buffer through an IPC mapping
+    glob = a.gather_inner_data()
+    if rank == 0:
+        bad = int(np.count_nonzero(glob != history[n][1:NY + 1, 1:NX + 1]))
+        if bad:
+            print(f"ERROR rank 0: gather_inner_data: {bad} cells differ from the undivided field", flush=True)
+            errors += bad
+    # (3) the distributed shallow-water step (three fields per message, eight directions) against the oracle's step on
+    #     the undivided domain; nine fields, leapfrog rotation, the joined and the time-loop entry alternately
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    F, HG = {}, {}
+    for k, nm in enumerate(names):
+        F[nm] = D.r2d_field(g, pts[nm[0]])
+        D.psy.hash_init(F[nm], SEED + 200 + k, box=ring)
+        F[nm].data.mul_(0.01)
+        F[nm].data.add_(1.0 if nm[0] == "p" else -0.005)
+        hg = O.hash_field(SEED + 200 + k, NY + 2, NX + 2, 0, 0, 1, NX + 2, 1, NY + 2)
+        hg *= 0.01
+        hg += 1.0 if nm[0] == "p" else -0.005
+        HG[nm] = hg
+    torch.cuda.synchronize()
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 20.0)
+    cur, old, new = names[:3], names[3:6], names[6:]
+    for k in range(STEPS):
+        fn = D.psy.invoke_shallow_step_dm_pipelined if k % 2 else D.psy.invoke_shallow_step_dm
+        fn(prm, *[F[q] for q in cur + old + new], stream=s)
+        O.sw_step(prm, gld, (2, NX + 1, 2, NY + 1), *[HG[q] for q in cur + old], *[HG[q] for q in new])
+        cur, old, new = new, cur, old
+    D.psy.halo_join(g, stream=s)
+    s.synchronize()
+    for q in cur:        # the newest level: internal region + the whole halo ring (corners included: nine-point footprint)
+        got = F[q].get_data()[it.ystart - 2:it.ystop + 1, it.xstart - 2:it.xstop + 1]
+        want = HG[q][gy0 + it.ystart - 2:gy0 + it.ystop + 1, gx0 + it.xstart - 2:gx0 + it.xstop + 1]
+        bad = int(np.count_nonzero(got != want))
+        if bad:
+            print(f"ERROR rank {rank}: shallow-water step, field {q}: {bad} cells differ from the undivided oracle", flush=True)
+            errors += bad
 if L.dlesm_wait_timed_out(0):
     print(f"ERROR rank {rank}: a device-side wait gave up", flush=True)
     errors += 1
@@ -127,5 +177,6 @@ t = torch.tensor([errors])
 dist.all_reduce(t)
 dist.barrier()
 print(f"rank {rank}: tile {it.nx}x{it.ny} of {NX}x{NY}, {n} steps, errors {errors} (all ranks {int(t.item())})", flush=True)
+D.parallel_finalise()
 dist.destroy_process_group()
 sys.exit(1 if int(t.item()) else 0)

@@ -19,9 +19,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("mode", ["connect", "mailbox"])
 @pytest.mark.parametrize("nx,ny,world,steps,align", [(96, 64, 2, 6, "64"), (64, 96, 2, 5, "none"), (640, 512, 4, 8, "64"),
                                                     (2048, 4096, 2, 6, "64"), (300, 200, 6, 5, "64")])    # 6 ranks: a 2 x 3 mesh, up to five neighbours per rank
-def test_peer_transport_between_processes(nx, ny, world, steps, align):
+def test_peer_transport_between_processes(nx, ny, world, steps, align, mode):
     import torch
     assert not torch.cuda.is_initialized(), "run this file before any in-process GPU test"
     port = _free_port()
@@ -30,7 +31,7 @@ def test_peer_transport_between_processes(nx, ny, world, steps, align):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_two_ranks_worker.py"), str(nx),
-                                       str(ny), str(steps), align], env=env, stdout=subprocess.PIPE,
+                                       str(ny), str(steps), align, mode], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
