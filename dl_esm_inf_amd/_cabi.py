@@ -173,6 +173,7 @@ PROTOTYPES = {
     "dlesm_board_is_open": (_i, []),
     "dlesm_board_allgather": (_i, [_vp, C.c_size_t, _vp]),
     "dlesm_board_close": (_i, []),
+    "dlesm_board_abort": (_i, [C.c_char_p]),
     "dlesm_halo_plan_peer_export": (_i, [_vp, _i, _i, _vp]),
     "dlesm_halo_plan_peer_connect": (_i, [_vp, _i, _i, _vp]),
     "dlesm_halo_plan_peer_connect_rccl": (_i, [_vp, _i]),

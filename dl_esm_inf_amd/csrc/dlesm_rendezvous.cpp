@@ -233,11 +233,29 @@ int board_write(const std::string &name, const void *data, size_t bytes)
     return DLESM_OK;
 }
 
+// A rank that stops (parallel_abort -> dlesm_board_abort) leaves a note; the others, waiting for a file of that rank that
+// will never come, find the note and fail with its text instead of sitting out the time-out -- what MPI_Abort does for
+// the reference (parallel_utils_mod.f90:104-111), as far as a host-side board can.
+int board_aborted(char *why, size_t n)
+{
+    const std::string note = g_board.prefix + ".abort";
+    const int fd = open(note.c_str(), O_RDONLY);
+    if (fd < 0) return 0;
+    const ssize_t r = read(fd, why, n - 1);
+    close(fd);
+    why[r > 0 ? r : 0] = 0;
+    return 1;
+}
+
 int board_read(const std::string &name, void *data, size_t bytes, int timeout_ms)
 {
     struct timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (;;) {
+    for (long spin = 0;; spin++) {
+        if (spin % 64 == 63) {
+            char why[400];
+            if (board_aborted(why, sizeof why)) return fail(DLESM_EABORT, "board: another rank stopped the job: %s", why);
+        }
         const int fd = open(name.c_str(), O_RDONLY);
         if (fd >= 0) {
             size_t done = 0;
@@ -322,6 +340,15 @@ extern "C" int dlesm_board_allgather(const void *mine, size_t bytes, void *all)
         if (int rc = board_read(board_name(op, r), dst, bytes, to)) return rc;
     }
     if (op > 1) unlink(board_name(op - 1, g_board.rank).c_str());
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_board_abort(const char *msg)
+{
+    if (g_board.rank < 0) return DLESM_OK;
+    char text[400];
+    snprintf(text, sizeof text, "rank %d: %.300s", g_board.rank, msg ? msg : "");
+    (void)board_write(g_board.prefix + ".abort", text, strlen(text));
     return DLESM_OK;
 }
 

@@ -429,6 +429,11 @@ module dlesm_hip_mod
        character(kind=c_char), intent(out) :: id(*)
        integer(c_int) :: rc
      end function
+     function dlesm_board_abort(msg) bind(C, name="dlesm_board_abort") result(rc)
+       import :: c_int, c_char
+       character(kind=c_char), intent(in) :: msg(*)
+       integer(c_int) :: rc
+     end function
      function dlesm_comm_init_mailbox(id, nranks, rank0) bind(C, name="dlesm_comm_init_mailbox") result(rc)
        import :: c_int, c_char
        character(kind=c_char), intent(in) :: id(*)

@@ -214,6 +214,8 @@ contains
     flush(error_unit)
     ! do not leave this job's id file behind for the next job on the same port to trip over
     if (publishing) rc = dlesm_rendezvous_remove(c_string(rendezvous_file))
+    ! mailbox mode: tell the ranks that are waiting for this one on the board (a no-op otherwise)
+    rc = dlesm_board_abort(c_string(msg))
     error stop 1
   end subroutine parallel_abort
 

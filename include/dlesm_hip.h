@@ -477,6 +477,9 @@ int dlesm_board_open(const void *id, int nranks, int rank0);
 int dlesm_board_is_open(void);
 int dlesm_board_allgather(const void *mine, size_t bytes, void *all);
 int dlesm_board_close(void);
+/* parallel_abort in mailbox mode: leaves a note; ranks waiting on the board for this rank fail with its text (DLESM_EABORT)
+ * instead of sitting out the time-out.  The note stays (it names a dead job's session, which no other job shares). */
+int dlesm_board_abort(const char *msg);
 
 /* Message plan for fields of shape (ld, ny): device copy of the tables, pack
  * buffers for the strided (east/west) strips.  One plan serves every field of

@@ -399,3 +399,31 @@ def test_board_refusals(tmp_path):
     nonce = C.create_string_buffer(_cabi.UNIQUE_ID_BYTES)
     _cabi.check(L.dlesm_board_nonce(nonce))
     assert nonce.value.startswith(b"mbx-") and L.dlesm_board_is_open() == 0
+
+
+def test_board_abort_note_ends_the_wait(tmp_path):
+    """a rank that stops leaves a note (dlesm_board_abort, what parallel_abort calls in mailbox mode): a rank waiting for it
+    on the board fails within a moment with the note's text, not after the time-out"""
+    import subprocess
+    import sys
+    import time
+    code = (
+        "import ctypes as C, os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['DLESM_BOARD_DIR'] = %r; os.environ['DLESM_BOARD_TIMEOUT_S'] = '60'\n"
+        "from dl_esm_inf_amd import _cabi\n"
+        "L = _cabi.lib(); sid = C.create_string_buffer(b'abort-test', _cabi.UNIQUE_ID_BYTES)\n"
+        "rank = int(sys.argv[1]); _cabi.check(L.dlesm_board_open(sid, 2, rank))\n"
+        "if rank == 1:\n"
+        "    time.sleep(0.3); L.dlesm_board_abort(b'grid_init: ERROR: something fatal'); sys.exit(1)\n"
+        "t0 = time.time(); b = C.create_string_buffer(8); a = C.create_string_buffer(16)\n"
+        "rc = L.dlesm_board_allgather(b, 8, a)\n"
+        "print('rc', rc, 'waited %%.1f' %% (time.time() - t0), _cabi.last_error())\n"
+    ) % (ROOT, str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    out0, _ = procs[0].communicate(timeout=60)
+    procs[1].communicate(timeout=60)
+    assert f"rc {_cabi.EABORT}" in out0 and "rank 1: grid_init: ERROR: something fatal" in out0, out0
+    assert float(out0.split("waited")[1].split()[0]) < 10.0, out0
+
