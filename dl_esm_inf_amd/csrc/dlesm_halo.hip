@@ -696,8 +696,8 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
     for (const Msg &m : p->recvs)
         if (dir_enabled(mask, m.dir)) { any = true; any_rpack |= m.off >= 0; }
     if (!any) return DLESM_OK; // serial run, or no direction enabled: nothing to do (pcomms:1546,1557-1571)
-    if (p->peer_on && nf <= p->peer_fcap && !prepacked && !skip_unpack && !capturing(s) && tuning("dm_peer", 1) &&
-        tuning("dm_peer_exchange", 1))
+    if (p->peer_on && nf <= p->peer_fcap && !prepacked && !skip_unpack && !capturing(s) &&
+        (g_mailbox || (tuning("dm_peer", 1) && tuning("dm_peer_exchange", 1))))      // (mailbox mode has no other transport)
         return exchange_peer(p, fields, nf, mask, s);
     // (a single field on its own goes the same way: rows staged through the buffer travel faster than rows
     //  sent in place from their 8-byte-aligned position in the field -- 42 against 52 us at 8192^2)
@@ -1020,7 +1020,7 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) // single tile: one launch over the whole box
         return launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s);
-    if (p->peer_on && tuning("dm_peer", 1))      // connected mailboxes: the frame workgroups are the exchange
+    if (p->peer_on && (g_mailbox || tuning("dm_peer", 1)))      // connected mailboxes: the frame workgroups are the exchange
         return jacobi5_step_peer(p, in, out, ld, ny, xstart, xstop, ystart, ystop, s, pipelined);
     // The previous step of a pipelined sequence left its exchange in flight.  If this step can take
     // the one-launch form on the same stream, its frame workgroups wait for that exchange on the
@@ -1159,7 +1159,7 @@ extern "C" int dlesm_stencil9_step_dm(dlesm_halo_plan *p, const double *in, doub
     if (p->sends.empty() && p->recvs.empty()) return launch_stencil9(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, s);
     const bool corners = coef[0] != 0.0 || coef[2] != 0.0 || coef[6] != 0.0 || coef[8] != 0.0;
     const unsigned mask = corners ? DLESM_DIRS_ALL : (DLESM_DIRS_ALL | DLESM_DIRS_NO_DIAGONALS);
-    if (p->peer_on && tuning("dm_peer", 1) && tuning("dm_peer_exchange", 1) && !capturing(s)) {
+    if (p->peer_on && (g_mailbox || (tuning("dm_peer", 1) && tuning("dm_peer_exchange", 1))) && !capturing(s)) {
         // mailboxes: the whole box, then the two-launch exchange behind it on the same stream (7 us against an RCCL group's 42)
         if (int rc = launch_stencil9(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, s)) return rc;
         return exchange_on(p, out, mask, s);
@@ -1378,7 +1378,7 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
     };
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) return box(xstart, xstop, ystart, ystop);
-    if (p->peer_on && p->peer_fcap >= 3 && !graph && tuning("dm_peer", 1))      // mailboxes connected for three fields
+    if (p->peer_on && p->peer_fcap >= 3 && !graph && (g_mailbox || tuning("dm_peer", 1)))      // mailboxes connected for three fields
         return shallow_step_peer(p, q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew, s,
                                  smooth_alpha);
     // 1. frame: the one-cell ring of the box, one cell per thread, all four sides, its west/east columns
