@@ -682,8 +682,10 @@ static int exchange_peer(dlesm_halo_plan *p, double *const *fields, int nf, unsi
     }
     PeerStrips st{};
     if (int rc = peer_in_strips(p, mask, seq, nf, st.s, &st.n)) return rc;
-    if (int rc = launch_peer_pack(out, fields, nf, p->ld, p->peer_counter, seq, s)) return rc;
     p->peer_seq = seq;
+    if (tuning("dm_peer_one_launch", 1))       // both halves in one launch (0: a pack launch, then a wait + unpack launch)
+        return launch_peer_exchange(out, st, fields, nf, p->ld, p->peer_counter, seq, p->frame_timed_out, s);
+    if (int rc = launch_peer_pack(out, fields, nf, p->ld, p->peer_counter, seq, s)) return rc;
     return launch_peer_unpack(st, seq, fields, nf, p->ld, p->frame_timed_out, s);
 }
 

@@ -208,6 +208,10 @@ struct PeerStrips { PeerJob::In s[PeerJob::MAXM]; int n; };
 struct PeerOuts { PeerJob::Out s[PeerJob::MAXM]; int n; };
 int launch_peer_pack(const PeerOuts &out, const double *const *fields, int nf, int ld, unsigned *counter, unsigned long long seq,
                      hipStream_t s);
+// both halves of an exchange in one launch (pack half dispatched first; the unpack half waits for the neighbours only)
+struct PeerStrips;
+int launch_peer_exchange(const PeerOuts &out, const PeerStrips &in, double *const *fields, int nf, int ld, unsigned *counter,
+                         unsigned long long seq, int *timed_out, hipStream_t s);
 // nf fields: field k of a strip sits k*ni*nj doubles behind its first (the aggregated layout)
 int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *const *fields, int nf, int ld, int *timed_out,
                        hipStream_t s);

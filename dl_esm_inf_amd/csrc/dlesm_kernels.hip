@@ -513,6 +513,51 @@ __global__ __launch_bounds__(256) void peer_pack_k(PeerOuts out, PeerFields fiel
     }
 }
 
+// Both halves of an exchange in ONE launch: grid = (parts, strips, 2 x fields); the first `nf` z-slices are the pack half
+// (dispatched first), the other nf the unpack half -- which waits for the NEIGHBOURS' flags and so does not depend on this
+// launch's own pack half (nor theirs on ours): no cycle.  One launch less per exchange (7 -> 5 us from a compiled host).
+__global__ __launch_bounds__(256) void peer_exchange_k(PeerOuts out, PeerStrips in, PeerFields fields, int nf, int ld,
+                                                       unsigned *counter, unsigned long long seq, unsigned long long ticks,
+                                                       int *timed_out)
+{
+    const int k = blockIdx.z % nf;
+    if ((int)blockIdx.z < nf) {                          // ---- pack half
+        if ((int)blockIdx.y < out.n) {
+            const PeerJob::Out m = out.s[blockIdx.y];
+            const long n = (long)m.ni * m.nj;
+            const double *__restrict__ field = fields.f[k];
+            double *dst = m.dst + (long)k * n;
+            for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+                const int jj = (int)(t / m.ni), ii = (int)(t - (long)jj * m.ni);
+                __hip_atomic_store(dst + t, field[(size_t)(m.j0 + jj) * ld + (m.i0 + ii)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned total = gridDim.x * gridDim.y * nf;       // every block of the pack half reports, idle ones too
+            const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == total - 1) {
+                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int q = 0; q < out.n; q++)
+                    __hip_atomic_store(out.s[q].flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+    if ((int)blockIdx.y >= in.n) return;                 // ---- unpack half
+    const PeerJob::In m = in.s[blockIdx.y];
+    if (threadIdx.x == 0) peer_wait_flags(&m, 1, seq, ticks, timed_out);
+    __syncthreads();
+    const long n = (long)m.ni * m.nj;
+    double *__restrict__ field = fields.f[k];
+    const double *src = m.src + (long)k * n;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int jj = (int)(t / m.ni), ii = (int)(t - (long)jj * m.ni);
+        field[(size_t)(m.j0 + jj) * ld + (m.i0 + ii)] = __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 struct PeerFlagList { unsigned long long *f[PeerJob::MAXM]; };
 __global__ void peer_flags_set_k(PeerFlagList fl, int n, unsigned long long seq)
 {
@@ -1065,6 +1110,24 @@ int launch_peer_pack(const PeerOuts &out, const double *const *fields, int nf, i
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = const_cast<double *>(fields[k]);
     hipLaunchKernelGGL(peer_pack_k, dim3(parts, out.n, nf), dim3(256), 0, s, out, pf, ld, counter, seq);
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}
+
+int launch_peer_exchange(const PeerOuts &out, const PeerStrips &in, double *const *fields, int nf, int ld, unsigned *counter,
+                         unsigned long long seq, int *timed_out, hipStream_t s)
+{
+    if (out.n == 0 && in.n == 0) return DLESM_OK;
+    DLESM_REQUIRE(nf >= 1 && nf <= 16 && counter != nullptr, "peer exchange of %d fields", nf);
+    long longest = 1;
+    for (int k = 0; k < out.n; k++) longest = std::max(longest, (long)out.s[k].ni * out.s[k].nj);
+    for (int k = 0; k < in.n; k++) longest = std::max(longest, (long)in.s[k].ni * in.s[k].nj);
+    int parts = (int)((longest + 255) / 256);
+    if (parts > 16) parts = 16;
+    PeerFields pf{};
+    for (int k = 0; k < nf; k++) pf.f[k] = fields[k];
+    hipLaunchKernelGGL(peer_exchange_k, dim3(parts, std::max(out.n, in.n), 2 * nf), dim3(256), 0, s, out, in, pf, nf, ld, counter,
+                       seq, remote_wait_ticks(), timed_out);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }

@@ -201,8 +201,9 @@ def test_eight_direction_steps_and_refusals(D):
 
 @pytest.mark.parametrize("dirs,no_diag", [((), False), ((1,), False), ((1, 4), False), ((1, 2, 3), False), ((1, 2, 3, 4), False),
                                           ((1, 2, 3, 4), True), ((2, 4), True)])
-@pytest.mark.parametrize("nx,ny,alignment,nf", [(37, 23, 8, 1), (130, 6, None, 3), (700, 300, 64, 2)])
-def test_halo_exchange_over_the_mailboxes(D, nx, ny, alignment, nf, dirs, no_diag):
+@pytest.mark.parametrize("nx,ny,alignment,nf,one_launch", [(37, 23, 8, 1, 0), (130, 6, None, 3, 0), (700, 300, 64, 2, 0),
+                                                           (37, 23, 8, 1, 1), (700, 300, 64, 3, 1)])
+def test_halo_exchange_over_the_mailboxes(D, nx, ny, alignment, nf, one_launch, dirs, no_diag):
     """r2d_field%halo_exchange (exchange_generic with a choice of comm1..comm4, parallel_comms_mod.f90:1557-1571) on a
     connected plan: two small launches, no RCCL.  dm_skip_parts=1 switches the RCCL group OFF for the duration, so only
     the mailbox path can produce the oracle's halos; then the same exchange through RCCL (dm_peer_exchange=0) and through
@@ -220,6 +221,7 @@ def test_halo_exchange_over_the_mailboxes(D, nx, ny, alignment, nf, dirs, no_dia
     C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
     mask = sum(1 << (d - 1) for d in dirs) | (D._cabi.DIRS_NO_DIAGONALS if no_diag else 0)
     ptrs = (C.c_void_p * nf)(*[f.device_ptr for f in F])
+    L.dlesm_set_tuning(b"dm_peer_one_launch", one_launch)      # 1 (default): both halves of the exchange in ONE launch
     try:
         for rnd, (skip, peer_x) in enumerate(((1, 1), (0, 0), (1, 1), (1, 1))):
             for k, f in enumerate(F):
@@ -238,6 +240,7 @@ def test_halo_exchange_over_the_mailboxes(D, nx, ny, alignment, nf, dirs, no_dia
     finally:
         L.dlesm_set_tuning(b"dm_skip_parts", 0)
         L.dlesm_set_tuning(b"dm_peer_exchange", 1)
+        L.dlesm_set_tuning(b"dm_peer_one_launch", 1)
         D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 
 
