@@ -178,6 +178,8 @@ PROTOTYPES = {
     "dlesm_halo_plan_peer_connect": (_i, [_vp, _i, _i, _vp]),
     "dlesm_halo_plan_peer_connect_rccl": (_i, [_vp, _i]),
     "dlesm_halo_plan_peer_connected": (_i, [_vp]),
+    "dlesm_peer_blob_describe": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "dlesm_peer_match_describe": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, C.POINTER(_i)]),
     "dlesm_wait_timed_out": (_i, [_i]),
     "dlesm_probe_stream_concurrency": (_i, [_vp]),
     "dlesm_jacobi5_multi_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -217,6 +219,11 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+class PeerMatchDesc(C.Structure):
+    _fields_ = [("peer", _i), ("dir", _i), ("i0", _i), ("j0", _i), ("nx", _i), ("ny", _i), ("count", C.c_long), ("slot", _i),
+                ("off", C.c_long)]
 
 
 def last_error():

@@ -788,6 +788,78 @@ constexpr char PEER_MAGIC[8] = {'D', 'L', 'E', 'S', 'M', 'P', 'B', '1'};
 constexpr size_t PEER_PAYLOAD_AT = 4096;
 } // namespace
 
+// ---- the host-only part of the peer transport: which receive of which neighbour every send meets -----------------
+// dlesm_halo_plan_peer_export / _connect use exactly these two functions; dlesm_peer_match_describe runs them on bare tables
+// (no device, no mailbox) so that the matching can be checked for any mesh on a machine without a GPU.
+static void peer_blob_fill(PeerBlob &b, int my_rank, int fcap, long ragg_len, const std::vector<Msg> &recvs, const std::vector<long> &ragg)
+{
+    memset(&b, 0, sizeof b);
+    memcpy(b.magic, PEER_MAGIC, 8);
+    b.rank = my_rank;
+    b.nrecv = (int)recvs.size();
+    b.fcap = fcap;
+    b.par_len = ((long)fcap * ragg_len + 15) & ~15L;
+    b.pid = (long)getpid();
+    for (size_t m = 0; m < recvs.size(); m++) b.r[m] = PeerBlob::R{recvs[m].peer, recvs[m].dir, recvs[m].count, ragg[m]};
+}
+
+struct PeerMatch { int peer, slot; long off, par_len; };
+
+static int peer_match(const std::vector<Msg> &sends, int my_rank, int nranks, int fcap, const void *blobs, std::vector<PeerMatch> &out)
+{
+    auto blob_of = [&](int r) { PeerBlob b; memcpy(&b, (const char *)blobs + (size_t)r * DLESM_PEER_BLOB_BYTES, sizeof b); return b; };
+    out.assign(sends.size(), PeerMatch{-1, -1, 0, 0});
+    for (size_t m = 0; m < sends.size(); m++) {
+        const Msg &sm = sends[m];
+        DLESM_REQUIRE(sm.peer >= 0 && sm.peer < nranks, "send %zu goes to rank %d of %d", m, sm.peer, nranks);
+        const PeerBlob b = blob_of(sm.peer);
+        DLESM_REQUIRE(memcmp(b.magic, PEER_MAGIC, 8) == 0 && b.rank == sm.peer && b.nrecv >= 0 && b.nrecv <= 16,
+                      "peer blob of rank %d is not valid", sm.peer);
+        DLESM_REQUIRE(b.fcap == fcap, "rank %d made its mailbox for %d field(s), this rank for %d", sm.peer, b.fcap, fcap);
+        int k = 0;                                      // this is my k-th message to that neighbour ...
+        for (size_t q = 0; q < m; q++) k += sends[q].peer == sm.peer;
+        int j = -1;                                     // ... and meets its k-th receive from me
+        for (int q = 0, seen = 0; q < b.nrecv; q++)
+            if (b.r[q].peer == my_rank && seen++ == k) { j = q; break; }
+        DLESM_REQUIRE(j >= 0 && b.r[j].count == sm.count, "send %zu (to rank %d, direction %d, %ld cells) has no matching receive there",
+                      m, sm.peer, sm.dir, sm.count);
+        out[m] = PeerMatch{sm.peer, j, b.r[j].off, b.par_len};
+    }
+    return DLESM_OK;
+}
+
+// Host only (no device, no communicator): the blob a plan made from `tables` for ld x ny fields would export (without an IPC
+// handle), and, given the blobs of all ranks, the (neighbour, receive index there) every send of this rank is matched with.
+extern "C" int dlesm_peer_blob_describe(const dlesm_comm_tables *tables, int ld, int ny, int my_rank, int nfields, void *blob)
+{
+    DLESM_REQUIRE(tables != nullptr && blob != nullptr && nfields >= 1 && nfields <= 16, "bad arguments");
+    MsgLists L;
+    if (int rc = build_msg_lists(tables, ld, ny, L)) return rc;
+    DLESM_REQUIRE(L.recvs.size() <= 16 && L.sends.size() <= 16, "more than 16 messages");
+    PeerBlob b;
+    peer_blob_fill(b, my_rank, nfields, L.ragg_len, L.recvs, L.ragg);
+    memset(blob, 0, DLESM_PEER_BLOB_BYTES);
+    memcpy(blob, &b, sizeof b);
+    return DLESM_OK;
+}
+
+extern "C" int dlesm_peer_match_describe(const dlesm_comm_tables *tables, int ld, int ny, int my_rank, int nranks, int nfields,
+                                         const void *blobs, dlesm_peer_match_desc *out, int max_out, int *n_out)
+{
+    DLESM_REQUIRE(tables != nullptr && blobs != nullptr && n_out != nullptr && (out != nullptr || max_out == 0), "null pointer");
+    MsgLists L;
+    if (int rc = build_msg_lists(tables, ld, ny, L)) return rc;
+    std::vector<PeerMatch> mt;
+    if (int rc = peer_match(L.sends, my_rank, nranks, nfields, blobs, mt)) return rc;
+    *n_out = (int)mt.size();
+    DLESM_REQUIRE((int)mt.size() <= max_out || max_out == 0, "%zu sends, room for %d", mt.size(), max_out);
+    for (size_t m = 0; m < mt.size() && (int)m < max_out; m++) {
+        const Msg &sm = L.sends[m];
+        out[m] = dlesm_peer_match_desc{sm.peer, sm.dir, sm.i0 + 1, sm.j0 + 1, sm.nx, sm.ny, sm.count, mt[m].slot, mt[m].off};
+    }
+    return DLESM_OK;
+}
+
 extern "C" int dlesm_halo_plan_peer_export(dlesm_halo_plan *p, int my_rank, int nfields, void *blob)
 {
     DLESM_REQUIRE(p != nullptr && blob != nullptr, "null pointer");
@@ -819,18 +891,10 @@ extern "C" int dlesm_halo_plan_peer_export(dlesm_halo_plan *p, int my_rank, int 
     }
     DLESM_REQUIRE(nfields == p->peer_fcap, "mailbox was made for %d field(s)", p->peer_fcap);
     PeerBlob b;
-    memset(&b, 0, sizeof b);
-    memcpy(b.magic, PEER_MAGIC, 8);
-    b.rank = my_rank;
-    b.nrecv = (int)p->recvs.size();
-    b.fcap = p->peer_fcap;
-    b.par_len = p->peer_par_len;
-    b.pid = (long)getpid();
+    peer_blob_fill(b, my_rank, p->peer_fcap, p->ragg_len, p->recvs, p->ragg);
     // (a process cannot open its own handle: a rank that is its own neighbour -- loop-back -- uses the pointer)
     b.has_handle = hipIpcGetMemHandle(&b.handle, p->peer_box) == hipSuccess ? 1 : 0;
     if (!b.has_handle) (void)hipGetLastError();
-    for (size_t m = 0; m < p->recvs.size(); m++)
-        b.r[m] = PeerBlob::R{p->recvs[m].peer, p->recvs[m].dir, p->recvs[m].count, p->ragg[m]};
     memset(blob, 0, DLESM_PEER_BLOB_BYTES);
     memcpy(blob, &b, sizeof b);
     return DLESM_OK;
@@ -844,6 +908,8 @@ extern "C" int dlesm_halo_plan_peer_connect(dlesm_halo_plan *p, int my_rank, int
     DLESM_REQUIRE(my_rank >= 0 && my_rank < nranks, "rank %d of %d", my_rank, nranks);
     if (int rc = ensure_device()) return rc;
     auto blob_of = [&](int r) { PeerBlob b; memcpy(&b, (const char *)blobs + (size_t)r * DLESM_PEER_BLOB_BYTES, sizeof b); return b; };
+    std::vector<PeerMatch> mt;                            // which receive of which neighbour every send meets: host-only code,
+    if (int rc0 = peer_match(p->sends, my_rank, nranks, p->peer_fcap, blobs, mt)) return rc0;   // also behind dlesm_peer_match_describe
     std::vector<void *> base(nranks, nullptr);
     const size_t ns = p->sends.size();
     std::vector<double *> tx(ns);
@@ -852,39 +918,24 @@ extern "C" int dlesm_halo_plan_peer_connect(dlesm_halo_plan *p, int my_rank, int
     std::vector<void *> mapped;
     int rc = DLESM_OK;
     for (size_t m = 0; m < ns && !rc; m++) {
-        const Msg &sm = p->sends[m];
-        if (sm.peer < 0 || sm.peer >= nranks) { rc = fail(DLESM_EINVAL, "send %zu goes to rank %d of %d", m, sm.peer, nranks); break; }
-        const PeerBlob b = blob_of(sm.peer);
-        if (memcmp(b.magic, PEER_MAGIC, 8) != 0 || b.rank != sm.peer || b.nrecv < 0 || b.nrecv > 16) {
-            rc = fail(DLESM_EINVAL, "peer blob of rank %d is not valid", sm.peer);
-            break;
-        }
-        if (b.fcap != p->peer_fcap) { rc = fail(DLESM_EINVAL, "rank %d made its mailbox for %d field(s), this rank for %d", sm.peer, b.fcap, p->peer_fcap); break; }
-        int k = 0;                                      // this is my k-th message to that neighbour ...
-        for (size_t q = 0; q < m; q++) k += p->sends[q].peer == sm.peer;
-        int j = -1;                                     // ... and meets its k-th receive from me
-        for (int q = 0, seen = 0; q < b.nrecv; q++)
-            if (b.r[q].peer == my_rank && seen++ == k) { j = q; break; }
-        if (j < 0 || b.r[j].count != sm.count) {
-            rc = fail(DLESM_EINVAL, "send %zu (to rank %d, direction %d, %ld cells) has no matching receive there", m, sm.peer, sm.dir, sm.count);
-            break;
-        }
-        if (!base[sm.peer]) {
-            if (sm.peer == my_rank) {
-                base[sm.peer] = p->peer_box;
+        const int peer = mt[m].peer;
+        if (!base[peer]) {
+            if (peer == my_rank) {
+                base[peer] = p->peer_box;
             } else {
-                if (!b.has_handle) { rc = fail(DLESM_EHIP, "rank %d could not export its mailbox (hipIpcGetMemHandle failed there)", sm.peer); break; }
+                const PeerBlob b = blob_of(peer);
+                if (!b.has_handle) { rc = fail(DLESM_EHIP, "rank %d could not export its mailbox (hipIpcGetMemHandle failed there)", peer); break; }
                 void *ptr = nullptr;
                 const hipError_t e = hipIpcOpenMemHandle(&ptr, b.handle, hipIpcMemLazyEnablePeerAccess);
-                if (e != hipSuccess) { rc = fail(DLESM_EHIP, "hipIpcOpenMemHandle(mailbox of rank %d): %s", sm.peer, hipGetErrorString(e)); break; }
+                if (e != hipSuccess) { rc = fail(DLESM_EHIP, "hipIpcOpenMemHandle(mailbox of rank %d): %s", peer, hipGetErrorString(e)); break; }
                 mapped.push_back(ptr);
-                base[sm.peer] = ptr;
+                base[peer] = ptr;
             }
         }
-        tx[m] = (double *)((char *)base[sm.peer] + PEER_PAYLOAD_AT);
-        par[m] = b.par_len;
-        off[m] = b.r[j].off;
-        txf[m] = (unsigned long long *)base[sm.peer] + j;
+        tx[m] = (double *)((char *)base[peer] + PEER_PAYLOAD_AT);
+        par[m] = mt[m].par_len;
+        off[m] = mt[m].off;
+        txf[m] = (unsigned long long *)base[peer] + mt[m].slot;
     }
     if (rc) {
         for (void *q : mapped) (void)hipIpcCloseMemHandle(q);

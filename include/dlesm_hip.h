@@ -595,6 +595,19 @@ int dlesm_halo_plan_peer_export(dlesm_halo_plan *plan, int my_rank, int nfields,
 int dlesm_halo_plan_peer_connect(dlesm_halo_plan *plan, int my_rank, int nranks, const void *blobs);
 int dlesm_halo_plan_peer_connect_rccl(dlesm_halo_plan *plan, int nfields);
 int dlesm_halo_plan_peer_connected(const dlesm_halo_plan *plan);   /* 1 / 0 */
+/* HOST ONLY (no device, no communicator), for checking the matching on any mesh: the blob a plan made from `tables` would
+ * export (without an IPC handle), and, given the blobs of all ranks, what every SEND of this rank is matched with -- the code
+ * dlesm_halo_plan_peer_export / _connect run.  One record per send, in the plan's (peer, direction) order. */
+typedef struct dlesm_peer_match_desc {
+    int peer, dir;         /* the neighbour (0-based rank) and the direction code of the send                   */
+    int i0, j0, nx, ny;    /* the strip it reads in this rank's field (1-based origin, extent)                 */
+    long count;            /* cells per field                                                                  */
+    int slot;              /* index of the matching receive in the NEIGHBOUR's (peer, direction)-sorted list   */
+    long off;              /* its per-field offset in the neighbour's mailbox parity                           */
+} dlesm_peer_match_desc;
+int dlesm_peer_blob_describe(const dlesm_comm_tables *tables, int ld, int ny, int my_rank, int nfields, void *blob);
+int dlesm_peer_match_describe(const dlesm_comm_tables *tables, int ld, int ny, int my_rank, int nranks, int nfields,
+                              const void *blobs, dlesm_peer_match_desc *out, int max_out, int *n_out);
 
 /* Device-side waits of the distributed steps are bounded: 30 s for this GPU's own frame workgroups, and
  * dm_wait_seconds (dlesm_set_tuning; default 600, 0 = no limit, as the reference waits in MPI_Waitany,

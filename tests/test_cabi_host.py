@@ -427,3 +427,62 @@ def test_board_abort_note_ends_the_wait(tmp_path):
     assert f"rc {_cabi.EABORT}" in out0 and "rank 1: grid_init: ERROR: something fatal" in out0, out0
     assert float(out0.split("waited")[1].split()[0]) < 10.0, out0
 
+
+
+@pytest.mark.parametrize("nx,ny,nranks,depth", [(16, 32, 8, None), (10, 10, 6, None), (64, 64, 16, None), (32, 64, 8, 4), (13, 11, 9, None),
+                                                (7, 40, 5, None), (10, 4, 2, None)])
+@pytest.mark.parametrize("nf", [1, 3])
+def test_mailbox_matching_on_whole_meshes(nx, ny, nranks, depth, nf):
+    """the peer transport's matching -- which receive slot of which neighbour every send strip is stored into -- run by the
+    product's own code (dlesm_peer_blob_describe / dlesm_peer_match_describe: the functions dlesm_halo_plan_peer_export and
+    _connect call) for EVERY rank of a mesh, BASELINE configs[4]'s 2 x 4 among them, with no device.  Checked against the
+    geometry, not against the rule: the strip a send reads, shifted into the neighbour's frame of reference, must be
+    exactly the halo strip the matched receive writes there; every receive slot is matched by exactly one send; slots of
+    one mailbox do not overlap."""
+    d = D.go_decompose(nx, ny, ndomains=nranks, halo_width=depth or 1)
+    tabs, dims, blobs = [], [], b""
+    for r in range(nranks):
+        t = D.map_comms(d, rank1=r + 1, nranks=nranks, depth=depth)
+        g = d.subdomains[r].glob
+        ld, nyy = g.nx + 1 + (r % 2), g.ny + 1
+        blob = C.create_string_buffer(_cabi.PEER_BLOB_BYTES)
+        _cabi.check(L.dlesm_peer_blob_describe(C.byref(t), ld, nyy, r, nf, blob))
+        tabs.append(t), dims.append((ld, nyy))
+        blobs += blob.raw
+    allb = C.create_string_buffer(blobs, nranks * _cabi.PEER_BLOB_BYTES)
+    # the receives of every rank in the plan's own (peer, direction) order: (source rank, dir, 1-based dest strip)
+    recvs = []
+    for r in range(nranks):
+        calls = [c for c in _calls(tabs[r], *dims[r], 1, 0x1F & 0xF, 1) if c.is_recv]
+        recvs.append(calls)
+    taken = [set() for _ in range(nranks)]
+    for r in range(nranks):
+        n = C.c_int()
+        out = (_cabi.PeerMatchDesc * 16)()
+        _cabi.check(L.dlesm_peer_match_describe(C.byref(tabs[r]), *dims[r], r, nranks, nf, allb, out, 16, C.byref(n)))
+        assert n.value == tabs[r].nsend
+        for k in range(n.value):
+            m = out[k]
+            q = m.peer
+            rc = recvs[q][m.slot]                       # the receive this send is stored into
+            assert rc.peer == r and rc.count == m.count * 1 and (rc.nx, rc.ny) == (m.nx, m.ny), (r, k, q, m.slot)
+            # geometry: global coordinates of the cells sent == global coordinates of the halo cells received
+            sx = d.subdomains[r].glob.xstart - d.subdomains[r].internal.xstart      # local -> global shift of the sender
+            sy = d.subdomains[r].glob.ystart - d.subdomains[r].internal.ystart
+            qx = d.subdomains[q].glob.xstart - d.subdomains[q].internal.xstart
+            qy = d.subdomains[q].glob.ystart - d.subdomains[q].internal.ystart
+            assert (m.i0 + sx, m.j0 + sy) == (rc.i0 + qx, rc.j0 + qy), (r, k, q, (m.i0, m.j0), (rc.i0, rc.j0))
+            assert m.slot not in taken[q]
+            taken[q].add(m.slot)
+            assert m.off * nf == rc.buffer_offset * nf // 1     # the per-field slot offset the neighbour's plan reports (aggregated layout, 1 field)
+    for q in range(nranks):
+        assert taken[q] == set(range(len(recvs[q]))), (q, taken[q])
+    # a blob of the wrong rank in a slot is refused
+    if nranks > 1:
+        wrong = C.create_string_buffer(blobs[_cabi.PEER_BLOB_BYTES:2 * _cabi.PEER_BLOB_BYTES] + blobs[_cabi.PEER_BLOB_BYTES:],
+                                       nranks * _cabi.PEER_BLOB_BYTES)
+        n = C.c_int()
+        out = (_cabi.PeerMatchDesc * 16)()
+        bad = [r for r in range(nranks) if any(tabs[r].destination[k] == 0 for k in range(tabs[r].nsend))]
+        if bad:
+            assert L.dlesm_peer_match_describe(C.byref(tabs[bad[0]]), *dims[bad[0]], bad[0], nranks, nf, wrong, out, 16, C.byref(n)) != 0
