@@ -90,7 +90,9 @@ class r2d_field:
         return C.c_void_p(self.data.data_ptr())
 
     def get_data(self):
-        """host copy, shape (ny, nx) (field_mod.f90:530-542)"""
+        """host copy, shape (ny, nx) (field_mod.f90:530-542): a BLOCKING read, as the reference's read_from_device with
+        blocking = .true. -- whatever was enqueued on any stream of this process before the call is in the copy"""
+        _torch().cuda.synchronize()
         return self.data.cpu().numpy()
 
     def set_data(self, array):
