@@ -1047,6 +1047,7 @@ static int jacobi5_step_peer(dlesm_halo_plan *p, const double *in, double *out, 
     job.counter = p->peer_counter;
     job.wait_ticks = remote_wait_ticks();
     job.timed_out = p->frame_timed_out;
+    job.fenced = tuning("mailbox_fences", 0);
     bool fused = false;
     if (int rc = launch_stencil5_peer(in, out, ld, ny, xstart, xstop, ystart, ystop, job, s, &fused)) return rc;
     if (!fused) {     // arrays or box the tile kernel does not take: the frame workgroups alone, then the plain interior sweep
@@ -1365,6 +1366,7 @@ static int shallow_step_peer(dlesm_halo_plan *p, const dlesm_sw_params *q, int l
         fp.n++;
     }
     job.npeer = fp.n;
+    job.fenced = tuning("mailbox_fences", 0);
     fp.buf = p->peer_rx;                                  // (never used: every strip has its own base)
     job.counter = p->peer_counter;
     job.flag = p->frame_flag;

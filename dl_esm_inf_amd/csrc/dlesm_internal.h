@@ -194,6 +194,7 @@ struct PeerJob {
     unsigned long long seq;       // stored to every out[k].flag when the last frame workgroup is done
     unsigned long long wait_ticks;   // bound of the wait (remote_wait_ticks(); 0 = none)
     int *timed_out;
+    int fenced;                   // mailbox_fences: release store of the flags, acquire fence behind the wait (peer_raise_flag)
 };
 // frame (peer stores) + interior sweep in ONE launch; *fused = false (nothing launched) when the arrays do not qualify
 int launch_stencil5_peer(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
@@ -247,6 +248,7 @@ struct SwFrameJob {
     // raises THEIR arrival flags with `seq` instead of the local frame flag
     int npeer;
     unsigned long long *peer_flag[FramePack3::MAXS];
+    int fenced;                   // mailbox_fences (see PeerJob)
     int diag;                     // profiling only (results wrong): 1 = no frame cells, 2 = south/north rows only
 };
 // shallow-water step, register-tiled linear sweep (dlesm_shallow.hip); 0-based inclusive box

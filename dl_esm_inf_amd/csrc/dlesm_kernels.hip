@@ -425,9 +425,20 @@ __device__ __forceinline__ void peer_frame_cell(long t, const double *__restrict
     }
 }
 
+// The arrival flag of a message.  fenced = false (default): a relaxed system-scope store behind payload stores that are
+// themselves write-through system-scope stores, drained -- enough for uncached mailboxes by what the hardware does, and what the
+// loop-back / multi-process measurements are quoted for.  fenced = true (tuning mailbox_fences = 1): a system-scope RELEASE store
+// (L2 write-back first) here and an ACQUIRE fence behind the wait: the flag -> payload order is then a release / acquire pair of
+// the memory model too, at 2-5 % of a 4096^2 step (the write-back and the invalidate land in the middle of the sweep).
+__device__ __forceinline__ void peer_raise_flag(unsigned long long *flag, unsigned long long seq, bool fenced)
+{
+    if (fenced) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // bounded wait of ONE thread for n arrival flags (system scope: they are stored by other GPUs)
 __device__ __forceinline__ void peer_wait_flags(const PeerJob::In *in, int n, unsigned long long seq,
-                                                unsigned long long ticks, int *timed_out)
+                                                unsigned long long ticks, int *timed_out, bool fenced = false)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (int k = 0; k < n; k++)
@@ -438,6 +449,7 @@ __device__ __forceinline__ void peer_wait_flags(const PeerJob::In *in, int n, un
                 return;
             }
         }
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // see peer_raise_flag
 }
 
 template <int VEC, int R, int NT>
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
         return;
     }
     if (pj.wait_seq) {      // the neighbours' frames of the previous step: in steady state long since there (one load each)
-        if (threadIdx.x == 0) peer_wait_flags(pj.in, pj.nin, pj.wait_seq, pj.wait_ticks, pj.timed_out);
+        if (threadIdx.x == 0) peer_wait_flags(pj.in, pj.nin, pj.wait_seq, pj.wait_ticks, pj.timed_out, pj.fenced != 0);
         __syncthreads();
     }
     const long total = frame_cells(pj.fx1 - pj.fx0 + 1, pj.fy1 - pj.fy0 + 1);
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
         if (done == (unsigned)pj.nblocks - 1) {
             __hip_atomic_store(pj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int k = 0; k < pj.nout; k++)
-                __hip_atomic_store(pj.out[k].flag, pj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                peer_raise_flag(pj.out[k].flag, pj.seq, pj.fenced != 0);
         }
     }
 }
@@ -472,10 +484,10 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
 // of the field (ordinary stores: the readers are later launches on this stream).  grid = (parts, strips).
 struct PeerFields { double *f[16]; };
 __global__ __launch_bounds__(256) void peer_unpack_k(PeerStrips st, unsigned long long seq, PeerFields fields, int ld,
-                                                     unsigned long long ticks, int *timed_out)
+                                                     unsigned long long ticks, int *timed_out, int fenced)
 {
     const PeerJob::In m = st.s[blockIdx.y];
-    if (threadIdx.x == 0) peer_wait_flags(&m, 1, seq, ticks, timed_out);
+    if (threadIdx.x == 0) peer_wait_flags(&m, 1, seq, ticks, timed_out, fenced != 0);
     __syncthreads();
     const long n = (long)m.ni * m.nj;
     double *__restrict__ field = fields.f[blockIdx.z];
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(256) void peer_unpack_k(PeerStrips st, unsigned lon
 // jacobi5_tile_peer: system-scope write-through stores, drained, barrier, one counter increment per workgroup, the last
 // arriver raises every neighbour's flag.
 __global__ __launch_bounds__(256) void peer_pack_k(PeerOuts out, PeerFields fields, int ld, unsigned *counter,
-                                                   unsigned long long seq)
+                                                   unsigned long long seq, int fenced)
 {
     const PeerJob::Out m = out.s[blockIdx.y];
     const long n = (long)m.ni * m.nj;
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(256) void peer_pack_k(PeerOuts out, PeerFields fiel
         if (done == total - 1) {
             __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int k = 0; k < out.n; k++)
-                __hip_atomic_store(out.s[k].flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                peer_raise_flag(out.s[k].flag, seq, fenced != 0);
         }
     }
 }
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(256) void peer_pack_k(PeerOuts out, PeerFields fiel
 // launch's own pack half (nor theirs on ours): no cycle.  One launch less per exchange (7 -> 5 us from a compiled host).
 __global__ __launch_bounds__(256) void peer_exchange_k(PeerOuts out, PeerStrips in, PeerFields fields, int nf, int ld,
                                                        unsigned *counter, unsigned long long seq, unsigned long long ticks,
-                                                       int *timed_out)
+                                                       int *timed_out, int fenced)
 {
     const int k = blockIdx.z % nf;
     if ((int)blockIdx.z < nf) {                          // ---- pack half
@@ -540,14 +552,14 @@ __global__ __launch_bounds__(256) void peer_exchange_k(PeerOuts out, PeerStrips 
             if (done == total - 1) {
                 __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (int q = 0; q < out.n; q++)
-                    __hip_atomic_store(out.s[q].flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    peer_raise_flag(out.s[q].flag, seq, fenced != 0);
             }
         }
         return;
     }
     if ((int)blockIdx.y >= in.n) return;                 // ---- unpack half
     const PeerJob::In m = in.s[blockIdx.y];
-    if (threadIdx.x == 0) peer_wait_flags(&m, 1, seq, ticks, timed_out);
+    if (threadIdx.x == 0) peer_wait_flags(&m, 1, seq, ticks, timed_out, fenced != 0);
     __syncthreads();
     const long n = (long)m.ni * m.nj;
     double *__restrict__ field = fields.f[k];
@@ -559,9 +571,9 @@ __global__ __launch_bounds__(256) void peer_exchange_k(PeerOuts out, PeerStrips 
 }
 
 struct PeerFlagList { unsigned long long *f[PeerJob::MAXM]; };
-__global__ void peer_flags_set_k(PeerFlagList fl, int n, unsigned long long seq)
+__global__ void peer_flags_set_k(PeerFlagList fl, int n, unsigned long long seq, int fenced)
 {
-    if (threadIdx.x < (unsigned)n) __hip_atomic_store(fl.f[threadIdx.x], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x < (unsigned)n) peer_raise_flag(fl.f[threadIdx.x], seq, fenced != 0);
 }
 
 // LDS-staged form (j5_kernel = 2, the comparison point for "stage the tile and its halo ring in
@@ -1093,7 +1105,8 @@ int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *con
     if (parts > 16) parts = 16;
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = fields[k];
-    hipLaunchKernelGGL(peer_unpack_k, dim3(parts, st.n, nf), dim3(256), 0, s, st, seq, pf, ld, remote_wait_ticks(), timed_out);
+    hipLaunchKernelGGL(peer_unpack_k, dim3(parts, st.n, nf), dim3(256), 0, s, st, seq, pf, ld, remote_wait_ticks(), timed_out,
+                       tuning("mailbox_fences", 0));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -1109,7 +1122,7 @@ int launch_peer_pack(const PeerOuts &out, const double *const *fields, int nf, i
     if (parts > 16) parts = 16;
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = const_cast<double *>(fields[k]);
-    hipLaunchKernelGGL(peer_pack_k, dim3(parts, out.n, nf), dim3(256), 0, s, out, pf, ld, counter, seq);
+    hipLaunchKernelGGL(peer_pack_k, dim3(parts, out.n, nf), dim3(256), 0, s, out, pf, ld, counter, seq, tuning("mailbox_fences", 0));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -1127,7 +1140,7 @@ int launch_peer_exchange(const PeerOuts &out, const PeerStrips &in, double *cons
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = fields[k];
     hipLaunchKernelGGL(peer_exchange_k, dim3(parts, std::max(out.n, in.n), 2 * nf), dim3(256), 0, s, out, in, pf, nf, ld, counter,
-                       seq, remote_wait_ticks(), timed_out);
+                       seq, remote_wait_ticks(), timed_out, tuning("mailbox_fences", 0));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -1138,7 +1151,7 @@ int launch_peer_flags_set(unsigned long long *const *flags, int n, unsigned long
     DLESM_REQUIRE(n <= PeerJob::MAXM, "%d peer flags", n);
     PeerFlagList fl{};
     for (int k = 0; k < n; k++) fl.f[k] = flags[k];
-    hipLaunchKernelGGL(peer_flags_set_k, dim3(1), dim3(64), 0, s, fl, n, seq);
+    hipLaunchKernelGGL(peer_flags_set_k, dim3(1), dim3(64), 0, s, fl, n, seq, tuning("mailbox_fences", 0));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }

@@ -320,7 +320,10 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
             __hip_atomic_store(fj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (fj.npeer)         // peer transport: the neighbours' arrival flags
                 for (int k = 0; k < fj.npeer; k++)
-                    __hip_atomic_store(fj.peer_flag[k], fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    {
+                        if (fj.fenced) __hip_atomic_store(fj.peer_flag[k], fj.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        else __hip_atomic_store(fj.peer_flag[k], fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
             else
                 __hip_atomic_store(fj.flag, fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -314,3 +314,42 @@ def test_mailbox_operations_issued_on_alternating_streams(D):
     assert np.array_equal(a.get_data(), hx)
     assert L.dlesm_wait_timed_out(0) == 0
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+@pytest.mark.parametrize("nx,ny,alignment,nsteps", [(300, 41, 64, 5), (37, 29, None, 4), (1500, 700, 64, 6)])
+def test_fenced_mailboxes_change_no_bit(D, nx, ny, alignment, nsteps):
+    """mailbox_fences = 1: the arrival flags are system-scope RELEASE stores and the waits end in an ACQUIRE fence (the
+    form bench.py falls back to if the default one fails its self-check between GPUs): same bits, every entry that uses
+    the mailboxes -- time loop, joined step, the exchange in one and in two launches"""
+    import torch
+    L, g, x, y, plan, oc = _setup(D, nx, ny, alignment)
+    it = x.internal
+    L.dlesm_set_tuning(b"mailbox_fences", 1)
+    try:
+        D.psy.hash_init(x, SEED + 41)
+        want = x.get_data()
+        assert O.exchange_all([want], [g.nx], [oc]) == 0
+        for one_launch in (1, 0):                # the exchange on its own, both forms (the second one changes nothing)
+            L.dlesm_set_tuning(b"dm_peer_one_launch", one_launch)
+            D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
+            assert np.array_equal(x.get_data(), want)
+        L.dlesm_set_tuning(b"dm_peer_one_launch", 1)
+        D.copy_field(x, y)
+        torch.cuda.synchronize()
+        hx, hy = x.get_data(), y.get_data()
+        a, b = x, y
+        for k in range(nsteps):
+            fn = L.dlesm_jacobi5_step_dm if k == nsteps // 2 else L.dlesm_jacobi5_step_dm_pipelined
+            D._cabi.check(fn(plan, a.device_ptr, b.device_ptr, g.nx, g.ny, *it.box(), None))
+            a, b = b, a
+            O.jacobi5(hx, hy, g.nx, *it.box())
+            assert O.exchange_dirs([hy], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+            hx, hy = hy, hx
+        D._cabi.check(L.dlesm_halo_plan_join(plan, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(a.get_data(), hx)
+        assert L.dlesm_wait_timed_out(0) == 0
+    finally:
+        L.dlesm_set_tuning(b"mailbox_fences", 0)
+        L.dlesm_set_tuning(b"dm_peer_one_launch", 1)
+        D._cabi.check(L.dlesm_halo_plan_destroy(plan))
