@@ -107,3 +107,32 @@ def test_fortran_jacobi_app_on_four_ranks_equals_one_rank(fuse):
     for k in a:
         assert abs(a[k] - b[k]) <= 1e-12 * abs(b[k]), (k, a[k], b[k])
     assert a["final"] != a["initial"]
+
+
+def _build_c_demo(tmp_path):
+    exe = str(tmp_path / "mailbox_demo")
+    libdir = os.path.join(ROOT, "dl_esm_inf_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-D_POSIX_C_SOURCE=200809L", "-D__HIP_PLATFORM_AMD__",
+                           "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", os.path.join(ROOT, "examples", "mailbox_demo.c"),
+                           "-L" + libdir, "-ldlesm_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("nx,ny", [(600, 600), (1000, 260)])
+def test_plain_c_job_without_a_communication_library(tmp_path, nx, ny):
+    """examples/mailbox_demo.c -- plain C99 over the C ABI, nothing else in the process: the same global domain on 1, 2, 4
+    and 6 ranks (mailbox mode: session name through the file rendezvous, plans that connect their own mailboxes, the
+    time-loop form of the distributed step, global sums over the board) ends in the same checksums"""
+    exe = _build_c_demo(tmp_path)
+    got = {}
+    for world in (1, 2, 4, 6):
+        outs = _run_ranks(exe, world, {"DL_ESM_ALIGNMENT": 8}, args=(nx, ny, 24))
+        line = [ln for ln in outs[0].splitlines() if ln.startswith("G: checksum")]
+        assert len(line) == 1 and all("G: checksum" not in o for o in outs[1:]), outs[0][-1500:]
+        got[world] = [float(v) for v in line[0].split()[2:]]
+        assert f"G: ranks {world} " in outs[0] and f"mailbox {1 if world > 1 else 0}" in outs[0], outs[0][-800:]
+    for world in (2, 4, 6):
+        for a, b in zip(got[world], got[1]):
+            assert abs(a - b) <= 1e-12 * abs(b), (world, got[world], got[1])
+    assert got[1][0] != got[1][1]

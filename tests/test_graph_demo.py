@@ -68,3 +68,19 @@ def test_graph_replay_equals_stepwise_and_the_oracle(tmp_path, nx, ny, nsteps):
         a, b = b, a
     cs = O.lib().orc_checksum(a, ld, 1, nx + 2, 1, ny + 2)
     assert abs(float(g["graph"][0]) - cs) <= 1e-12 * cs
+
+
+def test_mailbox_demo_builds_and_refuses_to_run_without_a_device(tmp_path):
+    """examples/mailbox_demo.c (a multi-rank job from plain C with no communication library): strict C99 build against the
+    header; without a device it stops with the documented status (the multi-rank runs are in
+    tests/test_a_reference_programs_multirank_gpu.py)"""
+    import torch
+    exe = str(tmp_path / "mailbox_demo")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-D_POSIX_C_SOURCE=200809L", "-D__HIP_PLATFORM_AMD__",
+                           "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", os.path.join(ROOT, "examples", "mailbox_demo.c"),
+                           "-L" + LIBDIR, "-ldlesm_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + LIBDIR,
+                           "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: covered by the gpu test")
+    p = subprocess.run([exe, "64", "48", "4"], env=_env(), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "no HIP device" in p.stderr
