@@ -23,6 +23,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <string>
+
 #include "dlesm_error.h"
 #include "dlesm_hip.h"
 
@@ -205,8 +207,6 @@ extern "C" int dlesm_rendezvous_wait_acks(const char *path, int nranks, int time
 // reference.  Operation k of rank r is the file <prefix>.<k>.<r>, written whole and published with rename(2); a rank
 // has finished operation k when it has read the n files of k.  A rank writes its file of k+1 only after that, so once
 // a rank has read all files of k+1 nobody needs its file of k any more: it removes it then.  Host code only.
-#include <string>
-
 namespace {
 
 struct Board {
