@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DLESM_VERSION 300   /* round 3: entries added (the GOcean shallow kernels one by one, time_smooth, fused periodic step, plan description ...); no signature changed */
+#define DLESM_VERSION 310   /* round 3: entries added (the GOcean shallow kernels one by one, time_smooth, fused periodic step, plan description; 310: the peer transport, mailbox mode, the board); no signature changed */
 
 /* error codes */
 #define DLESM_OK 0
