@@ -170,6 +170,23 @@ if MODE == "mailbox":
         if bad:
             print(f"ERROR rank {rank}: shallow-water step, field {q}: {bad} cells differ from the undivided oracle", flush=True)
             errors += bad
+    # (4) halo_exchange_multi of SIX fields: more than a mailbox has room for (3), so the exchange goes in two turns
+    six = [F[q] for q in names[:6]]
+    for k, f in enumerate(six):
+        D.psy.hash_init(f, SEED + 400 + k, box=ring)        # a wrong field everywhere ...
+        D.psy.hash_init(f, SEED + 500 + k, box=it)          # ... the right one on the internal region
+    D.psy.halo_exchange_multi(six)
+    torch.cuda.synchronize()
+    for k, f in enumerate(six):
+        got = f.get_data()[it.ystart - 2:it.ystop + 1, it.xstart - 2:it.xstop + 1]
+        right = O.hash_field(SEED + 500 + k, NY + 2, NX + 2, 0, 0, 1, NX + 2, 1, NY + 2)
+        want = O.hash_field(SEED + 400 + k, NY + 2, NX + 2, 0, 0, 1, NX + 2, 1, NY + 2)
+        want[1:NY + 1, 1:NX + 1] = right[1:NY + 1, 1:NX + 1]
+        want = want[gy0 + it.ystart - 2:gy0 + it.ystop + 1, gx0 + it.xstart - 2:gx0 + it.xstop + 1]
+        bad = int(np.count_nonzero(got != want))
+        if bad:
+            print(f"ERROR rank {rank}: halo_exchange_multi of six fields, field {k}: {bad} cells differ", flush=True)
+            errors += bad
 if L.dlesm_wait_timed_out(0):
     print(f"ERROR rank {rank}: a device-side wait gave up", flush=True)
     errors += 1
