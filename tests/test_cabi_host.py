@@ -486,3 +486,65 @@ def test_mailbox_matching_on_whole_meshes(nx, ny, nranks, depth, nf):
         bad = [r for r in range(nranks) if any(tabs[r].destination[k] == 0 for k in range(tabs[r].nsend))]
         if bad:
             assert L.dlesm_peer_match_describe(C.byref(tabs[bad[0]]), *dims[bad[0]], bad[0], nranks, nf, wrong, out, 16, C.byref(n)) != 0
+
+
+def _mesh_or_none(nx, ny, nranks, depth=None):
+    try:
+        d = D.go_decompose(nx, ny, ndomains=nranks, halo_width=depth or 1)
+        tabs = [D.map_comms(d, rank1=r + 1, nranks=nranks, depth=depth) for r in range(nranks)]
+    except Exception:                                        # noqa: BLE001  (domains too small for that many ranks etc.)
+        return None
+    return d, tabs
+
+
+def test_mailbox_matching_on_random_meshes():
+    """the same geometric check as test_mailbox_matching_on_whole_meshes on a few hundred random (domain, rank count)
+    combinations that go_decompose / map_comms accept: 2 to 16 ranks, uneven tiles, thin domains"""
+    import random
+    rng = random.Random(20261004)
+    checked = 0
+    for _ in range(400):
+        nranks = rng.randint(2, 16)
+        nx, ny = rng.randint(2, 90), rng.randint(2, 90)
+        mesh = _mesh_or_none(nx, ny, nranks)
+        if mesh is None:
+            continue
+        d, tabs = mesh
+        if any(t.nsend > 8 or t.nrecv > 8 for t in tabs):
+            continue
+        dims, blobs = [], b""
+        ok = True
+        for r in range(nranks):
+            g = d.subdomains[r].glob
+            ld, nyy = g.nx + 1 + (r % 3), g.ny + 1
+            blob = C.create_string_buffer(_cabi.PEER_BLOB_BYTES)
+            if L.dlesm_peer_blob_describe(C.byref(tabs[r]), ld, nyy, r, 2, blob) != 0:
+                ok = False
+                break
+            dims.append((ld, nyy))
+            blobs += blob.raw
+        if not ok:
+            continue
+        allb = C.create_string_buffer(blobs, nranks * _cabi.PEER_BLOB_BYTES)
+        recvs = [[c for c in _calls(tabs[r], *dims[r], 1, 0xF, 1) if c.is_recv] for r in range(nranks)]
+        taken = [set() for _ in range(nranks)]
+        for r in range(nranks):
+            n = C.c_int()
+            out = (_cabi.PeerMatchDesc * 16)()
+            _cabi.check(L.dlesm_peer_match_describe(C.byref(tabs[r]), *dims[r], r, nranks, 2, allb, out, 16, C.byref(n)))
+            assert n.value == tabs[r].nsend
+            sx = d.subdomains[r].glob.xstart - d.subdomains[r].internal.xstart
+            sy = d.subdomains[r].glob.ystart - d.subdomains[r].internal.ystart
+            for k in range(n.value):
+                m = out[k]
+                rc = recvs[m.peer][m.slot]
+                qx = d.subdomains[m.peer].glob.xstart - d.subdomains[m.peer].internal.xstart
+                qy = d.subdomains[m.peer].glob.ystart - d.subdomains[m.peer].internal.ystart
+                assert rc.peer == r and (rc.nx, rc.ny) == (m.nx, m.ny) and (m.i0 + sx, m.j0 + sy) == (rc.i0 + qx, rc.j0 + qy), \
+                    (nx, ny, nranks, r, k)
+                assert m.slot not in taken[m.peer]
+                taken[m.peer].add(m.slot)
+        for q in range(nranks):
+            assert taken[q] == set(range(len(recvs[q]))), (nx, ny, nranks, q)
+        checked += 1
+    assert checked >= 150, checked
