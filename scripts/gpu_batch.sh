@@ -35,8 +35,8 @@ prof)
 pmc)
     rm -rf $OUT/pmc_fetch $OUT/pmc_write
     [ -f profiles/traffic.json ] && cp profiles/traffic.json $OUT/traffic.json   # records are merged by key
-    step pmcF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile > $OUT/pmc_fetch.log 2>&1
-    step pmcW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile > $OUT/pmc_write.log 2>&1
+    step pmcF 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile --no-peer > $OUT/pmc_fetch.log 2>&1
+    step pmcW 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile --no-peer > $OUT/pmc_write.log 2>&1
     python scripts/parse_rocprof.py pmc $OUT/pmc_fetch $OUT/pmc_write "16384x16384/A64" $OUT/traffic.json jacobi5_ 20 2>&1 | tail -12 ;;   # the 20 timed launches (planned shape)
 pmcx)    # HBM traffic of the fused kernel, FUSED steps per launch (default 8)
     F=${FUSED:-8}
@@ -101,8 +101,8 @@ pmcconfigs)   # fabric traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the
     for cfg in "8192 64" "4096 64" "16384 1" "4096 1"; do
         set -- $cfg
         rm -rf $OUT/pmcc_fetch $OUT/pmcc_write
-        step pmccF$1 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcc_fetch -- python3 bench.py --tile $1 --alignment $2 --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile > $OUT/pmcc_fetch.log 2>&1
-        step pmccW$1 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcc_write -- python3 bench.py --tile $1 --alignment $2 --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile > $OUT/pmcc_write.log 2>&1
+        step pmccF$1 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcc_fetch -- python3 bench.py --tile $1 --alignment $2 --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile --no-peer > $OUT/pmcc_fetch.log 2>&1
+        step pmccW$1 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcc_write -- python3 bench.py --tile $1 --alignment $2 --steps 20 --warmup 4 --no-cpu-baseline --no-temporal-blocking --no-shallow --no-configs --no-weak-tile --no-peer > $OUT/pmcc_write.log 2>&1
         python scripts/parse_rocprof.py pmc $OUT/pmcc_fetch $OUT/pmcc_write "$1x$1/A$2" $OUT/traffic.json jacobi5_ 20 2>&1 | tail -4
     done ;;
 dmprof)
