@@ -1301,8 +1301,11 @@ def main():
             if not args.no_peer and not os.environ.get("DLESM_BENCH_NO_PEER") and not mailbox:
                 # LAST: the one leg whose transport no earlier run has exercised between GPUs
                 stage(rank, world, "secondary leg: peer transport (mailboxes) next to RCCL, 8192^2 per GPU")
-                out["peer_transport"] = peer_transport_dm(D, torch, dist, min(WEAK_TILE, args.tile), args.alignment, world,
-                                                          P, Q, stream, args.steps)
+                try:                                         # an extra: what goes wrong in it is reported, not fatal
+                    out["peer_transport"] = peer_transport_dm(D, torch, dist, min(WEAK_TILE, args.tile), args.alignment,
+                                                              world, P, Q, stream, args.steps)
+                except Exception as e:                       # noqa: BLE001
+                    out["peer_transport"] = {"error": f"{type(e).__name__}: {e}"}
         except Exception as e:                               # noqa: BLE001
             dog.cancel()
             bail(f"{type(e).__name__}: {e}", 4)              # the other ranks may be stuck in a collective
