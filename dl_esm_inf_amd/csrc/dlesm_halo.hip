@@ -24,6 +24,7 @@
 // sending and on the receiving side of a message.
 #include <rccl/rccl.h>
 
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -769,6 +770,23 @@ extern "C" int dlesm_halo_exchange_f64(dlesm_halo_plan *p, double *field, unsign
     return exchange_on(p, field, dirs_mask & 0x1Fu, (hipStream_t)stream);
 }
 
+// hipIpcOpenMemHandle with patience: several ranks map the same neighbour's buffer at the same moment, and with four processes
+// on one GPU a mapping was seen to fail once in dozens of runs and succeed the next time.  Up to five attempts, 2-32 ms apart.
+static hipError_t ipc_open(void **ptr, hipIpcMemHandle_t handle)
+{
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 5; attempt++) {
+        e = hipIpcOpenMemHandle(ptr, handle, hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+        fprintf(stderr, "dlesm: hipIpcOpenMemHandle attempt %d failed (%s)%s\n", attempt + 1, hipGetErrorString(e),
+                attempt < 4 ? ", trying again" : "");
+        const struct timespec nap = {0, (2L << attempt) * 1000 * 1000};
+        nanosleep(&nap, nullptr);
+    }
+    return e;
+}
+
 // ---- peer transport ------------------------------------------------------------------------------------------------
 // What one rank tells the others (dlesm_halo_plan_peer_export), DLESM_PEER_BLOB_BYTES per rank, all-gathered by the host
 // program or by dlesm_halo_plan_peer_connect_rccl: where its mailbox is (an IPC handle) and which slot and flag each of
@@ -926,7 +944,7 @@ extern "C" int dlesm_halo_plan_peer_connect(dlesm_halo_plan *p, int my_rank, int
                 const PeerBlob b = blob_of(peer);
                 if (!b.has_handle) { rc = fail(DLESM_EHIP, "rank %d could not export its mailbox (hipIpcGetMemHandle failed there)", peer); break; }
                 void *ptr = nullptr;
-                const hipError_t e = hipIpcOpenMemHandle(&ptr, b.handle, hipIpcMemLazyEnablePeerAccess);
+                const hipError_t e = ipc_open(&ptr, b.handle);
                 if (e != hipSuccess) { rc = fail(DLESM_EHIP, "hipIpcOpenMemHandle(mailbox of rank %d): %s", peer, hipGetErrorString(e)); break; }
                 mapped.push_back(ptr);
                 base[peer] = ptr;
@@ -1615,27 +1633,33 @@ static int gather_mailbox(const double *send, double *recv, int n)
     }
     std::vector<Note> notes(g_size);
     if (int rc = dlesm_board_allgather(&mine, sizeof mine, notes.data())) return rc;
-    int rc = DLESM_OK;
     if (n > 0 && notes[0].ok) {
+        char why[256] = "";
         if (g_rank == 0) {
-            if (hipMemcpy(recv, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = fail(DLESM_EHIP, "gather: local copy failed");
+            const hipError_t e = hipMemcpy(recv, send, bytes, hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) snprintf(why, sizeof why, "local copy: %s", hipGetErrorString(e));
         } else {
             void *rootbuf = nullptr;
-            if (hipIpcOpenMemHandle(&rootbuf, notes[0].h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
-                rc = fail(DLESM_EHIP, "gather: cannot map the root's receive buffer");
+            hipError_t e = ipc_open(&rootbuf, notes[0].h);
+            if (e != hipSuccess) {
+                snprintf(why, sizeof why, "hipIpcOpenMemHandle of the root's receive buffer: %s", hipGetErrorString(e));
             } else {
-                if (hipMemcpy((char *)rootbuf + notes[0].off + (size_t)g_rank * bytes, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess ||
-                    hipDeviceSynchronize() != hipSuccess)
-                    rc = fail(DLESM_EHIP, "gather: copy into the root's receive buffer failed");
+                e = hipMemcpy((char *)rootbuf + notes[0].off + (size_t)g_rank * bytes, send, bytes, hipMemcpyDeviceToDevice);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                if (e != hipSuccess) snprintf(why, sizeof why, "copy into the root's receive buffer: %s", hipGetErrorString(e));
                 (void)hipIpcCloseMemHandle(rootbuf);
             }
+            if (why[0]) (void)hipGetLastError();
         }
-        char done = rc ? 1 : 0;
+        char failed = why[0] ? 1 : 0;
         std::vector<char> every(g_size);
-        if (int rc2 = dlesm_board_allgather(&done, 1, every.data())) return rc2;       // all blocks have landed (or not)
-        for (int r = 0; r < g_size && !rc; r++)
-            if (every[r]) rc = fail(DLESM_EHIP, "gather: rank %d could not deliver its block", r);
-        return rc;
+        if (int rc2 = dlesm_board_allgather(&failed, 1, every.data())) return rc2;      // all blocks have landed (or not)
+        bool any = false;
+        for (int r = 0; r < g_size; r++) any |= every[r] != 0;
+        if (!any) return DLESM_OK;
+        // some rank could not use the mapping (seen once in dozens of runs with four processes on one GPU): every rank
+        // sees the same verdict, so all of them take the route through host memory below -- slower, same result
+        if (why[0]) fprintf(stderr, "dlesm gather: rank %d falls back to host memory (%s)\n", g_rank, why);
     }
     // through host memory
     std::vector<double> block((size_t)n), all;
