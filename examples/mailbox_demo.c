@@ -53,10 +53,11 @@ int main(int argc, char **argv)
 
     /* the session name: made by rank 0, handed round like an RCCL id */
     if (world > 1) {
-        char path[256], token[64];
+        char path[256], token[100];
         unsigned char id[DLESM_UNIQUE_ID_BYTES];
         snprintf(path, sizeof path, "/dev/shm/dlesm_mailbox_demo_%d", env_int("MASTER_PORT", 29700));
-        snprintf(token, sizeof token, "%d:mailbox-demo", world);
+        const char *job = getenv("DLESM_JOB_ID");                /* a launcher's run id keeps a dead job's record out */
+        snprintf(token, sizeof token, "%d:mailbox-demo:%.40s", world, job ? job : "-");
         if (rank == 0) {
             CHECK(dlesm_rendezvous_remove(path));
             CHECK(dlesm_board_nonce(id));

@@ -15,6 +15,7 @@ children."""
 import os
 import socket
 import subprocess
+import time
 
 import pytest
 
@@ -37,10 +38,12 @@ def _run_ranks(exe, world, env_extra, args=()):
     if not os.path.exists(path):
         pytest.skip(f"{path} not built (make -C oracle dropin, in a container that has /root/reference)")
     port = _free_port()
+    # a job token no earlier run can have used: a record left under the same port by a finished job is then never taken for ours
+    job = f"pytest-{port}-{os.getpid()}-{time.time_ns()}"
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), DLESM_TRANSPORT="mailbox", DLESM_JOB_ID=f"pytest-{port}",
+                   MASTER_PORT=str(port), DLESM_TRANSPORT="mailbox", DLESM_JOB_ID=job,
                    DLESM_BOARD_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
         env.pop("DL_ESM_ALIGNMENT", None)
         env.update({k: str(v) for k, v in env_extra.items()})
