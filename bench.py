@@ -1286,6 +1286,7 @@ def main():
         dog = threading.Timer(180.0, bail, args=("secondary legs did not finish in 180 s", 3))
         dog.daemon = True
         dog.start()
+        legs_t0 = time.perf_counter()
         try:
             if not args.no_weak_tile and args.tile != WEAK_TILE:
                 stage(rank, world, "secondary leg: 8192^2 weak-scaling tile")
@@ -1298,7 +1299,12 @@ def main():
                 stage(rank, world, "secondary leg: distributed shallow-water step, 8192^2 per GPU")
                 out["shallow_water_dm"] = shallow_water_dm(D, torch, dist, min(WEAK_TILE, args.tile), args.alignment, world,
                                                            P, Q, stream, args.steps)
-            if not args.no_peer and not os.environ.get("DLESM_BENCH_NO_PEER") and not mailbox:
+            spent = torch.tensor([time.perf_counter() - legs_t0], dtype=torch.float64, device="cuda")
+            if world > 1:
+                dist.all_reduce(spent, op=dist.ReduceOp.MAX)     # (every rank takes the same decision)
+            if not args.no_peer and not os.environ.get("DLESM_BENCH_NO_PEER") and not mailbox and float(spent[0]) > 100.0:
+                out["peer_transport"] = {"skipped": f"the other secondary legs took {float(spent[0]):.0f} s of the 180 s they share"}
+            elif not args.no_peer and not os.environ.get("DLESM_BENCH_NO_PEER") and not mailbox:
                 # LAST: the one leg whose transport no earlier run has exercised between GPUs
                 stage(rank, world, "secondary leg: peer transport (mailboxes) next to RCCL, 8192^2 per GPU")
                 try:                                         # an extra: what goes wrong in it is reported, not fatal
