@@ -227,6 +227,8 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
 
 // block shape (waves per workgroup, padded tiles per row) of a linear tile sweep
 void choose_block_shape(int *nxw_io, int *tpb_out, int prefer = 0);
+// the same for a sweep with the Jacobi tile geometry over the 0-based box: the planned Jacobi shape of that (ld, box) if there is one
+void shape_for_tile_sweep(int ld, int x0, int x1, int y0, int y1, int *nxw_io, int *tpb_out);
 int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart, int ystop, int ring);
 // the shallow-water frame as the first workgroups of the interior launch (shallow_tile_framed)
 struct SwFrameJob {

@@ -806,6 +806,24 @@ __global__ __launch_bounds__(256) void jacobi5_frame(const double *__restrict__ 
         frame_cell<false>(t, in, out, ld, x0, x1, y0, y1, pk);
 }
 
+// The other two-row wave-tile sweeps (3 x 3, masked, continuity) have the Jacobi sweep's tile geometry, and what decides the
+// launch shape is the geometry (which XCD the tile below lands on), not the arithmetic: a shape the planning call
+// (dlesm_stencil5_autotune_f64) measured for this (pitch, box) serves them too -- +1.7 / +2.5 points for the 3 x 3 / masked
+// sweeps at 16384^2, nothing lost elsewhere (scripts/shape_share_probe.py); without a plan, the rule.
+void shape_for_tile_sweep(int ld, int x0, int x1, int y0, int y1, int *nxw_io, int *tpb_out)
+{
+    if (tuning("j5_autoshape", 1) && tuning("j5_use_tuned", 1) && tuning("j5_share_plan", 1) && !tuning("j5_tpb", 0)) {
+        std::lock_guard<std::mutex> lk(g_shape_mu);
+        auto it = g_shape_cache.find(ShapeKey{ld, x0, x1, y0, y1, 2});
+        if (it != g_shape_cache.end() && it->second.nxw >= *nxw_io) {
+            *nxw_io = it->second.nxw;
+            *tpb_out = it->second.tpb;
+            return;
+        }
+    }
+    choose_block_shape(nxw_io, tpb_out);
+}
+
 int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
               int ring)
 {

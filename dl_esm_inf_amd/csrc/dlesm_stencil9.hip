@@ -234,7 +234,7 @@ int launch_stencil9(const double *in, double *out, const double *coef, int ld, i
     if (tile) {
         const int c_first = (x0 / 2) & ~7, c_last = x1 / 2;  // tiles anchored on 128-byte lines of the row
         int nxw = (c_last - c_first + 64) / 64, tpb = 4;
-        choose_block_shape(&nxw, &tpb);
+        shape_for_tile_sweep(ld, x0, x1, y0, y1, &nxw, &tpb);
         const int strips = (y1 - y0 + R) / R;
         const unsigned grid = (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
         if (nt_stores_for(ld, y0, y1))
