@@ -48,7 +48,15 @@ def timed(name, fn, bytes_per_cell, n=30):
     print(f"{name:46s} {ms:8.4f} ms  {gbs:7.0f} GB/s  ({gbs / 80:.1f}% of 8 TB/s; {bytes_per_cell} B/cell)", flush=True)
 
 
-timed("jacobi5 (reference point)", lambda: D.psy.invoke_jacobi5(b, a, stream=s), 16)
+timed("jacobi5 (reference point; launch shape by rule)", lambda: D.psy.invoke_jacobi5(b, a, stream=s), 16)
+if "--no-plan" not in sys.argv:
+    # the optional planning call of an application (plan_jacobi5): the shape it measures for this geometry also serves the
+    # 3x3, masked and continuity sweeps below (shape_for_tile_sweep)
+    with torch.cuda.stream(s):
+        D.psy.autotune_jacobi5(b, a, stream=s)
+        D.copy_field(a, b, stream=s)
+    s.synchronize()
+    timed("jacobi5, planned shape", lambda: D.psy.invoke_jacobi5(b, a, stream=s), 16)
 timed("stencil9 (general 3x3 weights)", lambda: D.psy.invoke_stencil9(b, a, [0.0625, 0.125, 0.0625, 0.125, 0.25, 0.125,
                                                                                   0.0625, 0.125, 0.0625], stream=s), 16)
 timed("jacobi5 masked, all-wet mask", lambda: D.psy.invoke_jacobi5_masked(b, a, stream=s), 20)
