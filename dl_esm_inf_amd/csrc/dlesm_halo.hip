@@ -1066,6 +1066,11 @@ static int jacobi5_step_peer(dlesm_halo_plan *p, const double *in, double *out, 
     job.wait_ticks = remote_wait_ticks();
     job.timed_out = p->frame_timed_out;
     job.fenced = tuning("mailbox_fences", 0);
+    // joined form: the join rides in the same launch (a few workgroups that wait for this step's strips and copy them into
+    // out's halos) -- dm_peer_join_fused = 0: the separate wait + unpack launch behind the step
+    const bool join_inside = !pipelined && tuning("dm_peer_join_fused", 1);
+    if (join_inside)
+        if (int rc = peer_in_strips(p, mask, seq, 1, job.un, &job.nun)) return rc;
     bool fused = false;
     if (int rc = launch_stencil5_peer(in, out, ld, ny, xstart, xstop, ystart, ystop, job, s, &fused)) return rc;
     if (!fused) {     // arrays or box the tile kernel does not take: the frame workgroups alone, then the plain interior sweep
@@ -1073,6 +1078,7 @@ static int jacobi5_step_peer(dlesm_halo_plan *p, const double *in, double *out, 
         if (int rc = launch_stencil5(in, out, ld, ny, xstart + 1, xstop - 1, ystart + 1, ystop - 1, s)) return rc;
     }
     p->peer_seq = seq;
+    if (fused && join_inside && job.nun > 0) return DLESM_OK;       // joined already: nothing pending
     p->peer_pending = true;
     p->pending_field = out;
     p->pending_mask = mask;
@@ -1390,6 +1396,11 @@ static int shallow_step_peer(dlesm_halo_plan *p, const dlesm_sw_params *q, int l
     job.flag = p->frame_flag;
     job.seq = seq;
     job.timed_out = p->frame_timed_out;
+    job.halo_wait_ticks = remote_wait_ticks();
+    // the join inside the launch: a few workgroups wait for this step's strips and copy them into the halos of the new fields
+    const bool join_inside = tuning("dm_peer_join_fused", 1) != 0;
+    if (join_inside)
+        if (int rc = peer_in_strips(p, DLESM_DIRS_ALL, seq, 3, job.un, &job.nun)) return rc;
     bool fused = false;
     if (fp.n && tuning("sw_dm_fused", 1))
         if (int rc = launch_shallow_framed(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew,
@@ -1413,6 +1424,7 @@ static int shallow_step_peer(dlesm_halo_plan *p, const dlesm_sw_params *q, int l
         }
     }
     p->peer_seq = seq;
+    if (fused && join_inside && job.nun > 0) return DLESM_OK;        // joined inside the launch
     PeerStrips st{};
     if (int rc = peer_in_strips(p, DLESM_DIRS_ALL, seq, 3, st.s, &st.n)) return rc;
     double *fields[3] = {unew, vnew, pnew};

@@ -195,6 +195,11 @@ struct PeerJob {
     unsigned long long wait_ticks;   // bound of the wait (remote_wait_ticks(); 0 = none)
     int *timed_out;
     int fenced;                   // mailbox_fences: release store of the flags, acquire fence behind the wait (peer_raise_flag)
+    // joined form in ONE launch: `nunb` workgroups behind the frame workgroups wait for THIS step's arrival flags and copy the
+    // received strips (un[], parity of this step) into the halo cells of `out` -- the join without a second launch.  They
+    // depend on the NEIGHBOURS' frame workgroups only (dispatched first in their launches, as ours are in this one).
+    In un[MAXM];
+    int nun, nunb;                // strips, workgroups (a multiple of 8, so that the tile workgroups keep their XCD); 0: none
 };
 // frame (peer stores) + interior sweep in ONE launch; *fused = false (nothing launched) when the arrays do not qualify
 int launch_stencil5_peer(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
@@ -251,6 +256,10 @@ struct SwFrameJob {
     int npeer;
     unsigned long long *peer_flag[FramePack3::MAXS];
     int fenced;                   // mailbox_fences (see PeerJob)
+    // ... and the join inside the launch (as PeerJob::un): `nunb` workgroups behind the ring workgroups wait for THIS step's
+    // arrival flags and copy the received strips -- three fields per message -- into the halos of unew, vnew, pnew
+    PeerJob::In un[PeerJob::MAXM];
+    int nun, nunb;
     int diag;                     // profiling only (results wrong): 1 = no frame cells, 2 = south/north rows only
 };
 // shallow-water step, register-tiled linear sweep (dlesm_shallow.hip); 0-based inclusive box

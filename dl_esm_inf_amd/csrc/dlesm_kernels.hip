@@ -457,8 +457,23 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
                                                          int x0, int x1, int y0, int y1, int c_first, int nxw, int flags,
                                                          PeerJob pj)
 {
-    if (blockIdx.x >= (unsigned)pj.nblocks) {
-        jacobi5_tile_body<VEC, R, NT>(in, out, ld, x0, x1, y0, y1, c_first, nxw, flags, blockIdx.x - pj.nblocks);
+    if (blockIdx.x >= (unsigned)(pj.nblocks + pj.nunb)) {
+        jacobi5_tile_body<VEC, R, NT>(in, out, ld, x0, x1, y0, y1, c_first, nxw, flags, blockIdx.x - pj.nblocks - pj.nunb);
+        return;
+    }
+    if (blockIdx.x >= (unsigned)pj.nblocks) {      // the join inside the launch: wait for this step's strips, copy them into out's halos
+        const int b = blockIdx.x - pj.nblocks;
+        for (int k = b % pj.nun, part = b / pj.nun; k < pj.nun; k += pj.nunb) {      // (nunb >= nun: one strip per group, several groups per strip)
+            const PeerJob::In m = pj.un[k];
+            const int parts = (pj.nunb - k + pj.nun - 1) / pj.nun;                  // groups that share strip k
+            if (threadIdx.x == 0) peer_wait_flags(&m, 1, pj.seq, pj.wait_ticks, pj.timed_out, pj.fenced != 0);
+            __syncthreads();
+            const long n = (long)m.ni * m.nj;
+            for (long t = (long)part * blockDim.x + threadIdx.x; t < n; t += (long)parts * blockDim.x) {
+                const int jj = (int)(t / m.ni), ii = (int)(t - (long)jj * m.ni);
+                out[(size_t)(m.j0 + jj) * ld + (m.i0 + ii)] = __hip_atomic_load(m.src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         return;
     }
     if (pj.wait_seq) {      // the neighbours' frames of the previous step: in steady state long since there (one load each)
@@ -740,11 +755,12 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
             const long cells = 2L * (pj->fx1 - pj->fx0 + 1) + 2L * (pj->fy1 - pj->fy0 + 1);
             long nb = ((cells + 64 * tpb - 1) / (64 * tpb) + 7) & ~7L;
             pj->nblocks = (int)(nb < 8 ? 8 : nb > 256 ? 256 : nb);
+            pj->nunb = pj->nun > 0 ? 16 : 0;             // join workgroups: two per strip at eight strips, a multiple of 8
             if (nts)
-                hipLaunchKernelGGL((jacobi5_tile_peer<2, 2, 2>), dim3(grid + pj->nblocks), dim3(64 * tpb), 0, s, in, out, ld,
+                hipLaunchKernelGGL((jacobi5_tile_peer<2, 2, 2>), dim3(grid + pj->nblocks + pj->nunb), dim3(64 * tpb), 0, s, in, out, ld,
                                    x0, x1, y0, y1, c_first, nxw, flags, *pj);
             else
-                hipLaunchKernelGGL((jacobi5_tile_peer<2, 2, 0>), dim3(grid + pj->nblocks), dim3(64 * tpb), 0, s, in, out, ld,
+                hipLaunchKernelGGL((jacobi5_tile_peer<2, 2, 0>), dim3(grid + pj->nblocks + pj->nunb), dim3(64 * tpb), 0, s, in, out, ld,
                                    x0, x1, y0, y1, c_first, nxw, flags, *pj);
         }
         return;
@@ -1106,6 +1122,7 @@ int launch_stencil5_peer_frame(const double *in, double *out, int ld, int ny, in
     const long cells = 2L * (xstop - xstart + 1) + 2L * (ystop - ystart + 1);
     long nb = (cells + 255) / 256;
     job.nblocks = (int)(nb < 1 ? 1 : nb > 256 ? 256 : nb);
+    job.nun = job.nunb = 0;                               // (the join of this form is the separate launch)
     // the frame workgroups of the one-launch kernel with no tile workgroup behind them
     hipLaunchKernelGGL((jacobi5_tile_peer<2, 2, 0>), dim3(job.nblocks), dim3(256), 0, s, in, out, ld, 0, 0, 0, 0, 0, 1, 0, job);
     DLESM_HIP_TRY(hipGetLastError());

@@ -259,11 +259,37 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
     typename OldLevel<SM>::ptr uold, typename OldLevel<SM>::ptr vold, typename OldLevel<SM>::ptr pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, SwFrameJob fj)
 {
+    if (blockIdx.x >= (unsigned)fj.nblocks && blockIdx.x < (unsigned)(fj.nblocks + fj.nunb)) {
+        // the join inside the launch (peer transport): wait for this step's strips, copy the three fields into the halos
+        const int b = blockIdx.x - fj.nblocks, k = b % fj.nun, part = b / fj.nun, parts = (fj.nunb - k + fj.nun - 1) / fj.nun;
+        const PeerJob::In m = fj.un[k];
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(m.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < fj.seq) {
+                __builtin_amdgcn_s_sleep(32);
+                if (fj.halo_wait_ticks && __builtin_amdgcn_s_memrealtime() - t0 > fj.halo_wait_ticks) {
+                    __hip_atomic_store(fj.timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+            if (fj.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        }
+        __syncthreads();
+        const long n = (long)m.ni * m.nj;
+        double *const dst[3] = {unew, vnew, pnew};
+        for (long t = (long)part * blockDim.x + threadIdx.x; t < 3 * n; t += (long)parts * blockDim.x) {
+            const int f = (int)(t / n);
+            const long e = t - (long)f * n;
+            const int jj = (int)(e / m.ni), ii = (int)(e - (long)jj * m.ni);
+            dst[f][(size_t)(m.j0 + jj) * ld + (m.i0 + ii)] = __hip_atomic_load(m.src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     if (blockIdx.x >= (unsigned)fj.nblocks) {
         const SwSmooth sm = fj.smooth ? SwSmooth{fj.alpha, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold)}
                                       : SwSmooth{0.0, nullptr, nullptr, nullptr};
         shallow_tile_body<R, DPP, NTM, SM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew,
-                                           blockIdx.x - fj.nblocks, 1, sm);
+                                           blockIdx.x - fj.nblocks - fj.nunb, 1, sm);
         return;
     }
     auto put = [](double *ptr, double val) { __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -580,7 +606,8 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
         const long cells = 2L * (fj->fx1 - fj->fx0 + 1) + 2L * (fj->fy1 - fj->fy0 + 1);
         long nb = ((cells + 64 * tpb - 1) / (64 * tpb) + 7) & ~7L;    // a multiple of 8: tile groups keep their XCD
         fj->nblocks = (int)(nb < 8 ? 8 : nb > 512 ? 512 : nb);
-        const unsigned g2 = grid + (unsigned)fj->nblocks;
+        fj->nunb = fj->nun > 0 ? 16 : 0;                 // join workgroups of the peer transport (a multiple of 8)
+        const unsigned g2 = grid + (unsigned)fj->nblocks + (unsigned)fj->nunb;
 #define DLESM_SWF(NN, SS) hipLaunchKernelGGL((shallow_tile_framed<2, true, NN, SS>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj)
         if (sm.uo) {
             switch (ntm & 3) {

@@ -66,12 +66,15 @@ def _setup(D, nx, ny, alignment, connect="rccl"):
 
 @pytest.mark.parametrize("nx,ny,alignment", [(300, 41, 64), (64, 64, 2), (1500, 700, 64), (130, 5, 2), (37, 29, None),
                                              (3, 3, 64), (8, 3, None), (2048, 2048, 64), (2049, 1031, None)])
-@pytest.mark.parametrize("connect", ["rccl", "host"])
-def test_joined_steps_over_the_mailboxes(D, nx, ny, alignment, connect):
+@pytest.mark.parametrize("connect,join_inside", [("rccl", 1), ("host", 1), ("host", 0)])
+def test_joined_steps_over_the_mailboxes(D, nx, ny, alignment, connect, join_inside):
     """dlesm_jacobi5_step_dm on a connected plan: after every step the output (edge halos included) equals the oracle's
-    stencil + edge exchange; odd leading dimensions and boxes without an interior take the frame-only launch"""
+    stencil + edge exchange; odd leading dimensions and boxes without an interior take the frame-only launch.
+    join_inside (dm_peer_join_fused, default 1): the join rides in the step's launch (a few workgroups behind the frame
+    workgroups wait for this step's strips and copy them into the halos); 0: the separate wait + unpack launch"""
     import torch
     L, g, x, y, plan, oc = _setup(D, nx, ny, alignment, connect)
+    L.dlesm_set_tuning(b"dm_peer_join_fused", join_inside)
     it = x.internal
     D.psy.hash_init(x, SEED + 31)
     D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, None))
@@ -84,6 +87,7 @@ def test_joined_steps_over_the_mailboxes(D, nx, ny, alignment, connect):
         torch.cuda.synchronize()
         assert np.array_equal(y.get_data(), want)
         x, y = y, x
+    L.dlesm_set_tuning(b"dm_peer_join_fused", 1)
     assert L.dlesm_wait_timed_out(0) == 0
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
 

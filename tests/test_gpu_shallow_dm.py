@@ -29,7 +29,7 @@ def D():
 @pytest.mark.parametrize("nx,ny,alignment", [(1, 1, 2), (2, 3, 2), (5, 1, 2), (1, 7, 2), (40, 33, 8), (257, 66, 64),
                                              (130, 9, None), (700, 300, 64)])
 @pytest.mark.parametrize("one_launch_frame,fused,aggregate,peer", [(1, 1, 1, 0), (1, 0, 1, 0), (0, 0, 1, 0), (1, 1, 0, 0),
-                                                                   (0, 0, 0, 0), (1, 1, 1, 1), (1, 0, 1, 1)])
+                                                                   (0, 0, 0, 0), (1, 1, 1, 1), (1, 0, 1, 1), (1, 1, 1, 2)])
 def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, fused, aggregate, peer):
     """peer=1: the plan connected to the mailboxes for three fields -- the ring workgroups store into the
     neighbour's mailbox, no RCCL kernel in the step (fused=0: the ring in its own launch, its flags behind it).  fused: the ring as the first workgroups of the interior launch + device flag (default) /
@@ -42,6 +42,7 @@ def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, 
     L.dlesm_set_tuning(b"sw_dm_frame", one_launch_frame)
     L.dlesm_set_tuning(b"sw_dm_fused", fused)
     L.dlesm_set_tuning(b"dm_aggregate", aggregate)
+    L.dlesm_set_tuning(b"dm_peer_join_fused", 0 if peer == 2 else 1)    # peer=2: the join as its own wait + unpack launch
     if alignment is None:
         os.environ.pop("DL_ESM_ALIGNMENT", None)
     else:
@@ -98,11 +99,12 @@ def test_shallow_step_dm_matches_oracle(D, nx, ny, alignment, one_launch_frame, 
     L.dlesm_set_tuning(b"sw_dm_frame", 1)
     L.dlesm_set_tuning(b"sw_dm_fused", 1)
     L.dlesm_set_tuning(b"dm_aggregate", 1)
+    L.dlesm_set_tuning(b"dm_peer_join_fused", 1)
 
 
 @pytest.mark.parametrize("nx,ny,alignment,nsteps", [(40, 33, 8, 7), (257, 66, 64, 5), (130, 9, None, 6), (700, 300, 64, 9),
                                                     (2, 3, 2, 4)])
-@pytest.mark.parametrize("chain,peer", [(1, 0), (0, 0), (1, 1)])
+@pytest.mark.parametrize("chain,peer", [(1, 0), (0, 0), (1, 1), (1, 2)])
 def test_pipelined_shallow_time_loop(D, nx, ny, alignment, nsteps, chain, peer):
     """peer=1: the same loop over the mailboxes (plan connected for three fields).  a leapfrog time loop of dlesm_shallow_step_dm_pipelined (three time levels rotated by pointer,
     the exchange of step k joined on the device by step k+1's frame workgroups, one join at the end)
@@ -112,6 +114,7 @@ def test_pipelined_shallow_time_loop(D, nx, ny, alignment, nsteps, chain, peer):
     from dm_overhead import loopback_tables
     L = D._cabi.lib()
     L.dlesm_set_tuning(b"sw_dm_chain", chain)
+    L.dlesm_set_tuning(b"dm_peer_join_fused", 0 if peer == 2 else 1)    # peer=2: separate wait + unpack launch behind each step
     if alignment is None:
         os.environ.pop("DL_ESM_ALIGNMENT", None)
     else:
@@ -162,6 +165,7 @@ def test_pipelined_shallow_time_loop(D, nx, ny, alignment, nsteps, chain, peer):
     D._cabi.check(L.dlesm_halo_plan_destroy(plan))
     g._halo_plan = None
     L.dlesm_set_tuning(b"sw_dm_chain", 1)
+    L.dlesm_set_tuning(b"dm_peer_join_fused", 1)
 
 
 def test_shallow_dm_at_the_weak_scaling_tile(D):
@@ -290,7 +294,7 @@ def test_time_loop_forms_of_both_steps_share_a_plan(D, peer):
 
 @pytest.mark.parametrize("nx,ny,alignment", [(2, 3, 2), (40, 33, 8), (257, 66, 64), (130, 9, None), (700, 300, 64)])
 @pytest.mark.parametrize("one_launch_frame,fused,pipelined,peer", [(1, 1, True, 0), (1, 1, False, 0), (1, 0, False, 0),
-                                                                   (0, 0, False, 0), (1, 1, True, 1), (1, 0, False, 1)])
+                                                                   (0, 0, False, 0), (1, 1, True, 1), (1, 0, False, 1), (1, 1, False, 2)])
 def test_distributed_step_with_the_filter_folded_in(D, nx, ny, alignment, one_launch_frame, fused, pipelined, peer):
     """(peer=1: over the mailboxes.)  dlesm_shallow_step_smooth_dm[_pipelined] -- the distributed step that also filters the old level in place (Asselin,
     time_smooth) -- in a four-step time loop with the benchmark's rotation, RCCL in loop-back, against the oracle's step +
@@ -301,6 +305,7 @@ def test_distributed_step_with_the_filter_folded_in(D, nx, ny, alignment, one_la
     L = D._cabi.lib()
     L.dlesm_set_tuning(b"sw_dm_frame", one_launch_frame)
     L.dlesm_set_tuning(b"sw_dm_fused", fused)
+    L.dlesm_set_tuning(b"dm_peer_join_fused", 0 if peer == 2 else 1)    # peer=2: the join as its own wait + unpack launch
     try:
         if alignment is None:
             os.environ.pop("DL_ESM_ALIGNMENT", None)
@@ -351,3 +356,4 @@ def test_distributed_step_with_the_filter_folded_in(D, nx, ny, alignment, one_la
     finally:
         L.dlesm_set_tuning(b"sw_dm_frame", 1)
         L.dlesm_set_tuning(b"sw_dm_fused", 1)
+        L.dlesm_set_tuning(b"dm_peer_join_fused", 1)
