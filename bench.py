@@ -517,7 +517,17 @@ def shallow_water_smooth(D, torch, stream, g, F, prm, tile, steps, alpha=0.001):
         res[label] = e0.elapsed_time(e1) / steps
     ms = res["one_launch"]
     gbs = 96 * cells / (ms * 1e-3) / 1e9
-    return {"workload": f"one whole leapfrog step incl. the Asselin filter (time_smooth) of the old level, {tile}x{tile} fp64, "
+    # the ceiling of THIS stream count in the same process: six arrays read, six written, three of them in place (the old
+    # level), as the filtered step does -- the last thing this leg does with the arrays (the sweep clobbers them)
+    try:
+        cur, old, new = [F[n].data for n in names[:3]], [F[n].data for n in names[3:6]], [F[n].data for n in names[6:]]
+        cc = copy_ceiling(D, torch, stream, cur + old, new + old, g.nx * g.ny)
+        cc["sweep"] += " (three of the written arrays are read arrays: in place, as the filter of the old level)"
+        cc_frac = round(gbs / cc["best_gbs"], 4)
+    except Exception as e:      # noqa: BLE001  (a diagnostic must not cost the leg)
+        cc, cc_frac = {"error": f"{type(e).__name__}: {e}"}, None
+    return {"copy_ceiling": cc, "frac_of_copy_ceiling": cc_frac,
+            "workload": f"one whole leapfrog step incl. the Asselin filter (time_smooth) of the old level, {tile}x{tile} fp64, "
                         "one launch per time step", "steps": steps,
             "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),
             "bit_identical_to_step_plus_time_smooth": same,

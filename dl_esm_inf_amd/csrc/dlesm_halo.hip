@@ -149,7 +149,9 @@ struct dlesm_halo_plan {
     std::vector<unsigned long long *> peer_txflag;
     std::vector<void *> peer_mapped;           // hipIpcOpenMemHandle results, closed with the plan
     unsigned *peer_counter = nullptr;
-    unsigned long long peer_seq = 0;           // steps taken through the mailboxes (the same number on every rank)
+    unsigned long long *peer_seqw = nullptr;   // three device words behind the counter: the sequence numbers the kernels use (peer_seq_load)
+    bool peer_pending_captured = false;        // the pending step was issued into a stream capture (its join may be captured too)
+    unsigned long long peer_seq = 0;           // mailbox operations ISSUED by the host (the same number on every rank): its parity picks the mailbox half; the kernels take the number itself from peer_seqw
     bool peer_pending = false;                 // halos of pending_field are still in the mailbox (parity peer_seq & 1)
     hipEvent_t ev_peer = nullptr;
     // the mailboxes, their counter and the sequence number are ONE resource: an operation issued on another stream than
@@ -560,9 +562,11 @@ static int ensure_buffers(dlesm_halo_plan *p, int nfields, hipStream_t s)
 // then leaves the caller's capture intact).  Measured (scripts/graphprobe.hip): a captured
 // ncclSend/ncclRecv group is fine with RCCL 2.27.7 / HIP 7.2 and segfaults inside hipStreamEndCapture
 // with the RCCL 2.26.6 / HIP 7.0 pair that PyTorch 2.10 bundles.
-static int capture_ok(const dlesm_halo_plan *p, hipStream_t s)
+// over_mailboxes: the entry will take the peer transport, which has no RCCL call to capture (its sequence numbers live on the
+// device, peer_seq_load) -- only an EVEN number of mailbox operations per plan and graph is asked for.
+static int capture_ok(const dlesm_halo_plan *p, hipStream_t s, bool over_mailboxes = false)
 {
-    if ((p->sends.empty() && p->recvs.empty()) || !capturing(s)) return DLESM_OK;
+    if (over_mailboxes || (p->sends.empty() && p->recvs.empty()) || !capturing(s)) return DLESM_OK;
     int v = 0;
     DLESM_NCCL_TRY(ncclGetVersion(&v));
     DLESM_REQUIRE(v >= 22707 || tuning("dm_graph_force", 0),
@@ -685,9 +689,9 @@ static int exchange_peer(dlesm_halo_plan *p, double *const *fields, int nf, unsi
     if (int rc = peer_in_strips(p, mask, seq, nf, st.s, &st.n)) return rc;
     p->peer_seq = seq;
     if (tuning("dm_peer_one_launch", 1))       // both halves in one launch (0: a pack launch, then a wait + unpack launch)
-        return launch_peer_exchange(out, st, fields, nf, p->ld, p->peer_counter, seq, p->frame_timed_out, s);
-    if (int rc = launch_peer_pack(out, fields, nf, p->ld, p->peer_counter, seq, s)) return rc;
-    return launch_peer_unpack(st, seq, fields, nf, p->ld, p->frame_timed_out, s);
+        return launch_peer_exchange(out, st, fields, nf, p->ld, p->peer_counter, seq, p->peer_seqw, p->frame_timed_out, s);
+    if (int rc = launch_peer_pack(out, fields, nf, p->ld, p->peer_counter, seq, p->peer_seqw, p->frame_timed_out, s)) return rc;
+    return launch_peer_unpack(st, seq, p->peer_seqw, fields, nf, p->ld, p->frame_timed_out, s);
 }
 
 static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsigned mask, hipStream_t s,
@@ -699,7 +703,7 @@ static int exchange_on(dlesm_halo_plan *p, double *const *fields, int nf, unsign
     for (const Msg &m : p->recvs)
         if (dir_enabled(mask, m.dir)) { any = true; any_rpack |= m.off >= 0; }
     if (!any) return DLESM_OK; // serial run, or no direction enabled: nothing to do (pcomms:1546,1557-1571)
-    if (p->peer_on && nf <= p->peer_fcap && !prepacked && !skip_unpack && !capturing(s) &&
+    if (p->peer_on && nf <= p->peer_fcap && !prepacked && !skip_unpack &&
         (g_mailbox || (tuning("dm_peer", 1) && tuning("dm_peer_exchange", 1))))      // (mailbox mode has no other transport)
         return exchange_peer(p, fields, nf, mask, s);
     // (a single field on its own goes the same way: rows staged through the buffer travel faster than rows
@@ -900,8 +904,11 @@ extern "C" int dlesm_halo_plan_peer_export(dlesm_halo_plan *p, int my_rank, int 
             DLESM_HIP_TRY(hipExtMallocWithFlags(&p->peer_box, bytes, hipDeviceMallocFinegrained));
         }
         DLESM_HIP_TRY(hipMemset(p->peer_box, 0, bytes));
-        DLESM_HIP_TRY(hipMalloc((void **)&p->peer_counter, 64));
-        DLESM_HIP_TRY(hipMemset(p->peer_counter, 0, 64));
+        DLESM_HIP_TRY(hipMalloc((void **)&p->peer_counter, 128));
+        DLESM_HIP_TRY(hipMemset(p->peer_counter, 0, 128));
+        p->peer_seqw = (unsigned long long *)(p->peer_counter + 16);      // its own 64 bytes
+        const unsigned long long first[3] = {0, 1, 0};                   // next even / next odd operation (the first is number 1) / last raised
+        DLESM_HIP_TRY(hipMemcpy(p->peer_seqw, first, sizeof first, hipMemcpyHostToDevice));
         DLESM_HIP_TRY(hipDeviceSynchronize());
         p->peer_flags = (unsigned long long *)p->peer_box;
         p->peer_rx = (double *)((char *)p->peer_box + PEER_PAYLOAD_AT);
@@ -992,6 +999,8 @@ extern "C" int dlesm_halo_plan_peer_connected(const dlesm_halo_plan *p) { return
 static int peer_order(dlesm_halo_plan *p, hipStream_t s)
 {
     if (p->peer_used && p->peer_last_stream != s) {
+        DLESM_REQUIRE(!capturing(s), "the plan's previous mailbox operation was issued on another stream: an event from there cannot be "
+                      "made part of this capture -- issue the operations before the capture on the capturing stream");
         DLESM_HIP_TRY(hipEventRecord(p->ev_peer, p->peer_last_stream));
         DLESM_HIP_TRY(hipStreamWaitEvent(s, p->ev_peer, 0));
     }
@@ -1016,12 +1025,13 @@ static int peer_in_strips(const dlesm_halo_plan *p, unsigned mask, unsigned long
 
 static int peer_join(dlesm_halo_plan *p, hipStream_t s)
 {
-    DLESM_REQUIRE(!capturing(s), "a peer-transport step is in flight: call dlesm_halo_plan_join before capturing a graph");
+    DLESM_REQUIRE(!capturing(s) || p->peer_pending_captured,
+                  "a peer-transport step is in flight: call dlesm_halo_plan_join before capturing a graph");
     PeerStrips st{};
     if (int rc = peer_in_strips(p, p->pending_mask, p->peer_seq, 1, st.s, &st.n)) return rc;
     if (int rc = peer_order(p, s)) return rc;      // the step itself may have run on another stream
     double *one[1] = {p->pending_field};
-    if (int rc = launch_peer_unpack(st, p->peer_seq, one, 1, p->ld, p->frame_timed_out, s)) return rc;
+    if (int rc = launch_peer_unpack(st, p->peer_seq, p->peer_seqw, one, 1, p->ld, p->frame_timed_out, s)) return rc;
     p->peer_pending = false;
     p->pending_field = nullptr;
     return DLESM_OK;
@@ -1033,7 +1043,6 @@ static int peer_join(dlesm_halo_plan *p, hipStream_t s)
 static int jacobi5_step_peer(dlesm_halo_plan *p, const double *in, double *out, int ld, int ny, int xstart, int xstop,
                              int ystart, int ystop, hipStream_t s, bool pipelined)
 {
-    DLESM_REQUIRE(!capturing(s), "the peer transport hands over through sequence numbers: it cannot be captured into a graph");
     DLESM_REQUIRE(!p->frame_timed_out || *(volatile int *)p->frame_timed_out == 0,
                   "an earlier distributed step gave up waiting for a flag (frame or halo wait timed out)");
     const unsigned mask = tuning("j5_dm_corners", 0) ? DLESM_DIRS_ALL : (DLESM_DIRS_ALL | DLESM_DIRS_NO_DIAGONALS);
@@ -1062,6 +1071,7 @@ static int jacobi5_step_peer(dlesm_halo_plan *p, const double *in, double *out, 
         job.virt = 1;
     }
     job.seq = seq;
+    job.seqw = p->peer_seqw;
     job.counter = p->peer_counter;
     job.wait_ticks = remote_wait_ticks();
     job.timed_out = p->frame_timed_out;
@@ -1080,6 +1090,7 @@ static int jacobi5_step_peer(dlesm_halo_plan *p, const double *in, double *out, 
     p->peer_seq = seq;
     if (fused && join_inside && job.nun > 0) return DLESM_OK;       // joined already: nothing pending
     p->peer_pending = true;
+    p->peer_pending_captured = capturing(s);
     p->pending_field = out;
     p->pending_mask = mask;
     p->pending_stream = s;
@@ -1094,7 +1105,7 @@ static int jacobi5_step_dm_impl(dlesm_halo_plan *p, const double *in, double *ou
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
     if (int rc = ensure_device()) return rc;
     hipStream_t side = side_stream();
-    if (int rc = capture_ok(p, s)) return rc;
+    if (int rc = capture_ok(p, s, p->peer_on && (g_mailbox || tuning("dm_peer", 1)))) return rc;
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) // single tile: one launch over the whole box
         return launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s);
@@ -1232,12 +1243,12 @@ extern "C" int dlesm_stencil9_step_dm(dlesm_halo_plan *p, const double *in, doub
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
     if (int rc = ensure_device()) return rc;
     hipStream_t s = (hipStream_t)stream, side = side_stream();
-    if (int rc = capture_ok(p, s)) return rc;
+    if (int rc = capture_ok(p, s, p->peer_on && (g_mailbox || (tuning("dm_peer", 1) && tuning("dm_peer_exchange", 1))))) return rc;
     if (int rc = join_pending(p, s)) return rc;
     if (p->sends.empty() && p->recvs.empty()) return launch_stencil9(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, s);
     const bool corners = coef[0] != 0.0 || coef[2] != 0.0 || coef[6] != 0.0 || coef[8] != 0.0;
     const unsigned mask = corners ? DLESM_DIRS_ALL : (DLESM_DIRS_ALL | DLESM_DIRS_NO_DIAGONALS);
-    if (p->peer_on && (g_mailbox || (tuning("dm_peer", 1) && tuning("dm_peer_exchange", 1))) && !capturing(s)) {
+    if (p->peer_on && (g_mailbox || (tuning("dm_peer", 1) && tuning("dm_peer_exchange", 1)))) {
         // mailboxes: the whole box, then the two-launch exchange behind it on the same stream (7 us against an RCCL group's 42)
         if (int rc = launch_stencil9(in, out, coef, ld, ny, xstart, xstop, ystart, ystop, s)) return rc;
         return exchange_on(p, out, mask, s);
@@ -1395,6 +1406,7 @@ static int shallow_step_peer(dlesm_halo_plan *p, const dlesm_sw_params *q, int l
     job.counter = p->peer_counter;
     job.flag = p->frame_flag;
     job.seq = seq;
+    job.seqw = p->peer_seqw;
     job.timed_out = p->frame_timed_out;
     job.halo_wait_ticks = remote_wait_ticks();
     // the join inside the launch: a few workgroups wait for this step's strips and copy them into the halos of the new fields
@@ -1410,7 +1422,7 @@ static int shallow_step_peer(dlesm_halo_plan *p, const dlesm_sw_params *q, int l
         if (int rc = launch_shallow_frame(*q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew,
                                           &fp, s, smooth_alpha))
             return rc;
-        if (int rc = launch_peer_flags_set(job.peer_flag, job.npeer, seq, s)) return rc;
+        if (int rc = launch_peer_flags_set(job.peer_flag, job.npeer, seq, p->peer_seqw, p->frame_timed_out, s)) return rc;
         if (xstop - xstart >= 2 && ystop - ystart >= 2) {
             int rc;
             if (smooth_alpha)
@@ -1428,7 +1440,7 @@ static int shallow_step_peer(dlesm_halo_plan *p, const dlesm_sw_params *q, int l
     PeerStrips st{};
     if (int rc = peer_in_strips(p, DLESM_DIRS_ALL, seq, 3, st.s, &st.n)) return rc;
     double *fields[3] = {unew, vnew, pnew};
-    return launch_peer_unpack(st, seq, fields, 3, ld, p->frame_timed_out, s);
+    return launch_peer_unpack(st, seq, p->peer_seqw, fields, 3, ld, p->frame_timed_out, s);
 }
 
 // Distributed shallow-water step: the one-cell frame of unew/vnew/pnew first (four thin boxes),
@@ -1445,7 +1457,7 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
     DLESM_REQUIRE(p->ld == ld && p->ny == ny, "plan is for %dx%d fields, got %dx%d", p->ld, p->ny, ld, ny);
     if (int rc = ensure_device()) return rc;
     hipStream_t side = side_stream();
-    if (int rc = capture_ok(p, s)) return rc;
+    if (int rc = capture_ok(p, s, p->peer_on && p->peer_fcap >= 3 && (g_mailbox || tuning("dm_peer", 1)))) return rc;
     const bool graph = capturing(s);
     if (graph) pipelined = false;
     // time-loop form: a previous pipelined step on this stream left its exchange in flight; the frame
@@ -1463,7 +1475,7 @@ static int shallow_step_dm_impl(dlesm_halo_plan *p, const dlesm_sw_params *q, in
     };
     const bool comms = !p->sends.empty() || !p->recvs.empty();
     if (!comms) return box(xstart, xstop, ystart, ystop);
-    if (p->peer_on && p->peer_fcap >= 3 && !graph && (g_mailbox || tuning("dm_peer", 1)))      // mailboxes connected for three fields
+    if (p->peer_on && p->peer_fcap >= 3 && (g_mailbox || tuning("dm_peer", 1)))      // mailboxes connected for three fields
         return shallow_step_peer(p, q, ld, ny, xstart, xstop, ystart, ystop, u, v, pf, uold, vold, pold, unew, vnew, pnew, s,
                                  smooth_alpha);
     // 1. frame: the one-cell ring of the box, one cell per thread, all four sides, its west/east columns

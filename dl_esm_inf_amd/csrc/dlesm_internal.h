@@ -178,6 +178,28 @@ int launch_flag_set(unsigned long long *flag, unsigned long long seq, hipStream_
 // launch store every cell a neighbour needs STRAIGHT INTO THAT NEIGHBOUR'S receive mailbox (peer-mapped memory: xGMI
 // stores) and then raise the neighbour's arrival flag; they read their own halo operands from the local mailbox once its
 // arrival flags are up.  Mailboxes are double-buffered on the step's sequence number.
+// The sequence number of a mailbox operation LIVES ON THE DEVICE, so that operations captured into a hipGraph advance from
+// replay to replay: three words per plan, w[0] / w[1] = the number of the next operation of even / odd parity, w[2] = the number of
+// the last operation whose flags have been raised.  Every kernel of an operation the host counts as `host_seq` (whose parity
+// selected the mailbox half on the host) takes its number from w[host_seq & 1]; the ONE workgroup of the operation that raises the
+// neighbours' flags then stores seq + 1 into the OTHER word -- the next operation's, which no workgroup of this operation reads,
+// and which the next operation (behind this one in stream order) reads only after this launch has drained.  In a process that
+// never replays a graph the device number equals the host's.  A graph must hold an EVEN number of mailbox operations of a plan
+// (the parities are baked into its pointers); one replayed out of step finds w[2] != seq - 1 and raises the sticky word (value 2).
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned long long peer_seq_load(const unsigned long long *w, unsigned long long host_seq)
+{
+    return w ? __hip_atomic_load(w + (host_seq & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : host_seq;
+}
+__device__ __forceinline__ void peer_seq_advance(unsigned long long *w, unsigned long long seq, int *sticky)
+{
+    if (!w) return;
+    if (__hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq - 1 && sticky)
+        __hip_atomic_store(sticky, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 2, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + ((seq + 1) & 1), seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 struct PeerJob {
     static constexpr int MAXM = 8;
     int fx0, fx1, fy0, fy1;       // 0-based frame box (filled in by launch_stencil5_peer)
@@ -192,6 +214,7 @@ struct PeerJob {
     struct Out { int i0, j0, ni, nj; double *dst; unsigned long long *flag; } out[MAXM];
     int nout;
     unsigned long long seq;       // stored to every out[k].flag when the last frame workgroup is done
+    unsigned long long *seqw;     // the plan's sequence words on the device (peer_seq_load): the number the kernels USE
     unsigned long long wait_ticks;   // bound of the wait (remote_wait_ticks(); 0 = none)
     int *timed_out;
     int fenced;                   // mailbox_fences: release store of the flags, acquire fence behind the wait (peer_raise_flag)
@@ -213,16 +236,17 @@ struct PeerStrips { PeerJob::In s[PeerJob::MAXM]; int n; };
 // mailboxes (field after field inside a message), then -- by the last workgroup to finish -- `seq` into their arrival flags
 struct PeerOuts { PeerJob::Out s[PeerJob::MAXM]; int n; };
 int launch_peer_pack(const PeerOuts &out, const double *const *fields, int nf, int ld, unsigned *counter, unsigned long long seq,
-                     hipStream_t s);
+                     unsigned long long *seqw, int *sticky, hipStream_t s);
 // both halves of an exchange in one launch (pack half dispatched first; the unpack half waits for the neighbours only)
 struct PeerStrips;
 int launch_peer_exchange(const PeerOuts &out, const PeerStrips &in, double *const *fields, int nf, int ld, unsigned *counter,
-                         unsigned long long seq, int *timed_out, hipStream_t s);
+                         unsigned long long seq, unsigned long long *seqw, int *timed_out, hipStream_t s);
 // nf fields: field k of a strip sits k*ni*nj doubles behind its first (the aggregated layout)
-int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *const *fields, int nf, int ld, int *timed_out,
-                       hipStream_t s);
+int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, const unsigned long long *seqw, double *const *fields, int nf, int ld,
+                       int *timed_out, hipStream_t s);
 // *flag[k] = seq for n flags in peer memory (system scope), stream ordered: behind a frame launch that is not the fused one
-int launch_peer_flags_set(unsigned long long *const *flags, int n, unsigned long long seq, hipStream_t s);
+int launch_peer_flags_set(unsigned long long *const *flags, int n, unsigned long long seq, unsigned long long *seqw, int *sticky,
+                          hipStream_t s);
 
 // nsteps fused Jacobi steps (dlesm_jacobi_x2.hip); 1-based inclusive output box, last stage box,
 // grow flags -- see dlesm_stencil5_multi_f64
@@ -256,6 +280,7 @@ struct SwFrameJob {
     int npeer;
     unsigned long long *peer_flag[FramePack3::MAXS];
     int fenced;                   // mailbox_fences (see PeerJob)
+    unsigned long long *seqw;     // peer transport: the plan's sequence words (peer_seq_load); nullptr: `seq` as passed
     // ... and the join inside the launch (as PeerJob::un): `nunb` workgroups behind the ring workgroups wait for THIS step's
     // arrival flags and copy the received strips -- three fields per message -- into the halos of unew, vnew, pnew
     PeerJob::In un[PeerJob::MAXM];

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
         for (int k = b % pj.nun, part = b / pj.nun; k < pj.nun; k += pj.nunb) {      // (nunb >= nun: one strip per group, several groups per strip)
             const PeerJob::In m = pj.un[k];
             const int parts = (pj.nunb - k + pj.nun - 1) / pj.nun;                  // groups that share strip k
-            if (threadIdx.x == 0) peer_wait_flags(&m, 1, pj.seq, pj.wait_ticks, pj.timed_out, pj.fenced != 0);
+            if (threadIdx.x == 0) peer_wait_flags(&m, 1, peer_seq_load(pj.seqw, pj.seq), pj.wait_ticks, pj.timed_out, pj.fenced != 0);
             __syncthreads();
             const long n = (long)m.ni * m.nj;
             for (long t = (long)part * blockDim.x + threadIdx.x; t < n; t += (long)parts * blockDim.x) {
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
         return;
     }
     if (pj.wait_seq) {      // the neighbours' frames of the previous step: in steady state long since there (one load each)
-        if (threadIdx.x == 0) peer_wait_flags(pj.in, pj.nin, pj.wait_seq, pj.wait_ticks, pj.timed_out, pj.fenced != 0);
+        if (threadIdx.x == 0) peer_wait_flags(pj.in, pj.nin, peer_seq_load(pj.seqw, pj.seq) - 1, pj.wait_ticks, pj.timed_out, pj.fenced != 0);   // (wait_seq == seq - 1)
         __syncthreads();
     }
     const long total = frame_cells(pj.fx1 - pj.fx0 + 1, pj.fy1 - pj.fy0 + 1);
@@ -489,8 +489,10 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
         const unsigned done = __hip_atomic_fetch_add(pj.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (unsigned)pj.nblocks - 1) {
             __hip_atomic_store(pj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long seq = peer_seq_load(pj.seqw, pj.seq);
             for (int k = 0; k < pj.nout; k++)
-                peer_raise_flag(pj.out[k].flag, pj.seq, pj.fenced != 0);
+                peer_raise_flag(pj.out[k].flag, seq, pj.fenced != 0);
+            peer_seq_advance(pj.seqw, seq, pj.timed_out);
         }
     }
 }
@@ -498,11 +500,11 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
 // Joins of the peer transport: wait for the strips' arrival flags, then copy them from the mailbox into the halo cells
 // of the field (ordinary stores: the readers are later launches on this stream).  grid = (parts, strips).
 struct PeerFields { double *f[16]; };
-__global__ __launch_bounds__(256) void peer_unpack_k(PeerStrips st, unsigned long long seq, PeerFields fields, int ld,
-                                                     unsigned long long ticks, int *timed_out, int fenced)
+__global__ __launch_bounds__(256) void peer_unpack_k(PeerStrips st, unsigned long long seq, const unsigned long long *seqw, PeerFields fields,
+                                                     int ld, unsigned long long ticks, int *timed_out, int fenced)
 {
     const PeerJob::In m = st.s[blockIdx.y];
-    if (threadIdx.x == 0) peer_wait_flags(&m, 1, seq, ticks, timed_out, fenced != 0);
+    if (threadIdx.x == 0) peer_wait_flags(&m, 1, peer_seq_load(seqw, seq), ticks, timed_out, fenced != 0);
     __syncthreads();
     const long n = (long)m.ni * m.nj;
     double *__restrict__ field = fields.f[blockIdx.z];
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(256) void peer_unpack_k(PeerStrips st, unsigned lon
 // jacobi5_tile_peer: system-scope write-through stores, drained, barrier, one counter increment per workgroup, the last
 // arriver raises every neighbour's flag.
 __global__ __launch_bounds__(256) void peer_pack_k(PeerOuts out, PeerFields fields, int ld, unsigned *counter,
-                                                   unsigned long long seq, int fenced)
+                                                   unsigned long long seq, unsigned long long *seqw, int *sticky, int fenced)
 {
     const PeerJob::Out m = out.s[blockIdx.y];
     const long n = (long)m.ni * m.nj;
@@ -534,8 +536,10 @@ __global__ __launch_bounds__(256) void peer_pack_k(PeerOuts out, PeerFields fiel
         const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == total - 1) {
             __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long dseq = peer_seq_load(seqw, seq);
             for (int k = 0; k < out.n; k++)
-                peer_raise_flag(out.s[k].flag, seq, fenced != 0);
+                peer_raise_flag(out.s[k].flag, dseq, fenced != 0);
+            peer_seq_advance(seqw, dseq, sticky);
         }
     }
 }
@@ -544,8 +548,8 @@ __global__ __launch_bounds__(256) void peer_pack_k(PeerOuts out, PeerFields fiel
 // (dispatched first), the other nf the unpack half -- which waits for the NEIGHBOURS' flags and so does not depend on this
 // launch's own pack half (nor theirs on ours): no cycle.  One launch less per exchange (7 -> 5 us from a compiled host).
 __global__ __launch_bounds__(256) void peer_exchange_k(PeerOuts out, PeerStrips in, PeerFields fields, int nf, int ld,
-                                                       unsigned *counter, unsigned long long seq, unsigned long long ticks,
-                                                       int *timed_out, int fenced)
+                                                       unsigned *counter, unsigned long long seq, unsigned long long *seqw,
+                                                       unsigned long long ticks, int *timed_out, int fenced)
 {
     const int k = blockIdx.z % nf;
     if ((int)blockIdx.z < nf) {                          // ---- pack half
@@ -566,15 +570,17 @@ __global__ __launch_bounds__(256) void peer_exchange_k(PeerOuts out, PeerStrips 
             const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (done == total - 1) {
                 __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long dseq = peer_seq_load(seqw, seq);
                 for (int q = 0; q < out.n; q++)
-                    peer_raise_flag(out.s[q].flag, seq, fenced != 0);
+                    peer_raise_flag(out.s[q].flag, dseq, fenced != 0);
+                peer_seq_advance(seqw, dseq, timed_out);
             }
         }
         return;
     }
     if ((int)blockIdx.y >= in.n) return;                 // ---- unpack half
     const PeerJob::In m = in.s[blockIdx.y];
-    if (threadIdx.x == 0) peer_wait_flags(&m, 1, seq, ticks, timed_out, fenced != 0);
+    if (threadIdx.x == 0) peer_wait_flags(&m, 1, peer_seq_load(seqw, seq), ticks, timed_out, fenced != 0);
     __syncthreads();
     const long n = (long)m.ni * m.nj;
     double *__restrict__ field = fields.f[k];
@@ -586,9 +592,12 @@ __global__ __launch_bounds__(256) void peer_exchange_k(PeerOuts out, PeerStrips 
 }
 
 struct PeerFlagList { unsigned long long *f[PeerJob::MAXM]; };
-__global__ void peer_flags_set_k(PeerFlagList fl, int n, unsigned long long seq, int fenced)
+__global__ void peer_flags_set_k(PeerFlagList fl, int n, unsigned long long seq, unsigned long long *seqw, int *sticky, int fenced)
 {
-    if (threadIdx.x < (unsigned)n) peer_raise_flag(fl.f[threadIdx.x], seq, fenced != 0);
+    const unsigned long long dseq = peer_seq_load(seqw, seq);
+    if (threadIdx.x < (unsigned)n) peer_raise_flag(fl.f[threadIdx.x], dseq, fenced != 0);
+    __syncthreads();                      // (one workgroup: every lane has read the word before lane 0 moves the other one)
+    if (threadIdx.x == 0) peer_seq_advance(seqw, dseq, sticky);
 }
 
 // LDS-staged form (j5_kernel = 2, the comparison point for "stage the tile and its halo ring in
@@ -1116,7 +1125,7 @@ int launch_stencil5_peer(const double *in, double *out, int ld, int ny, int xsta
 int launch_stencil5_peer_frame(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                                PeerJob job, hipStream_t s)
 {
-    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (xstop < xstart || ystop < ystart) return launch_peer_flags_set(nullptr, 0, job.seq, job.seqw, job.timed_out, s);
     if (int rc = check_box("dlesm_jacobi5_step_dm", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     job.fx0 = xstart - 1, job.fx1 = xstop - 1, job.fy0 = ystart - 1, job.fy1 = ystop - 1;
     const long cells = 2L * (xstop - xstart + 1) + 2L * (ystop - ystart + 1);
@@ -1129,8 +1138,8 @@ int launch_stencil5_peer_frame(const double *in, double *out, int ld, int ny, in
     return DLESM_OK;
 }
 
-int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *const *fields, int nf, int ld, int *timed_out,
-                       hipStream_t s)
+int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, const unsigned long long *seqw, double *const *fields, int nf, int ld,
+                       int *timed_out, hipStream_t s)
 {
     if (st.n == 0) return DLESM_OK;
     DLESM_REQUIRE(nf >= 1 && nf <= 16, "peer unpack of %d fields", nf);
@@ -1140,16 +1149,16 @@ int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, double *con
     if (parts > 16) parts = 16;
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = fields[k];
-    hipLaunchKernelGGL(peer_unpack_k, dim3(parts, st.n, nf), dim3(256), 0, s, st, seq, pf, ld, remote_wait_ticks(), timed_out,
+    hipLaunchKernelGGL(peer_unpack_k, dim3(parts, st.n, nf), dim3(256), 0, s, st, seq, seqw, pf, ld, remote_wait_ticks(), timed_out,
                        tuning("mailbox_fences", 0));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
 
 int launch_peer_pack(const PeerOuts &out, const double *const *fields, int nf, int ld, unsigned *counter, unsigned long long seq,
-                     hipStream_t s)
+                     unsigned long long *seqw, int *sticky, hipStream_t s)
 {
-    if (out.n == 0) return DLESM_OK;
+    if (out.n == 0) return launch_peer_flags_set(nullptr, 0, seq, seqw, sticky, s);    // nothing to send: the operation still counts
     DLESM_REQUIRE(nf >= 1 && nf <= 16 && counter != nullptr, "peer pack of %d fields", nf);
     long longest = 1;
     for (int k = 0; k < out.n; k++) longest = std::max(longest, (long)out.s[k].ni * out.s[k].nj);
@@ -1157,15 +1166,15 @@ int launch_peer_pack(const PeerOuts &out, const double *const *fields, int nf, i
     if (parts > 16) parts = 16;
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = const_cast<double *>(fields[k]);
-    hipLaunchKernelGGL(peer_pack_k, dim3(parts, out.n, nf), dim3(256), 0, s, out, pf, ld, counter, seq, tuning("mailbox_fences", 0));
+    hipLaunchKernelGGL(peer_pack_k, dim3(parts, out.n, nf), dim3(256), 0, s, out, pf, ld, counter, seq, seqw, sticky, tuning("mailbox_fences", 0));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
 
 int launch_peer_exchange(const PeerOuts &out, const PeerStrips &in, double *const *fields, int nf, int ld, unsigned *counter,
-                         unsigned long long seq, int *timed_out, hipStream_t s)
+                         unsigned long long seq, unsigned long long *seqw, int *timed_out, hipStream_t s)
 {
-    if (out.n == 0 && in.n == 0) return DLESM_OK;
+    if (out.n == 0 && in.n == 0) return launch_peer_flags_set(nullptr, 0, seq, seqw, timed_out, s);   // the operation still counts
     DLESM_REQUIRE(nf >= 1 && nf <= 16 && counter != nullptr, "peer exchange of %d fields", nf);
     long longest = 1;
     for (int k = 0; k < out.n; k++) longest = std::max(longest, (long)out.s[k].ni * out.s[k].nj);
@@ -1175,18 +1184,19 @@ int launch_peer_exchange(const PeerOuts &out, const PeerStrips &in, double *cons
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = fields[k];
     hipLaunchKernelGGL(peer_exchange_k, dim3(parts, std::max(out.n, in.n), 2 * nf), dim3(256), 0, s, out, in, pf, nf, ld, counter,
-                       seq, remote_wait_ticks(), timed_out, tuning("mailbox_fences", 0));
+                       seq, seqw, remote_wait_ticks(), timed_out, tuning("mailbox_fences", 0));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
 
-int launch_peer_flags_set(unsigned long long *const *flags, int n, unsigned long long seq, hipStream_t s)
+int launch_peer_flags_set(unsigned long long *const *flags, int n, unsigned long long seq, unsigned long long *seqw, int *sticky,
+                          hipStream_t s)
 {
-    if (n == 0) return DLESM_OK;
+    if (n == 0 && !seqw) return DLESM_OK;                 // (n == 0 with sequence words: the launch only moves them on)
     DLESM_REQUIRE(n <= PeerJob::MAXM, "%d peer flags", n);
     PeerFlagList fl{};
     for (int k = 0; k < n; k++) fl.f[k] = flags[k];
-    hipLaunchKernelGGL(peer_flags_set_k, dim3(1), dim3(64), 0, s, fl, n, seq, tuning("mailbox_fences", 0));
+    hipLaunchKernelGGL(peer_flags_set_k, dim3(1), dim3(64), 0, s, fl, n, seq, seqw, sticky, tuning("mailbox_fences", 0));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }

@@ -11,7 +11,7 @@ namespace dlesm {
 namespace {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
-struct StreamPtrs { const d2 *r[8]; d2 *w[4]; };
+struct StreamPtrs { const d2 *r[8]; d2 *w[6]; };   // (no restrict: written arrays may BE read arrays -- the in-place sweeps)
 
 // NT bit 0: the second half of the read arrays is loaded non-temporally (the once-read old time level of the
 // shallow-water step); bit 1: every store is non-temporal
@@ -59,7 +59,7 @@ extern "C" int dlesm_stream_copy_f64(int nread, int nwrite, const double *const 
     DLESM_REQUIRE(src != nullptr && dst != nullptr, "dlesm_stream_copy_f64: null pointer");
     DLESM_REQUIRE(n % 2 == 0 && n / 2 < ((size_t)1 << 31) * 256, "dlesm_stream_copy_f64: n = %zu must be even and below 2^40", n);
     StreamPtrs p{};
-    DLESM_REQUIRE(nread >= 1 && nread <= 8 && nwrite >= 1 && nwrite <= 4, "dlesm_stream_copy_f64: %d read / %d written arrays",
+    DLESM_REQUIRE(nread >= 1 && nread <= 8 && nwrite >= 1 && nwrite <= 6, "dlesm_stream_copy_f64: %d read / %d written arrays",
                   nread, nwrite);
     for (int k = 0; k < nread; k++) {
         DLESM_REQUIRE(src[k] != nullptr && (uintptr_t)src[k] % 16 == 0, "dlesm_stream_copy_f64: read array %d null or not 16-byte aligned", k);
@@ -77,8 +77,9 @@ extern "C" int dlesm_stream_copy_f64(int nread, int nwrite, const double *const 
     else if (nread == 3 && nwrite == 1) launch_stream<3, 1>(p, n2, nt, s);
     else if (nread == 4 && nwrite == 1) launch_stream<4, 1>(p, n2, nt, s);
     else if (nread == 6 && nwrite == 3) launch_stream<6, 3>(p, n2, nt, s);
+    else if (nread == 6 && nwrite == 6) launch_stream<6, 6>(p, n2, nt, s);   // the filtered step: dst[3..5] may be src[3..5] (in place)
     else if (nread == 8 && nwrite == 1) launch_stream<8, 1>(p, n2, nt, s);
-    else return fail(DLESM_EINVAL, "dlesm_stream_copy_f64: no %d-read / %d-write sweep (1+1, 2+1, 3+1, 4+1, 6+3, 8+1)", nread, nwrite);
+    else return fail(DLESM_EINVAL, "dlesm_stream_copy_f64: no %d-read / %d-write sweep (1+1, 2+1, 3+1, 4+1, 6+3, 6+6, 8+1)", nread, nwrite);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }

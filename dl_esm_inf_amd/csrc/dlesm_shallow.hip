@@ -264,8 +264,8 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
         const int b = blockIdx.x - fj.nblocks, k = b % fj.nun, part = b / fj.nun, parts = (fj.nunb - k + fj.nun - 1) / fj.nun;
         const PeerJob::In m = fj.un[k];
         if (threadIdx.x == 0) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__hip_atomic_load(m.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < fj.seq) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), seq = peer_seq_load(fj.seqw, fj.seq);
+            while (__hip_atomic_load(m.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
                 __builtin_amdgcn_s_sleep(32);
                 if (fj.halo_wait_ticks && __builtin_amdgcn_s_memrealtime() - t0 > fj.halo_wait_ticks) {
                     __hip_atomic_store(fj.timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -344,13 +344,14 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
         const unsigned done = __hip_atomic_fetch_add(fj.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (unsigned)fj.nblocks - 1) {
             __hip_atomic_store(fj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (fj.npeer)         // peer transport: the neighbours' arrival flags
-                for (int k = 0; k < fj.npeer; k++)
-                    {
-                        if (fj.fenced) __hip_atomic_store(fj.peer_flag[k], fj.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                        else __hip_atomic_store(fj.peer_flag[k], fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-            else
+            if (fj.npeer) {       // peer transport: the neighbours' arrival flags, then this plan's sequence words (peer_seq_load)
+                const unsigned long long seq = peer_seq_load(fj.seqw, fj.seq);
+                for (int k = 0; k < fj.npeer; k++) {
+                    if (fj.fenced) __hip_atomic_store(fj.peer_flag[k], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    else __hip_atomic_store(fj.peer_flag[k], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                peer_seq_advance(fj.seqw, seq, fj.timed_out);
+            } else
                 __hip_atomic_store(fj.flag, fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

@@ -418,7 +418,7 @@ int dlesm_hash_init_f64(double *f, int ld, int ny, int xstart, int xstop, int ys
 /* Diagnostic (no reference counterpart): a linear sweep that reads `nread` arrays once and writes `nwrite`
  * arrays once, n doubles each, one 16-byte element per thread per array -- the ceiling a kernel with that many
  * concurrent HBM streams is measured against in the same process (bench.py's copy_ceiling).  Combinations:
- * 1+1, 2+1, 3+1, 4+1, 6+3, 8+1.  nt bit 0: the second half of the read arrays loaded non-temporally; bit 1:
+ * 1+1, 2+1, 3+1, 4+1, 6+3, 6+6 (written arrays may be read arrays: the in-place sweep of the filtered step), 8+1.  nt bit 0: the second half of the read arrays loaded non-temporally; bit 1:
  * non-temporal stores.  dst_k = (sum of the read arrays) + src_(k mod nread)   (1+1: a plain copy). */
 int dlesm_stream_copy_f64(int nread, int nwrite, const double *const *src, double *const *dst, size_t n,
                           int nt, void *stream);

@@ -357,3 +357,100 @@ def test_fenced_mailboxes_change_no_bit(D, nx, ny, alignment, nsteps):
         L.dlesm_set_tuning(b"mailbox_fences", 0)
         L.dlesm_set_tuning(b"dm_peer_one_launch", 1)
         D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+# --------------------------------------------------------------------------- hipGraph capture of mailbox operations
+@pytest.mark.parametrize("form", ["joined", "time_loop", "exchange", "joined_apart"])
+@pytest.mark.parametrize("nx,ny,alignment", [(300, 41, 64), (37, 29, None), (1500, 700, 64)])
+def test_mailbox_steps_captured_into_a_graph(D, form, nx, ny, alignment):
+    """The sequence numbers of the mailboxes live on the device (peer_seq_load), so mailbox operations can be
+    captured: a graph of TWO ping-pong steps -- joined form, time-loop form + join, plain sweep + halo_exchange over the
+    mailboxes, joined form with the join as its own launch -- replayed three times, with un-captured steps before, between
+    and after the replays, equals the oracle's steps + edge exchanges bit for bit.  (No RCCL call is in the capture: this
+    works with the RCCL that cannot be captured, too.)"""
+    import torch
+    L, g, x, y, plan, oc = _setup(D, nx, ny, alignment, "host")
+    it = x.internal
+    s = torch.cuda.Stream()
+    sp = C.c_void_p(s.cuda_stream)
+    L.dlesm_set_tuning(b"dm_peer_join_fused", 0 if form == "joined_apart" else 1)
+
+    def issue(src, dst):
+        if form in ("joined", "joined_apart"):
+            return [L.dlesm_jacobi5_step_dm(plan, src.device_ptr, dst.device_ptr, g.nx, g.ny, *it.box(), sp)]
+        if form == "time_loop":
+            return [L.dlesm_jacobi5_step_dm_pipelined(plan, src.device_ptr, dst.device_ptr, g.nx, g.ny, *it.box(), sp)]
+        return [L.dlesm_stencil5_f64(src.device_ptr, dst.device_ptr, g.nx, g.ny, *it.box(), sp),
+                L.dlesm_halo_exchange_f64(plan, dst.device_ptr, D._cabi.DIRS_EDGES_ONLY, sp)]
+
+    try:
+        with torch.cuda.stream(s):
+            D.psy.hash_init(x, SEED + 91, stream=s)
+            D._cabi.check(L.dlesm_halo_exchange_f64(plan, x.device_ptr, D._cabi.DIRS_ALL, sp))    # (the capturing stream: see peer_order)
+            D.copy_field(x, y, stream=s)
+        s.synchronize()
+        hx, hy = x.get_data(), y.get_data()
+
+        def oracle_step(src, dst):
+            O.jacobi5(src, dst, g.nx, *it.box())
+            assert O.exchange_dirs([dst], [g.nx], [oc], (1, 2, 3, 4), no_diagonals=True) == 0
+
+        def eager_pair():
+            assert all(rc == 0 for rc in issue(x, y) + issue(y, x)), L.dlesm_last_error()
+            D._cabi.check(L.dlesm_halo_plan_join(plan, sp))
+            oracle_step(hx, hy)
+            oracle_step(hy, hx)
+
+        eager_pair()                         # three operations so far (exchange + 2): the graph starts on an even parity
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
+            rcs = issue(x, y) + issue(y, x) + [L.dlesm_halo_plan_join(plan, sp)]
+        assert all(rc == 0 for rc in rcs), L.dlesm_last_error()
+        for k in range(3):
+            graph.replay()
+            oracle_step(hx, hy)
+            oracle_step(hy, hx)
+            if k == 1:
+                s.synchronize()
+                eager_pair()                 # un-captured operations between replays: an even number keeps the parities
+        eager_pair()
+        torch.cuda.synchronize()
+        assert L.dlesm_wait_timed_out(0) == 0
+        assert np.array_equal(x.get_data(), hx) and np.array_equal(y.get_data(), hy)
+        del graph
+    finally:
+        L.dlesm_set_tuning(b"dm_peer_join_fused", 1)
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+
+
+def test_a_graph_replayed_out_of_step_is_reported(D):
+    """a graph that holds an ODD number of mailbox operations has the wrong mailbox halves baked in from its second replay on:
+    the workgroup that raises the flags finds the last raised number != its own - 1 and raises the process-wide sticky word
+    (every later entry then fails, as after a time-out) -- wrong halos cannot leave silently"""
+    import torch
+    L, g, x, y, plan, oc = _setup(D, 130, 40, 64, "host")
+    it = x.internal
+    s = torch.cuda.Stream()
+    sp = C.c_void_p(s.cuda_stream)
+    try:
+        with torch.cuda.stream(s):
+            D.psy.hash_init(x, SEED + 92, stream=s)
+            D.copy_field(x, y, stream=s)
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
+            rc = L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), sp)
+        assert rc == 0, L.dlesm_last_error()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert L.dlesm_wait_timed_out(0) == 0            # the first replay is in step
+        graph.replay()
+        torch.cuda.synchronize()
+        assert L.dlesm_wait_timed_out(0) == 1
+        assert L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), sp) != 0
+        del graph
+    finally:
+        L.dlesm_halo_plan_destroy(plan)
+        L.dlesm_wait_timed_out(1)
+    assert L.dlesm_wait_timed_out(0) == 0
