@@ -3,6 +3,9 @@
  * and replayed; the result must equal the same steps issued one by one.  One rank, which is its own
  * eight neighbours (a periodic wrap), so that the RCCL group is real.  Needs RCCL >= 2.27.7 (ROCm 7.2):
  * the library refuses the capture on older ones, where hipStreamEndCapture crashes (scripts/graphprobe.hip).
+ * A fourth argument `peer` connects the plan's mailboxes first: the captured steps are then single launches
+ * whose frame workgroups store into the neighbours' mailboxes -- no RCCL call in the graph, any RCCL version; the sequence
+ * numbers of the mailboxes live on the device and advance from replay to replay (a graph holds an even number of steps).
  *
  *   gcc -std=c99 -O2 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/graph_demo.c \
  *       -Ldl_esm_inf_amd/lib -ldlesm_hip -L/opt/rocm/lib -lamdhip64 \
@@ -59,6 +62,7 @@ int main(int argc, char **argv)
 {
     const int nx = argc > 1 ? atoi(argv[1]) : 500, ny = argc > 2 ? atoi(argv[2]) : 300;
     const int nsteps = argc > 3 ? atoi(argv[3]) & ~1 : 8;           /* an even number: the graph holds two */
+    const int peer = argc > 4 && !strcmp(argv[4], "peer");
     dlesm_decomp decomp;
     dlesm_subdomain sub;
     CHECK(dlesm_decompose(nx, ny, 1, 0, 0, 1, &decomp, &sub));
@@ -81,6 +85,8 @@ int main(int argc, char **argv)
     loopback(&tables, &it);
     dlesm_halo_plan *plan = NULL;
     CHECK(dlesm_halo_plan_create(&tables, ld, nyarr, &plan));
+    if (peer) CHECK(dlesm_halo_plan_peer_connect_rccl(plan, 1));    /* mailboxes for one field; blobs all-gathered by the library */
+    printf("G: transport %s\n", dlesm_halo_plan_peer_connected(plan) ? "mailboxes" : "rccl");
     dlesm_field *fa = NULL, *fb = NULL;
     CHECK(dlesm_field_create(ld, nyarr, &fa));
     CHECK(dlesm_field_create(ld, nyarr, &fb));

@@ -25,7 +25,10 @@
  *     replays as one graph launch.  Planning calls, checksums, gathers and anything documented as
  *     synchronising may not.  Under capture a distributed step forks to the library's side stream
  *     and joins back inside the graph (the *_pipelined form then equals the joined form); run the
- *     call once uncaptured first -- pack buffers are allocated on first use.
+ *     call once uncaptured first -- pack buffers are allocated on first use.  On a plan whose
+ *     mailboxes are connected (peer transport, section 5) the captured operations are the ordinary
+ *     single launches -- no RCCL call in the graph, *_pipelined stays the time-loop form -- and a
+ *     graph has to hold an EVEN number of mailbox operations of a plan (see there).
  */
 #ifndef DLESM_HIP_H
 #define DLESM_HIP_H
@@ -580,6 +583,14 @@ int dlesm_halo_plan_join(dlesm_halo_plan *plan, void *stream);
  * operations on it issued on different streams are ordered one behind the other by the library (an event); ordering the
  * FIELDS between streams stays the caller's business, as with any other entry.  dm_peer = 0 (dlesm_set_tuning)
  * switches a connected plan back to RCCL -- on every rank or on none.
+ * hipGraph capture: the number of a mailbox operation is kept in DEVICE memory (each operation's flag-raising workgroup
+ * writes the next operation's number), the host only tracks its parity -- which mailbox half the operation's pointers
+ * address.  Mailbox operations may therefore be captured, and replayed any number of times between un-captured ones,
+ * provided (a) a graph holds an EVEN number of them per plan and ends joined (dlesm_halo_plan_join inside the capture
+ * after *_pipelined steps), (b) every replay starts at the parity the capture started at (an even number of un-captured
+ * operations in between), (c) the operation before the capture was issued on the capturing stream, and (d) every rank
+ * replays alike.  A replay out of step is detected on the device (last number raised != this one - 1) and raises the
+ * process-wide flag of dlesm_wait_timed_out: wrong halos cannot leave silently.
  *
  * Connecting is collective over the ranks that share neighbours:
  *   1. dlesm_halo_plan_peer_export(plan, my_rank, nfields = 1, blob): allocates this rank's mailbox and writes

@@ -59,7 +59,7 @@ gld, gny = NX + 2, NY + 2
 G = O.hash_field(SEED, gny, gld, 0, 0, 1, NX + 2, 1, NY + 2)
 H = G.copy()
 history = [G.copy()]
-for _ in range(2 * STEPS):
+for _ in range(2 * STEPS + 4):           # joined steps, time-loop steps, two replays of a two-step graph
     O.jacobi5(G, H, gld, 2, NX + 1, 2, NY + 1)
     G, H = H, G
     history.append(G.copy())
@@ -124,6 +124,23 @@ for k in range(STEPS):
 D.psy.halo_join(g, stream=s)
 s.synchronize()
 errors += check(a, n, "time-loop form")
+# the same two time-loop steps + join captured into ONE hipGraph per rank and replayed twice: the sequence numbers of the
+# mailboxes live on the device and advance with every replay, on every rank alike (no communication library call in the graph)
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
+    D.psy.invoke_jacobi5_dm_pipelined(b, a, stream=s)
+    D.psy.invoke_jacobi5_dm_pipelined(a, b, stream=s)
+    D.psy.halo_join(g, stream=s)
+for k in range(2):
+    with torch.cuda.stream(s):            # (replay() launches on the current stream)
+        graph.replay()
+    n += 2
+    if k == 0:
+        import time
+        time.sleep(0.03 * rank)
+torch.cuda.synchronize()
+errors += check(a, n, "time-loop steps replayed from a graph")
+del graph
 if MODE == "mailbox":
     # ---- everything else a multi-rank job needs, with no communication library underneath -------------------------
     # (1) field_checksum: the local sums travel over the host-side board and are added in rank order

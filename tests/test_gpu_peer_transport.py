@@ -408,7 +408,8 @@ def test_mailbox_steps_captured_into_a_graph(D, form, nx, ny, alignment):
             rcs = issue(x, y) + issue(y, x) + [L.dlesm_halo_plan_join(plan, sp)]
         assert all(rc == 0 for rc in rcs), L.dlesm_last_error()
         for k in range(3):
-            graph.replay()
+            with torch.cuda.stream(s):            # (replay() launches on the current stream)
+                graph.replay()
             oracle_step(hx, hy)
             oracle_step(hy, hx)
             if k == 1:
@@ -417,7 +418,12 @@ def test_mailbox_steps_captured_into_a_graph(D, form, nx, ny, alignment):
         eager_pair()
         torch.cuda.synchronize()
         assert L.dlesm_wait_timed_out(0) == 0
-        assert np.array_equal(x.get_data(), hx) and np.array_equal(y.get_data(), hy)
+        assert np.array_equal(x.get_data(), hx)
+        if form == "time_loop":              # the halos of the last-but-one level were read from the mailbox, never unpacked into the field
+            inner = (slice(it.ystart - 1, it.ystop), slice(it.xstart - 1, it.xstop))
+            assert np.array_equal(y.get_data()[inner], hy[inner])
+        else:
+            assert np.array_equal(y.get_data(), hy)
         del graph
     finally:
         L.dlesm_set_tuning(b"dm_peer_join_fused", 1)
@@ -442,10 +448,12 @@ def test_a_graph_replayed_out_of_step_is_reported(D):
         with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
             rc = L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), sp)
         assert rc == 0, L.dlesm_last_error()
-        graph.replay()
+        with torch.cuda.stream(s):            # (replay() launches on the current stream)
+            graph.replay()
         torch.cuda.synchronize()
         assert L.dlesm_wait_timed_out(0) == 0            # the first replay is in step
-        graph.replay()
+        with torch.cuda.stream(s):            # (replay() launches on the current stream)
+            graph.replay()
         torch.cuda.synchronize()
         assert L.dlesm_wait_timed_out(0) == 1
         assert L.dlesm_jacobi5_step_dm(plan, x.device_ptr, y.device_ptr, g.nx, g.ny, *it.box(), sp) != 0

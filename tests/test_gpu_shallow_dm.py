@@ -357,3 +357,84 @@ def test_distributed_step_with_the_filter_folded_in(D, nx, ny, alignment, one_la
         L.dlesm_set_tuning(b"sw_dm_frame", 1)
         L.dlesm_set_tuning(b"sw_dm_fused", 1)
         L.dlesm_set_tuning(b"dm_peer_join_fused", 1)
+
+
+@pytest.mark.parametrize("nx,ny,alignment", [(257, 66, 64), (130, 9, None), (700, 300, 64)])
+@pytest.mark.parametrize("filtered", [False, True])
+def test_shallow_time_loop_over_the_mailboxes_captured_into_a_graph(D, nx, ny, alignment, filtered):
+    """Six leapfrog steps of the distributed shallow-water step over the mailboxes (the three-level pointer rotation
+    repeats after three steps, the mailbox halves after two) captured into ONE hipGraph and replayed three times:
+    18 steps, against the oracle's step + exchange of the new level (+ time_smooth of the old level: the filtered form), every field and
+    halo, bit for bit.  The steps' sequence numbers live on the device (peer_seq_load); no RCCL call is in the graph."""
+    import torch
+    from dm_overhead import loopback_tables
+    L = D._cabi.lib()
+    if alignment is None:
+        os.environ.pop("DL_ESM_ALIGNMENT", None)
+    else:
+        os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (1, 1, 2), D.GO_OFFSET_NE)
+    g.decompose(nx, ny)
+    D.grid_init(g, 1.0, 1.0)
+    os.environ.pop("DL_ESM_ALIGNMENT", None)
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    F = {n: D.r2d_field(g, pts[n[0]]) for n in names}
+    it = F["p"].internal
+    t = loopback_tables(D, it)
+    plan = C.c_void_p()
+    D._cabi.check(L.dlesm_halo_plan_create(C.byref(t), g.nx, g.ny, C.byref(plan)))
+    g._halo_plan = plan
+    D.psy.halo_connect_peers(g, 3)
+    s = torch.cuda.Stream()
+    alpha = 0.001
+    with torch.cuda.stream(s):
+        for k, n in enumerate(names[:6]):
+            D.psy.hash_init(F[n], 300 + k, stream=s)
+            F[n].data.mul_(0.01)
+            F[n].data.add_(1.0 if n[0] == "p" else -0.005)
+        for n in names[6:]:
+            D.set_field(F[n], 9.0, stream=s)
+        D.psy.halo_exchange_multi([F[n] for n in names[:3]], stream=s)        # mailbox operations before the capture: on the capturing stream
+        D.psy.halo_exchange_multi([F[n] for n in names[3:6]], stream=s)
+    s.synchronize()
+    H = {n: F[n].get_data() for n in names}
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 20.0)
+    op = O.SwParams(prm.fsdx, prm.fsdy, prm.tdts8, prm.tdtsdx, prm.tdtsdy)
+    oc = O.Comms()
+    C.memmove(C.byref(oc), C.byref(t), C.sizeof(oc))
+    scratch = [np.zeros((g.ny, g.nx)) for _ in range(4)]
+    graph = torch.cuda.CUDAGraph()
+    start = (["u", "v", "p"], ["uold", "vold", "pold"], ["unew", "vnew", "pnew"])
+    cur, old, new = start
+
+    def rotate(cur, old, new):       # the filter leaves the filtered present level in `old`: two buffers swap; without it three rotate
+        return (new, old, cur) if filtered else (new, cur, old)
+
+    with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
+        for _ in range(6):
+            if filtered:
+                D.psy.invoke_shallow_step_smooth_dm(prm, alpha, *[F[n] for n in cur + old + new], stream=s)
+            else:
+                D.psy.invoke_shallow_step_dm_pipelined(prm, *[F[n] for n in cur + old + new], stream=s)
+            cur, old, new = rotate(cur, old, new)
+        D.psy.halo_join(g, stream=s)
+    assert (cur, old, new) == start
+    for _ in range(3):
+        with torch.cuda.stream(s):            # (replay() launches on the current stream)
+            graph.replay()
+        for _ in range(6):
+            O.lib().orc_sw_step(C.byref(op), g.nx, *it.box(), *[H[n] for n in cur + old], *scratch, *[H[n] for n in new])
+            for n in new:
+                assert O.exchange_all([H[n]], [g.nx], [oc]) == 0
+            if filtered:
+                for c, nw, o in zip(cur, new, old):
+                    O.sw_kernel("time_smooth", False, g.nx, it.box(), H[o], [H[c], H[nw], H[o]], alpha)
+            cur, old, new = rotate(cur, old, new)
+    torch.cuda.synchronize()
+    assert L.dlesm_wait_timed_out(0) == 0
+    for n in names:
+        assert np.array_equal(F[n].get_data(), H[n]), n
+    del graph
+    D._cabi.check(L.dlesm_halo_plan_destroy(plan))
+    g._halo_plan = None

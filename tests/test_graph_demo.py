@@ -42,12 +42,17 @@ def test_graph_demo_builds_and_refuses_to_run_without_a_device(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
 @pytest.mark.parametrize("nx,ny,nsteps", [(500, 300, 8), (130, 7, 6)])
-def test_graph_replay_equals_stepwise_and_the_oracle(tmp_path, nx, ny, nsteps):
+def test_graph_replay_equals_stepwise_and_the_oracle(tmp_path, nx, ny, nsteps, transport):
+    """transport = peer: the plan's mailboxes connected first -- the captured steps hold no RCCL call, their sequence numbers
+    advance on the device from replay to replay"""
     exe = _build(tmp_path)
-    p = subprocess.run([exe, str(nx), str(ny), str(nsteps)], env=_env(), capture_output=True, text=True, timeout=300)
+    p = subprocess.run([exe, str(nx), str(ny), str(nsteps)] + (["peer"] if transport == "peer" else []), env=_env(),
+                       capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     g = {ln.split()[1]: ln.split()[2:] for ln in p.stdout.splitlines() if ln.startswith("G: ")}
+    assert g["transport"] == ["mailboxes" if transport == "peer" else "rccl"]
     assert g["stepwise"] == g["graph"], p.stdout          # the printed 17 digits: bit for bit
     ld, nyarr = O.grid_extents(nx + 2, ny + 2)
     assert [int(v) for v in g["grid"]] == [ld, nyarr]
