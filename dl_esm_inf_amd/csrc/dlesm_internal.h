@@ -213,7 +213,8 @@ struct PeerJob {
     // what the neighbours get: strips of the frame, each into a PEER's mailbox (parity of this step) + that peer's flag
     struct Out { int i0, j0, ni, nj; double *dst; unsigned long long *flag; } out[MAXM];
     int nout;
-    unsigned long long seq;       // stored to every out[k].flag when the last frame workgroup is done
+    unsigned long long seq;       // the operation's number as the HOST counts it (its parity picked the mailbox halves above); what the
+                                  // last frame workgroup stores to every out[k].flag is the device's number, peer_seq_load(seqw, seq)
     unsigned long long *seqw;     // the plan's sequence words on the device (peer_seq_load): the number the kernels USE
     unsigned long long wait_ticks;   // bound of the wait (remote_wait_ticks(); 0 = none)
     int *timed_out;

@@ -165,8 +165,8 @@ def test_time_loop_over_the_mailboxes(D, nx, ny, alignment, nsteps, chain):
 
 def test_eight_direction_steps_and_refusals(D):
     """j5_dm_corners=1: the four corner messages travel through the mailboxes too (halos then equal a full exchange);
-    what the transport does not take is refused in words: a second connect, a mailbox for another field count, a
-    capture into a graph"""
+    what the transport does not take is refused in words: a second connect, a mailbox for another field count
+    (captures into a graph are taken since the sequence numbers moved to the device: test_mailbox_steps_captured_into_a_graph)"""
     import torch
     L, g, x, y, plan, oc = _setup(D, 257, 63, 64)
     it = x.internal
