@@ -460,6 +460,20 @@ def shallow_water_unfused(D, torch, stream, g, F, prm, tile, steps, fused_ms):
         e1.record(stream)
     stream.synchronize()
     ts = e0.elapsed_time(e1) / reps
+    # each kernel beside the linear sweep of ITS stream count, same arrays, same process (2, 3 or 4 arrays read + 1 written):
+    # the last thing this leg does with the intermediates (the sweeps write sums into cu)
+    ceilings = {}
+    try:
+        srcs = [F[n].data for n in ("p", "u", "v", "h")]
+        for nread in (2, 3, 4):
+            cc = copy_ceiling(D, torch, stream, srcs[:nread], [F["cu"].data], g.nx * g.ny)
+            ceilings[nread] = cc["best_gbs"]
+        for name, rec in per.items():
+            nread = SW_KERNEL_BYTES[name] // 8 - 1
+            rec["copy_ceiling_gbs"] = ceilings[nread]
+            rec["frac_of_copy_ceiling"] = round(rec["gbs"] / ceilings[nread], 4)
+    except Exception as e:                                   # noqa: BLE001  (a diagnostic must not cost the leg)
+        ceilings = {"error": f"{type(e).__name__}: {e}"}
     return {"workload": f"the same step as SEVEN launches, one per GOcean kernel (what an unmodified generated PSy layer "
                         f"runs), {tile}x{tile} fp64", "steps": steps,
             "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),
@@ -469,8 +483,10 @@ def shallow_water_unfused(D, torch, stream, g, F, prm, tile, steps, fused_ms):
                          "algorithmic_bytes_per_launch_sequence": 224 * cells,
                          "kernel": "swk_tile<compute_{cu,cv,z,h,unew,vnew,pnew}>"},
             "per_kernel": per,
+            "per_kernel_copy_ceilings_gbs": {f"{k}_read_1_written": v for k, v in ceilings.items()} if "error" not in ceilings else ceilings,
             "time_smooth": {"ms": round(ts, 5), "bytes_per_cell": 32, "gbs": round(32 * cells / (ts * 1e-3) / 1e9, 1),
-                            "frac": round(32 * cells / (ts * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                            "frac": round(32 * cells / (ts * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            **({"frac_of_copy_ceiling": round(32 * cells / (ts * 1e-3) / 1e9 / ceilings[3], 4)} if 3 in ceilings else {})},
             "fusion_speedup": round(ms / fused_ms, 3)}
 
 
