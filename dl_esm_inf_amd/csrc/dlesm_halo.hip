@@ -1814,6 +1814,84 @@ __global__ void unpack_gathered_k(const double *__restrict__ recv, long slot, co
     }
 }
 
+// End of round 3: the DESTINATION of the pack is one dense block, and so is the destination of the unpack of a box as wide
+// as the global domain (one rank; 1 x Q meshes).  A sweep that is linear in the destination -- thread t <-> destination pair
+// t, 256-thread workgroups front to back, exactly the shape of the copy that sets the ceiling -- keeps every store
+// workgroup full and 4 KiB-aligned; the source is read at whatever 8-byte alignment it has, rows one pitch apart (an even
+// row length: no pair straddles two rows).  util_gather_linear = 0 restores the row segments.
+template <bool NTS>
+__global__ __launch_bounds__(256) void pack_inner_linear_k(const double *__restrict__ f, int ld, int x0, int y0, int nx, size_t n2,
+                                                           size_t slot, double *__restrict__ send)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // destination pair
+    if (t < n2) {
+        const size_t e = 2 * t, j = e / (unsigned)nx;
+        const int i = (int)(e - j * (unsigned)nx);
+        const d2v v = *(const rs_d2a8 *)(f + (size_t)(y0 + (long)j) * ld + x0 + i);
+        if (NTS) __builtin_nontemporal_store(v, (d2v *)send + t);
+        else ((d2v *)send)[t] = v;
+    } else {                                                              // the rest of the slot (tiles are uneven): zeroed
+        if (2 * t < slot) send[2 * t] = 0.0;
+        if (2 * t + 1 < slot) send[2 * t + 1] = 0.0;
+    }
+}
+
+// The pack of a box that is NOT as wide as its rows reads a stream with a gap per row, and a read stream with gaps is served
+// like a store stream with gaps (scripts/store_probe.hip): ~73 % however the destination is indexed.  So the pack reads the rows
+// WHOLE -- linear in the SOURCE, thread t <-> source pair t of rows y0 .. y0+h-1 with their padding, aligned 16-byte loads front
+// to back -- and writes only what lies in the box.  A box that starts at an odd element (internal%xstart = 2, the usual case)
+// makes destination pair (e, e+1) the UPPER half of one source pair and the LOWER half of the next: one wave shift (DPP) brings
+// it over, lane 63 fetches it (an L2 hit), and the stores stay 16 bytes wide and aligned (even box width).
+template <bool ODD, bool NTS>
+__global__ __launch_bounds__(256) void pack_inner_srclinear_k(const double *__restrict__ f, int ld, int x0, int y0, int nx, int h,
+                                                              unsigned copy_blocks, size_t slot, double *__restrict__ send)
+{
+    if (blockIdx.x >= copy_blocks) {                         // the rest of the slot (tiles are uneven): zeroed
+        const size_t z = (size_t)nx * h + ((size_t)(blockIdx.x - copy_blocks) * 256 + threadIdx.x) * 2;
+        if (z < slot) send[z] = 0.0;
+        if (z + 1 < slot) send[z + 1] = 0.0;
+        return;
+    }
+    const unsigned hp = (unsigned)ld / 2;                    // pairs per row (>= 256: a workgroup touches at most two rows)
+    const size_t first = (size_t)blockIdx.x * 256;
+    size_t j = first / hp;
+    unsigned pp = (unsigned)(first - j * hp) + threadIdx.x;
+    if (pp >= hp) pp -= hp, j++;
+    const bool live = j < (size_t)h;
+    if (!live) j = (size_t)h - 1;                            // (every lane of a wave takes part in the shift below)
+    const double *row = f + ((size_t)y0 + j) * ld;
+    const int e = 2 * (int)pp, x1 = x0 + nx - 1;
+    const d2v v = *(const d2v *)(row + e);
+    double lo, hi;
+    int el;                                                   // element of the row that `lo` is
+    if (ODD) {
+        double nxt = from_upper<true>(v.x);                  // lane + 1's lower element = element e + 2 of this row
+        if ((threadIdx.x & 63) == 63) nxt = pp + 1 < hp ? row[e + 2] : 0.0;
+        lo = v.y, hi = nxt, el = e + 1;
+    } else {
+        lo = v.x, hi = v.y, el = e;
+    }
+    const bool m0 = live && el >= x0 && el <= x1, m1 = live && el + 1 >= x0 && el + 1 <= x1;
+    double *dst = send + j * (size_t)nx + (el - x0);
+    if (m0 && m1) {
+        if (NTS) __builtin_nontemporal_store(d2v{lo, hi}, (d2v *)dst);
+        else *(d2v *)dst = d2v{lo, hi};
+    } else {
+        if (m0) dst[0] = lo;
+        if (m1) dst[1] = hi;
+    }
+}
+
+// n2 pairs from src to dst, both 16-byte aligned: a received box that is as wide as the global array
+template <bool NTS>
+__global__ __launch_bounds__(256) void copy_pairs_k(const double *__restrict__ src, double *__restrict__ dst, size_t n2)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n2) return;
+    if (NTS) __builtin_nontemporal_store(((const d2v *)src)[t], (d2v *)dst + t);
+    else ((d2v *)dst)[t] = ((const d2v *)src)[t];
+}
+
 extern "C" int dlesm_pack_inner_f64(const double *field, int ld, int ny, int xstart, int xstop, int ystart,
                                     int ystop, double *send, long slot, void *stream)
 {
@@ -1824,6 +1902,35 @@ extern "C" int dlesm_pack_inner_f64(const double *field, int ld, int ny, int xst
     const long n = nx > 0 && h > 0 ? (long)nx * h : 0;
     DLESM_REQUIRE(slot >= n, "slot of %ld doubles for a %dx%d region", slot, nx, h);
     if (slot == 0) return DLESM_OK;
+    const int glin = tuning("util_rowseg", 1) ? tuning("util_gather_linear", 1) : 0;     // 1: linear in the source (whole rows read), 2: in the destination
+    if (glin == 1 && n > 0 && nx % 2 == 0 && ld % 2 == 0 && ld >= 512 && nx >= ld / 2 && (uintptr_t)field % 16 == 0 &&
+        (uintptr_t)send % 16 == 0) {
+        const size_t copy_blocks = ((size_t)(ld / 2) * h + 255) / 256, zero_blocks = ((size_t)(slot - n) + 511) / 512;
+        if (copy_blocks + zero_blocks < ((size_t)1 << 31)) {
+            const bool odd = (xstart - 1) % 2 != 0, nt = nt_stores_for(nx, 0, h - 1) != 0;
+#define DLESM_PACKSL(OO, NN) hipLaunchKernelGGL((pack_inner_srclinear_k<OO, NN>), dim3((unsigned)(copy_blocks + zero_blocks)), dim3(256), 0, \
+                                                (hipStream_t)stream, field, ld, xstart - 1, ystart - 1, nx, h, (unsigned)copy_blocks, (size_t)slot, send)
+            if (odd && nt) DLESM_PACKSL(true, true);
+            else if (odd) DLESM_PACKSL(true, false);
+            else if (nt) DLESM_PACKSL(false, true);
+            else DLESM_PACKSL(false, false);
+#undef DLESM_PACKSL
+            DLESM_HIP_TRY(hipGetLastError());
+            return DLESM_OK;
+        }
+    }
+    if (glin == 2 && n > 0 && nx % 2 == 0 && (uintptr_t)field % 8 == 0 && (uintptr_t)send % 16 == 0 &&
+        ((size_t)slot + 1) / 2 < ((size_t)1 << 31) * 256) {
+        const size_t pairs = ((size_t)slot + 1) / 2;
+        if (nt_stores_for(nx, 0, h - 1))
+            hipLaunchKernelGGL(pack_inner_linear_k<true>, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, field,
+                               ld, xstart - 1, ystart - 1, nx, (size_t)n / 2, (size_t)slot, send);
+        else
+            hipLaunchKernelGGL(pack_inner_linear_k<false>, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, field,
+                               ld, xstart - 1, ystart - 1, nx, (size_t)n / 2, (size_t)slot, send);
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
     if ((uintptr_t)field % 8 == 0 && (uintptr_t)send % 16 == 0 && (n == 0 || nx >= ROWSEG_MIN_NX) && tuning("util_rowseg", 1)) {
         int segs = 1, segp = 64;
         if (n > 0) rowseg_split(nx, tuning("util_segp", 256), &segs, &segp);
@@ -1866,8 +1973,32 @@ extern "C" int dlesm_unpack_gathered_f64(const double *recv, long slot, const dl
         if (h > tallest) tallest = h;
     }
     if (widest == 0) return DLESM_OK;
-    GBox *dboxes = nullptr;
     hipStream_t s = (hipStream_t)stream;
+    {   // every box as wide as the global array (one rank, 1 x Q meshes): each is one contiguous block on both sides
+        bool linear = tuning("util_rowseg", 1) && tuning("util_gather_linear", 1) && (uintptr_t)recv % 16 == 0 && (uintptr_t)global % 16 == 0;
+        for (int r = 0; r < nranks && linear; r++) {
+            const GBox &b = boxes[r];
+            if ((long)b.w * b.h == 0) continue;
+            linear = b.w == d->global_nx && b.x0 == 0 && ((long)b.w * b.h) % 2 == 0 && ((long)r * slot) % 2 == 0 &&
+                     ((long)b.y0 * d->global_nx) % 2 == 0;
+        }
+        if (linear) {
+            const bool nt = nt_stores_for(d->global_nx, 0, d->global_ny - 1) != 0;
+            for (int r = 0; r < nranks; r++) {
+                const GBox &b = boxes[r];
+                const size_t n2 = (size_t)b.w * b.h / 2;
+                if (n2 == 0) continue;
+                const double *src = recv + (size_t)r * slot;
+                double *dst = global + (size_t)b.y0 * d->global_nx;
+                if (nt) hipLaunchKernelGGL(copy_pairs_k<true>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, src, dst, n2);
+                else hipLaunchKernelGGL(copy_pairs_k<false>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, src, dst, n2);
+            }
+            DLESM_HIP_TRY(hipGetLastError());
+            DLESM_HIP_TRY(hipStreamSynchronize(s));       // (the entry returns with the copy done, as the table form below does)
+            return DLESM_OK;
+        }
+    }
+    GBox *dboxes = nullptr;
     DLESM_HIP_TRY(hipMalloc((void **)&dboxes, boxes.size() * sizeof(GBox)));
     hipError_t e = hipMemcpyAsync(dboxes, boxes.data(), boxes.size() * sizeof(GBox), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {

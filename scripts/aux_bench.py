@@ -87,3 +87,14 @@ timed("  pack of a box that starts on a 16-byte boundary", lambda: L.dlesm_pack_
     a.device_ptr, g.nx, g.ny, 1, tile, it.ystart, it.ystop, C.c_void_p(send.data_ptr()), slot, sp), 16)
 timed("gather: unpack_gathered (1 rank)", lambda: L.dlesm_unpack_gathered_f64(
     C.c_void_p(send.data_ptr()), slot, C.byref(pd._info), pd.subdomains, 1, C.c_void_p(glob.data_ptr()), sp), 16, n=10)
+# the pack linear in the dense destination (util_gather_linear = 2), then both copies as row segments (0): what the
+# source-linear pack and the contiguous unpack replaced
+L.dlesm_set_tuning(b"util_gather_linear", 2)
+timed("gather: pack_inner, linear in the destination", lambda: L.dlesm_pack_inner_f64(
+    a.device_ptr, g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop, C.c_void_p(send.data_ptr()), slot, sp), 16)
+L.dlesm_set_tuning(b"util_gather_linear", 0)
+timed("gather: pack_inner, row segments", lambda: L.dlesm_pack_inner_f64(
+    a.device_ptr, g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop, C.c_void_p(send.data_ptr()), slot, sp), 16)
+timed("gather: unpack_gathered (1 rank), row segments", lambda: L.dlesm_unpack_gathered_f64(
+    C.c_void_p(send.data_ptr()), slot, C.byref(pd._info), pd.subdomains, 1, C.c_void_p(glob.data_ptr()), sp), 16, n=10)
+L.dlesm_set_tuning(b"util_gather_linear", 1)

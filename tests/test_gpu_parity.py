@@ -359,14 +359,20 @@ def test_one_rank_gather_of_a_field_whose_internal_region_is_not_the_domain(D, a
         a.gather_inner_data()
 
 
-@pytest.mark.parametrize("nx,ny,nranks", [(10, 10, 4), (10, 10, 6), (37, 29, 6), (64, 48, 8), (13, 13, 9), (4500, 40, 2)])
-def test_device_gather_pack_and_unpack_for_uneven_tiles(D, nx, ny, nranks):
+@pytest.mark.parametrize("linear", [1, 2, 0])
+@pytest.mark.parametrize("nx,ny,nranks", [(10, 10, 4), (10, 10, 6), (37, 29, 6), (64, 48, 8), (13, 13, 9), (4500, 40, 2),
+                                           (40, 4500, 2), (64, 48, 1), (9, 8, 2), (4096, 66, 1), (38, 4501, 3), (2048, 2050, 4)])
+def test_device_gather_pack_and_unpack_for_uneven_tiles(D, nx, ny, nranks, linear):
     """gather_inner_data's device legs for 4-9 ranks on one GPU: every rank's internal region packed
     into its fixed-size slot (dlesm_pack_inner_f64, the slot is the LARGEST tile: tiles are uneven,
     field_mod.f90:1348-1351), all slots unpacked into the global array in one launch
-    (dlesm_unpack_gathered_f64) -- against the oracle's gather of the same per-rank fields"""
+    (dlesm_unpack_gathered_f64) -- against the oracle's gather of the same per-rank fields.  linear (util_gather_linear,
+    default 1): tiles of even width in rows of >= 512 elements are packed by a sweep that is linear in the SOURCE (whole rows
+    read, the box written; odd box starts through a wave shift), boxes as wide as the global array (one rank, 1 x Q meshes)
+    are unpacked as contiguous blocks; 2: the pack linear in the dense destination; 0: the row segments for everything"""
     import torch
     L = D._cabi.lib()
+    L.dlesm_set_tuning(b"util_gather_linear", linear)
     d, subs = O.decompose(nx, ny, nranks)
     ext = [O.grid_extents(s.glob.nx, s.glob.ny, 2) for s in subs]
     rng = np.random.default_rng(nranks)
@@ -386,6 +392,14 @@ def test_device_gather_pack_and_unpack_for_uneven_tiles(D, nx, ny, nranks):
         got = recv[r * slot:(r + 1) * slot].cpu().numpy()
         assert np.array_equal(got[:n], fields[r][it.ystart - 1:it.ystop, it.xstart - 1:it.xstop].ravel())
         assert np.all(got[n:] == 0.0)
+        if it.nx % 2 == 0 and r == 0:        # a box that starts on an even element (no wave shift in the source-linear form)
+            tmp = torch.full((slot,), -7.0, dtype=torch.float64, device="cuda")
+            D._cabi.check(L.dlesm_pack_inner_f64(C.c_void_p(f.data_ptr()), ext[r][0], ext[r][1], it.xstart - 1, it.xstop - 1,
+                                                 it.ystart, it.ystop, C.c_void_p(tmp.data_ptr()), slot, None))
+            torch.cuda.synchronize()
+            got = tmp.cpu().numpy()
+            assert np.array_equal(got[:n], fields[r][it.ystart - 1:it.ystop, it.xstart - 2:it.xstop - 1].ravel())
+            assert np.all(got[n:] == 0.0)
     glob = torch.full((ny, nx), -9.0, dtype=torch.float64, device="cuda")
     D._cabi.check(L.dlesm_unpack_gathered_f64(C.c_void_p(recv.data_ptr()), slot, C.byref(pd._info), pd.subdomains,
                                               nranks, C.c_void_p(glob.data_ptr()), None))
@@ -394,6 +408,7 @@ def test_device_gather_pack_and_unpack_for_uneven_tiles(D, nx, ny, nranks):
     # a slot that is too small is refused, not overrun
     assert L.dlesm_unpack_gathered_f64(C.c_void_p(recv.data_ptr()), 1, C.byref(pd._info), pd.subdomains, nranks,
                                        C.c_void_p(glob.data_ptr()), None) == D._cabi.EINVAL
+    L.dlesm_set_tuning(b"util_gather_linear", 1)
 
 
 def test_copy_patch_periodic_halos(D):
