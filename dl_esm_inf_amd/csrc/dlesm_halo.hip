@@ -1836,10 +1836,10 @@ __global__ __launch_bounds__(256) void pack_inner_linear_k(const double *__restr
     }
 }
 
-// The pack of a box that is NOT as wide as its rows reads a stream with a gap per row, and a read stream with gaps is served
-// like a store stream with gaps (scripts/store_probe.hip): ~73 % however the destination is indexed.  So the pack reads the rows
-// WHOLE -- linear in the SOURCE, thread t <-> source pair t of rows y0 .. y0+h-1 with their padding, aligned 16-byte loads front
-// to back -- and writes only what lies in the box.  A box that starts at an odd element (internal%xstart = 2, the usual case)
+// The pack of a box that is not as wide as its rows ran at 71-73 % of the HBM peak however the DESTINATION was indexed (row
+// segments, or linearly, with the source pairs loaded at their 8-byte alignment).  This form reads the rows WHOLE -- linear in the
+// SOURCE, thread t <-> source pair t of rows y0 .. y0+h-1 with their padding, ALIGNED 16-byte loads front to back -- and writes
+// only what lies in the box: 76.8 % at 16384^2.  A box that starts at an odd element (internal%xstart = 2, the usual case)
 // makes destination pair (e, e+1) the UPPER half of one source pair and the LOWER half of the next: one wave shift (DPP) brings
 // it over, lane 63 fetches it (an L2 hit), and the stores stay 16 bytes wide and aligned (even box width).
 template <bool ODD, bool NTS>

@@ -256,7 +256,8 @@ def test_jacobi5_full_size_properties(D, n, alignment):
 
 
 # --------------------------------------------------------------------------- checksum / fill / copy
-@pytest.mark.parametrize("nx,ny,alignment", [(4, 10, None), (256, 256, None), (1000, 333, 64)])
+@pytest.mark.parametrize("nx,ny,alignment", [(4, 10, None), (256, 256, None), (1000, 333, 64), (4100, 37, 64), (2200, 21, 2),
+                                             (3000, 5, None), (2046, 3, 2)])
 def test_checksum_matches_oracle(D, nx, ny, alignment):
     g = _grid(D, nx, ny, alignment)
     f = D.r2d_field(g, D.GO_T_POINTS)
@@ -279,6 +280,12 @@ def test_checksum_matches_oracle(D, nx, ny, alignment):
     _set_tuning(D, util_rowseg=0)
     assert abs(D.field_checksum(f) - want) <= 1e-12 * abs(want)
     _set_tuning(D, util_rowseg=1)
+    # sub-boxes of the same rows: one that leaves out a column, one of half the width
+    for box in ((it.xstart + 1, it.xstop, it.ystart, it.ystop), (it.xstart, max(it.xstart, it.xstop // 2), it.ystart, it.ystop)):
+        sub = f.get_data()[box[2] - 1:box[3], box[0] - 1:box[1]]
+        val = C.c_double()
+        D._cabi.check(L.dlesm_checksum_f64(f.device_ptr, g.nx, g.ny, *box, C.byref(val), None))
+        assert abs(val.value - float(np.abs(sub).sum())) <= 1e-12 * max(1.0, float(np.abs(sub).sum()))
 
 
 @pytest.mark.parametrize("ld,ny,box", [(40, 31, (1, 40, 1, 31)), (37, 12, (2, 36, 3, 11)), (4163, 7, (2, 4162, 1, 7)),
