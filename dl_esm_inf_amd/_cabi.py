@@ -168,6 +168,7 @@ PROTOTYPES = {
     "dlesm_halo_plan_join": (_i, [_vp, _vp]),
     "dlesm_comm_init_mailbox": (_i, [_vp, _i, _i]),
     "dlesm_comm_is_mailbox": (_i, []),
+    "dlesm_ipc_open_retries": (_i, []),
     "dlesm_board_nonce": (_i, [_vp]),
     "dlesm_board_open": (_i, [_vp, _i, _i]),
     "dlesm_board_is_open": (_i, []),

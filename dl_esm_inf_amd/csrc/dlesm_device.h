@@ -32,6 +32,32 @@ __device__ __forceinline__ void frame_index(long t, int x0, int x1, int y0, int 
     }
 }
 
+// ---- hand-overs between workgroups that are running at the same time ------------------------------------------------
+// The two halves of the form MI355X_MICROARCH.md lists under "Valid forms" (per-XCD L2s are not coherent with each
+// other, a CU's L1 is never refreshed by another CU's stores).  SYSTEM: the bytes were written by, or are meant for,
+// another GPU (mailboxes); otherwise agent scope.
+//   consumer: ONE lane polls with relaxed loads; when the poll has matched it calls handover_acquire() -- the acquire
+//             fence (buffer_inv) and the s_waitcnt that waits for the invalidate to have completed -- and the workgroup
+//             then passes __syncthreads() before any lane loads the handed-over bytes;
+//   producer: every storing wave `s_waitcnt vmcnt(0)`, __syncthreads(), then ONE lane calls handover_release() -- the
+//             release fence (buffer_wbl2) and an s_waitcnt written as inline asm, which the compiler cannot drop as it
+//             does the fence's own wait when it believes the lane's vmcnt scoreboard empty (the guide's "Compiler
+//             hazard": our publishing lane has just used a returned atomic) -- and only then stores the flag, relaxed.
+template <bool SYSTEM>
+__device__ __forceinline__ void handover_acquire()
+{
+    if constexpr (SYSTEM) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <bool SYSTEM>
+__device__ __forceinline__ void handover_release()
+{
+    if constexpr (SYSTEM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---- a box swept as ROW SEGMENTS (the utility kernels: fill, initial condition, checksum, gather copies) ----------
 // One workgroup (256 threads) = one segment of one row of the box: up to SEG_PAIRS 16-byte pairs, four per thread.  The
 // pairs of a row are anchored on the 128-BYTE LINE that holds the row's first element (elements of the line that lie

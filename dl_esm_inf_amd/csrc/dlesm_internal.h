@@ -150,6 +150,7 @@ struct FrameJob {
     unsigned long long halo_seq;  // 0: no wait
     unsigned long long halo_wait_ticks;   // bound of that wait (remote_wait_ticks(); 0 = none)
     int *timed_out;               // pinned host word raised by a wait that gives up
+    int acquire;                  // dm_acquire (default 1): one agent-scope acquire behind that wait (handover_acquire)
     // pipelined steps: the west/east halo columns of `in` have NOT been unpacked into the field; they
     // are read from the receive buffer of the previous exchange (contiguous), strip by strip
     struct HaloCol { int i, j0, nj; long off; } hs[FramePack::MAXS]; // 0-based halo column, first row, rows, slot
@@ -274,6 +275,7 @@ struct SwFrameJob {
     unsigned long long halo_seq;  // 0: no wait
     unsigned long long halo_wait_ticks;   // bound of that wait (remote_wait_ticks(); 0 = none)
     int *timed_out;
+    int acquire;                  // dm_acquire, as FrameJob
     int smooth;                   // != 0: the Asselin filter of the old level folded in (time_smooth, coefficient alpha)
     double alpha;
     // peer transport: the pack strips are the neighbours' mailboxes (system-scope stores) and the last frame workgroup

@@ -372,6 +372,12 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_framed(const double *__rest
                     break;
                 }
             }
+            // The halos were written by kernels that have ENDED (RCCL's receive, the unpack: plain stores, released at
+            // device scope when they ended, the flag stored by a later kernel), but this workgroup was already running:
+            // one acquire, waited for, then the barrier -- the guide's consumer form.  What it invalidates is this CU's
+            // L1 (and what this XCD's L2 may hold of lines other XCDs have rewritten); it costs ~2 us once per frame
+            // workgroup, beside the sweep (dm_acquire = 0 takes it out, for measurements only).
+            if (fj.acquire) handover_acquire<false>();
         }
         __syncthreads();
     }
@@ -425,20 +431,26 @@ __device__ __forceinline__ void peer_frame_cell(long t, const double *__restrict
     }
 }
 
-// The arrival flag of a message.  fenced = false (default): a relaxed system-scope store behind payload stores that are
-// themselves write-through system-scope stores, drained -- enough for uncached mailboxes by what the hardware does, and what the
-// loop-back / multi-process measurements are quoted for.  fenced = true (tuning mailbox_fences = 1): a system-scope RELEASE store
-// (L2 write-back first) here and an ACQUIRE fence behind the wait: the flag -> payload order is then a release / acquire pair of
-// the memory model too, at 2-5 % of a 4096^2 step (the write-back and the invalidate land in the middle of the sweep).
-__device__ __forceinline__ void peer_raise_flag(unsigned long long *flag, unsigned long long seq, bool fenced)
+// The arrival flags of an operation's messages, raised by the ONE lane that has seen every storing workgroup report (each
+// behind its waves' `s_waitcnt vmcnt(0)` and its barrier).  fenced (tuning mailbox_fences, default 1): the guide's producer
+// form at system scope -- release fence, an asm wait the compiler cannot drop, then the relaxed flag stores -- and on the
+// other side one acquire behind the poll (peer_wait_flags): flag -> payload is then a release / acquire pair of the memory
+// model whatever the page attributes of the mailbox.  fenced = 0 (measurements; the form the round-3 loop-back figures were
+// taken with): the flags follow payload stores that are write-through system-scope stores into uncached memory, drained --
+// enough by what the hardware was seen to do on ONE GPU, not a guarantee, and never exercised across xGMI.
+__device__ __forceinline__ void peer_publish(bool fenced)
 {
-    if (fenced) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    else __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (fenced) handover_release<true>();
+}
+__device__ __forceinline__ void peer_raise_flag(unsigned long long *flag, unsigned long long seq)
+{
+    __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// bounded wait of ONE thread for n arrival flags (system scope: they are stored by other GPUs)
+// bounded wait of ONE thread for n arrival flags (system scope: they are stored by other GPUs); the caller's workgroup
+// passes __syncthreads() before any of its lanes loads a strip
 __device__ __forceinline__ void peer_wait_flags(const PeerJob::In *in, int n, unsigned long long seq,
-                                                unsigned long long ticks, int *timed_out, bool fenced = false)
+                                                unsigned long long ticks, int *timed_out, bool fenced)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (int k = 0; k < n; k++)
@@ -449,7 +461,7 @@ __device__ __forceinline__ void peer_wait_flags(const PeerJob::In *in, int n, un
                 return;
             }
         }
-    if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // see peer_raise_flag
+    if (fenced) handover_acquire<true>();      // see peer_publish
 }
 
 template <int VEC, int R, int NT>
@@ -490,8 +502,9 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
         if (done == (unsigned)pj.nblocks - 1) {
             __hip_atomic_store(pj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long seq = peer_seq_load(pj.seqw, pj.seq);
+            peer_publish(pj.fenced != 0);
             for (int k = 0; k < pj.nout; k++)
-                peer_raise_flag(pj.out[k].flag, seq, pj.fenced != 0);
+                peer_raise_flag(pj.out[k].flag, seq);
             peer_seq_advance(pj.seqw, seq, pj.timed_out);
         }
     }
@@ -537,8 +550,9 @@ __global__ __launch_bounds__(256) void peer_pack_k(PeerOuts out, PeerFields fiel
         if (done == total - 1) {
             __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long dseq = peer_seq_load(seqw, seq);
+            peer_publish(fenced != 0);
             for (int k = 0; k < out.n; k++)
-                peer_raise_flag(out.s[k].flag, dseq, fenced != 0);
+                peer_raise_flag(out.s[k].flag, dseq);
             peer_seq_advance(seqw, dseq, sticky);
         }
     }
@@ -571,8 +585,9 @@ __global__ __launch_bounds__(256) void peer_exchange_k(PeerOuts out, PeerStrips 
             if (done == total - 1) {
                 __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long dseq = peer_seq_load(seqw, seq);
+                peer_publish(fenced != 0);
                 for (int q = 0; q < out.n; q++)
-                    peer_raise_flag(out.s[q].flag, dseq, fenced != 0);
+                    peer_raise_flag(out.s[q].flag, dseq);
                 peer_seq_advance(seqw, dseq, timed_out);
             }
         }
@@ -595,7 +610,8 @@ struct PeerFlagList { unsigned long long *f[PeerJob::MAXM]; };
 __global__ void peer_flags_set_k(PeerFlagList fl, int n, unsigned long long seq, unsigned long long *seqw, int *sticky, int fenced)
 {
     const unsigned long long dseq = peer_seq_load(seqw, seq);
-    if (threadIdx.x < (unsigned)n) peer_raise_flag(fl.f[threadIdx.x], dseq, fenced != 0);
+    peer_publish(fenced != 0);            // (behind a kernel boundary the payload is already released; kept for one form everywhere)
+    if (threadIdx.x < (unsigned)n) peer_raise_flag(fl.f[threadIdx.x], dseq);
     __syncthreads();                      // (one workgroup: every lane has read the word before lane 0 moves the other one)
     if (threadIdx.x == 0) peer_seq_advance(seqw, dseq, sticky);
 }
@@ -987,13 +1003,16 @@ __global__ void frame_flag_wait(const unsigned long long *flag, unsigned long lo
 {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+    // relaxed polls, ONE acquire behind them (polling with acquire loads is the guide's "correct, 2-3x slower per hop");
+    // whatever this stream runs next starts behind a kernel boundary anyway
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
         __builtin_amdgcn_s_sleep(64);
         if (max_ticks && __builtin_amdgcn_s_memrealtime() - t0 > max_ticks) {        // 100 MHz counter; 0 = no limit
             __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
     }
+    handover_acquire<false>();
 }
 
 __global__ void flag_set(unsigned long long *flag, unsigned long long seq)
@@ -1150,7 +1169,7 @@ int launch_peer_unpack(const PeerStrips &st, unsigned long long seq, const unsig
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = fields[k];
     hipLaunchKernelGGL(peer_unpack_k, dim3(parts, st.n, nf), dim3(256), 0, s, st, seq, seqw, pf, ld, remote_wait_ticks(), timed_out,
-                       tuning("mailbox_fences", 0));
+                       tuning("mailbox_fences", 1));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -1166,7 +1185,7 @@ int launch_peer_pack(const PeerOuts &out, const double *const *fields, int nf, i
     if (parts > 16) parts = 16;
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = const_cast<double *>(fields[k]);
-    hipLaunchKernelGGL(peer_pack_k, dim3(parts, out.n, nf), dim3(256), 0, s, out, pf, ld, counter, seq, seqw, sticky, tuning("mailbox_fences", 0));
+    hipLaunchKernelGGL(peer_pack_k, dim3(parts, out.n, nf), dim3(256), 0, s, out, pf, ld, counter, seq, seqw, sticky, tuning("mailbox_fences", 1));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -1184,7 +1203,7 @@ int launch_peer_exchange(const PeerOuts &out, const PeerStrips &in, double *cons
     PeerFields pf{};
     for (int k = 0; k < nf; k++) pf.f[k] = fields[k];
     hipLaunchKernelGGL(peer_exchange_k, dim3(parts, std::max(out.n, in.n), 2 * nf), dim3(256), 0, s, out, in, pf, nf, ld, counter,
-                       seq, seqw, remote_wait_ticks(), timed_out, tuning("mailbox_fences", 0));
+                       seq, seqw, remote_wait_ticks(), timed_out, tuning("mailbox_fences", 1));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }
@@ -1196,7 +1215,7 @@ int launch_peer_flags_set(unsigned long long *const *flags, int n, unsigned long
     DLESM_REQUIRE(n <= PeerJob::MAXM, "%d peer flags", n);
     PeerFlagList fl{};
     for (int k = 0; k < n; k++) fl.f[k] = flags[k];
-    hipLaunchKernelGGL(peer_flags_set_k, dim3(1), dim3(64), 0, s, fl, n, seq, seqw, sticky, tuning("mailbox_fences", 0));
+    hipLaunchKernelGGL(peer_flags_set_k, dim3(1), dim3(64), 0, s, fl, n, seq, seqw, sticky, tuning("mailbox_fences", 1));
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
 }

@@ -217,8 +217,12 @@ struct Board {
 
 int board_write(const std::string &name, const void *data, size_t bytes)
 {
-    const std::string tmp = name + ".tmp";
-    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    // /dev/shm is world-writable and the names are predictable: the temporary file must be a NEW regular file of ours --
+    // O_EXCL | O_NOFOLLOW refuse a pre-created file and a planted symbolic link alike (a leftover of a killed run of this
+    // very process name is removed first; rename(2) then replaces the final name atomically, whatever sits there)
+    const std::string tmp = name + ".tmp." + std::to_string((long)getpid());
+    (void)unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
     if (fd < 0) return fail(DLESM_EINVAL, "board: cannot create %s: %s", tmp.c_str(), strerror(errno));
     size_t done = 0;
     while (done < bytes) {
@@ -239,7 +243,7 @@ int board_write(const std::string &name, const void *data, size_t bytes)
 int board_aborted(char *why, size_t n)
 {
     const std::string note = g_board.prefix + ".abort";
-    const int fd = open(note.c_str(), O_RDONLY);
+    const int fd = open(note.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
     if (fd < 0) return 0;
     const ssize_t r = read(fd, why, n - 1);
     close(fd);
@@ -256,7 +260,7 @@ int board_read(const std::string &name, void *data, size_t bytes, int timeout_ms
             char why[400];
             if (board_aborted(why, sizeof why)) return fail(DLESM_EABORT, "board: another rank stopped the job: %s", why);
         }
-        const int fd = open(name.c_str(), O_RDONLY);
+        const int fd = open(name.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
         if (fd >= 0) {
             size_t done = 0;
             while (done < bytes) {
@@ -349,6 +353,12 @@ extern "C" int dlesm_board_abort(const char *msg)
     char text[400];
     snprintf(text, sizeof text, "rank %d: %.300s", g_board.rank, msg ? msg : "");
     (void)board_write(g_board.prefix + ".abort", text, strlen(text));
+    // this rank is leaving: its outstanding operation files are of no use to anybody (the others fail on the note).  The
+    // note itself has to outlive this process -- the waiting ranks read it after we are gone; the LAST of them to fail on it
+    // cannot be told apart from the first, so the note stays (a few hundred bytes under a session name no other job will
+    // ever use, dlesm_board_nonce) unless a rank of the job still gets to dlesm_board_close, which removes it.
+    for (long op = g_board.op > 1 ? g_board.op - 1 : 1; op <= g_board.op; op++) unlink(board_name(op, g_board.rank).c_str());
+    g_board = Board{};
     return DLESM_OK;
 }
 
@@ -374,6 +384,11 @@ extern "C" int dlesm_board_close(void)
         }
     }
     (void)a;
+    if (rc) {      // a failed close (a rank stopped, a time-out): nothing of THIS rank stays behind all the same
+        for (long op = g_board.op > 2 ? g_board.op - 2 : 1; op <= g_board.op; op++) unlink(board_name(op, g_board.rank).c_str());
+        unlink((g_board.prefix + ".done." + std::to_string(g_board.rank)).c_str());
+        if (g_board.rank == 0) unlink((g_board.prefix + ".abort").c_str());
+    }
     g_board = Board{};
     return rc;
 }

@@ -158,10 +158,10 @@ extern "C" int dlesm_finalize(void)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_ready) return DLESM_OK;
     (void)hipDeviceSynchronize();
-    if (g_wait_timed_out) {
-        (void)hipHostFree(g_wait_timed_out);
-        g_wait_timed_out = nullptr;
-    }
+    // The time-out word is NOT freed: halo plans cache its address (and hand it to kernels), and a plan may outlive a
+    // finalize / re-initialise pair of the host program.  Four bytes of pinned memory for the life of the process; the
+    // word is cleared so that a re-initialised library starts clean.
+    if (g_wait_timed_out) *(volatile int *)g_wait_timed_out = 0;
     invalidate_concurrency_probe();
     if (g_side) (void)hipStreamDestroy(g_side);
     if (g_xfer) (void)hipStreamDestroy(g_xfer);

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
                     break;
                 }
             }
-            if (fj.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            if (fj.fenced) handover_acquire<true>();      // (peer_wait_flags' form, dlesm_kernels.hip)
         }
         __syncthreads();
         const long n = (long)m.ni * m.nj;
@@ -309,6 +309,7 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
                     break;
                 }
             }
+            if (fj.acquire) handover_acquire<false>();    // the consumer form of jacobi5_tile_framed: acquire, waited for, barrier
         }
         __syncthreads();
     }
@@ -346,10 +347,9 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
             __hip_atomic_store(fj.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (fj.npeer) {       // peer transport: the neighbours' arrival flags, then this plan's sequence words (peer_seq_load)
                 const unsigned long long seq = peer_seq_load(fj.seqw, fj.seq);
-                for (int k = 0; k < fj.npeer; k++) {
-                    if (fj.fenced) __hip_atomic_store(fj.peer_flag[k], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    else __hip_atomic_store(fj.peer_flag[k], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
+                if (fj.fenced) handover_release<true>();      // (peer_publish's form, dlesm_kernels.hip)
+                for (int k = 0; k < fj.npeer; k++)
+                    __hip_atomic_store(fj.peer_flag[k], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 peer_seq_advance(fj.seqw, seq, fj.timed_out);
             } else
                 __hip_atomic_store(fj.flag, fj.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

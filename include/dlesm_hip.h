@@ -446,11 +446,16 @@ int dlesm_comm_init(const void *id, int nranks, int rank0);
  * DLESM_MAILBOX_FIELDS fields, default 3), halo exchanges and the distributed Jacobi / shallow-water steps go through them
  * (stores over xGMI, see the peer transport below), dlesm_global_sum_f64 is eight bytes per rank over the host-side board
  * (summed in rank order, the same bits on every rank), dlesm_gather_f64 / dlesm_gather_inner_f64 copy every rank's
- * block straight into the root's buffer through an IPC mapping.  `id`: a session name all ranks share, made by rank 0 with
+ * block straight into a gather buffer the library owns on the root (exported once, mapped once per job by each rank).  `id`: a session name all ranks share, made by rank 0 with
  * dlesm_board_nonce and handed round like an RCCL id (dlesm_rendezvous_publish / _fetch, a torch store ...).
  * Replaces MPI_Init + the MPI calls of parallel_utils_mod.f90:77-255 for a job of one process per GPU on one node. */
 int dlesm_comm_init_mailbox(const void *id, int nranks, int rank0);
 int dlesm_comm_is_mailbox(void);
+/* How often, in this process, hipIpcOpenMemHandle had to be tried again (or a gather fell back to host memory).  Processes
+ * of one node import in turns (flock on /dev/shm/dlesm-ipc-<uid>.lock), so anything but 0 is a finding: every occurrence is
+ * also logged to stderr with the HIP error name.  IPC mappings need HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of every
+ * process on this driver ("Environment"). */
+int dlesm_ipc_open_retries(void);
 int dlesm_comm_finalize(void);
 int dlesm_comm_rank(void);   /* 0-based, -1 before init */
 int dlesm_comm_size(void);

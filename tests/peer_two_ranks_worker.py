@@ -59,7 +59,7 @@ gld, gny = NX + 2, NY + 2
 G = O.hash_field(SEED, gny, gld, 0, 0, 1, NX + 2, 1, NY + 2)
 H = G.copy()
 history = [G.copy()]
-for _ in range(2 * STEPS + 4):           # joined steps, time-loop steps, two replays of a two-step graph
+for _ in range(2 * STEPS + 4 + 4):       # joined steps, time-loop steps, two replays of a two-step graph, four steps of the masks test
     O.jacobi5(G, H, gld, 2, NX + 1, 2, NY + 1)
     G, H = H, G
     history.append(G.copy())
@@ -150,12 +150,15 @@ if MODE == "mailbox":
         print(f"ERROR rank {rank}: field_checksum {cs!r}, the undivided field gives {want_cs!r}", flush=True)
         errors += 1
     # (2) gather_inner_data: every rank copies its block straight into the root's buffer through an IPC mapping
-    glob = a.gather_inner_data()
-    if rank == 0:
-        bad = int(np.count_nonzero(glob != history[n][1:NY + 1, 1:NX + 1]))
-        if bad:
-            print(f"ERROR rank 0: gather_inner_data: {bad} cells differ from the undivided field", flush=True)
-            errors += bad
+    #     (round 4: into a gather buffer the library owns on the root, mapped ONCE per job by every other rank -- the
+    #     second gather, of the previous time level, goes through the mapping the first one opened)
+    for fld, lvl in ((a, n), (b, n - 1)):
+        glob = fld.gather_inner_data()
+        if rank == 0:
+            bad = int(np.count_nonzero(glob != history[lvl][1:NY + 1, 1:NX + 1]))
+            if bad:
+                print(f"ERROR rank 0: gather_inner_data of time level {lvl}: {bad} cells differ from the undivided field", flush=True)
+                errors += bad
     # (3) the distributed shallow-water step (three fields per message, eight directions) against the oracle's step on
     #     the undivided domain; nine fields, leapfrog rotation, the joined and the time-loop entry alternately
     names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
@@ -204,6 +207,67 @@ if MODE == "mailbox":
         if bad:
             print(f"ERROR rank {rank}: halo_exchange_multi of six fields, field {k}: {bad} cells differ", flush=True)
             errors += bad
+# ---- operations of ONE plan whose direction masks DIFFER ---------------------------------------------
+# The reference's comm1..comm4 allow one-directional exchanges, and an edges-only Jacobi step shares its plan with full
+# eight-direction exchanges.  Round `rnd`: operation N = a time-loop step whose JOIN comes late on one rank (the victim
+# sleeps between step and join, so the strips of N sit unread in its mailbox half N & 1), operation N+1 = an exchange in ONE
+# direction (three of the victim's four neighbours receive nothing from it), operation N+2 = an exchange of all eight,
+# which stores into the half N & 1 again.  A neighbour that did not have to wait for the victim in N+1 would overwrite the
+# strips of N before the victim has read them: every operation therefore raises and awaits the flags of ALL the plan's
+# messages (peer_in_strips, dlesm_halo.hip).  Three different fields, so that a strip of the wrong operation shows.
+import time  # noqa: E402
+f2, f3 = D.r2d_field(g, D.GO_T_POINTS), D.r2d_field(g, D.GO_T_POINTS)
+edge_of_bit = {0: (it.xstop + 1, it.xstop + 1, it.ystart, it.ystop),      # Iplus: the east halo column
+               1: (it.xstart - 1, it.xstart - 1, it.ystart, it.ystop),    # Iminus: the west one
+               2: (it.xstart, it.xstop, it.ystop + 1, it.ystop + 1),      # Jplus: the north halo row
+               3: (it.xstart, it.xstop, it.ystart - 1, it.ystart - 1)}    # Jminus: the south one
+
+
+def halo_want(seed_wrong, seed_right, boxes):
+    """the field as it must look (this rank's window incl. the halo ring): `wrong` everywhere, `right` on the internal
+    region and on the cells of `boxes` (local 1-based inclusive) that lie inside the global interior"""
+    right = O.hash_field(seed_right, NY + 2, NX + 2, 0, 0, 1, NX + 2, 1, NY + 2)
+    want = O.hash_field(seed_wrong, NY + 2, NX + 2, 0, 0, 1, NX + 2, 1, NY + 2)
+    want[gy0 + it.ystart - 1:gy0 + it.ystop, gx0 + it.xstart - 1:gx0 + it.xstop] = \
+        right[gy0 + it.ystart - 1:gy0 + it.ystop, gx0 + it.xstart - 1:gx0 + it.xstop]
+    for (x0, x1, y0, y1) in boxes:
+        ga, gb = max(gy0 + y0 - 1, 1), min(gy0 + y1 - 1, NY)            # rows / columns of the global (padded) array
+        gc, gd = max(gx0 + x0 - 1, 1), min(gx0 + x1 - 1, NX)
+        if ga <= gb and gc <= gd:
+            want[ga:gb + 1, gc:gd + 1] = right[ga:gb + 1, gc:gd + 1]
+    return want[gy0 + it.ystart - 2:gy0 + it.ystop + 1, gx0 + it.xstart - 2:gx0 + it.xstop + 1]
+
+
+for rnd in range(4):
+    victim, bit = rnd % world, rnd % 4
+    for k, f in ((2, f2), (3, f3)):
+        D.psy.hash_init(f, SEED + 600 + 10 * rnd + k, box=ring, stream=s)
+        D.psy.hash_init(f, SEED + 700 + 10 * rnd + k, box=it, stream=s)
+    D.psy.invoke_jacobi5_dm_pipelined(b, a, stream=s)               # operation N (edges only): its halos stay in the mailbox ...
+    if rank == victim:
+        s.synchronize()
+        time.sleep(0.25)                                            # ... unread on the victim, while the others run ahead
+    D.psy.halo_join(g, stream=s)
+    f2.halo_exchange(1, stream=s, dirs=1 << bit)                    # operation N+1: one direction
+    f3.halo_exchange(1, stream=s)                                   # operation N+2: all eight, the mailbox half of N again
+    s.synchronize()
+    a, b = b, a
+    n += 1
+    errors += check(a, n, f"time-loop step whose join came late on rank {victim} (masks vary, round {rnd})")
+    win = (slice(it.ystart - 2, it.ystop + 1), slice(it.xstart - 2, it.xstop + 1))
+    bad = int(np.count_nonzero(f2.get_data()[win] != halo_want(SEED + 600 + 10 * rnd + 2, SEED + 700 + 10 * rnd + 2, [edge_of_bit[bit]])))
+    if bad:
+        print(f"ERROR rank {rank}: one-direction exchange (bit {bit}), round {rnd}: {bad} cells differ", flush=True)
+        errors += bad
+    bad = int(np.count_nonzero(f3.get_data()[win] != halo_want(SEED + 600 + 10 * rnd + 3, SEED + 700 + 10 * rnd + 3, [ring.box()])))
+    if bad:
+        print(f"ERROR rank {rank}: eight-direction exchange behind it, round {rnd}: {bad} cells differ", flush=True)
+        errors += bad
+del f2, f3
+if L.dlesm_ipc_open_retries():
+    print(f"ERROR rank {rank}: hipIpcOpenMemHandle had to be retried (or a gather fell back to host memory) "
+          f"{L.dlesm_ipc_open_retries()} time(s) although the importers take turns -- see the log above", flush=True)
+    errors += 1
 if L.dlesm_wait_timed_out(0):
     print(f"ERROR rank {rank}: a device-side wait gave up", flush=True)
     errors += 1
