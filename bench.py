@@ -48,6 +48,15 @@ def parse():
                     help="skip the 8192^2-per-GPU weak-scaling object (BASELINE configs[4]'s tile)")
     ap.add_argument("--no-peer", action="store_true", help="skip the peer-transport object (N > 1: beside RCCL on the "
                     "weak-scaling tile; N = 1: 4096^2 loop-back)")
+    ap.add_argument("--dm-form", choices=["timeloop", "joined", "safe"], default="timeloop",
+                    help="N > 1: form of the distributed step the headline times.  timeloop (default): one launch per step, "
+                         "the exchange of step k joined on the device by step k+1's frame workgroups behind ONE agent-scope "
+                         "acquire (the consumer form of MI355X_MICROARCH.md), one host join closing the loop; joined: every "
+                         "step joins its own exchange on the caller's stream (kernel boundaries only); safe: DLESM_DM_SAFE -- "
+                         "frame in its own launch, events, unpack into the field.  (--tune dm_acquire=0 is the round-3 "
+                         "time loop without the acquire: faster by a fraction of a percent, not guide-valid.)")
+    ap.add_argument("--selfcheck-steps", type=int, default=50,
+                    help="N > 1: back-to-back steps of the timed form compared with as many stencil + exchange steps before timing")
     ap.add_argument("--force-dm-leg", action="store_true",
                     help="rehearsal on 1 GPU: run the N>1 secondary leg with a 1-rank process group")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
@@ -205,6 +214,9 @@ def copy_ceiling(D, torch, stream, srcs, dsts, n_doubles, launches=MIN_SECONDARY
     `frac_of_copy_ceiling` is measured against the better of the two.  srcs / dsts: device tensors (clobbered: dsts)."""
     L = D._cabi.lib()
     nr, nw = len(srcs), len(dsts)
+    # 16-byte elements: an odd element count (the reference's DEFAULT alignment: ld 16387 x 16387 rows) is rounded down --
+    # one double of 268 million does not move the rate, and an odd count made the leg fail in round 3
+    n_doubles &= ~1
     sp = (C.c_void_p * nr)(*[t.data_ptr() for t in srcs])
     dp = (C.c_void_p * nw)(*[t.data_ptr() for t in dsts])
     out = {"sweep": f"{nr} arrays read + {nw} written, {n_doubles * 8 / 1e6:.0f} MB each, linear, 16 B per thread per array",
@@ -673,7 +685,7 @@ def temporal_blocking_dm(D, torch, dist, tile, P, Q, stream, steps, T=TB_STEPS):
             "kernel": f"jacobi5xt_tile<{T},{XT_ROWS[T]},dpp> + one depth-{T} RCCL exchange per launch"}
 
 
-def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, steps, warmup=10):
+def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, steps, warmup=10, dm_form="timeloop"):
     """Secondary object on EVERY line (N = 1, 2, 4, 8): the Jacobi step on the per-GPU tile BASELINE
     configs[4] names (8192^2), global domain (tile*P) x (tile*Q) cut by go_decompose, RCCL halo exchange
     hidden behind the interior when N > 1 -- so that t(1)/t(N) for THAT tile can be read off the driver's
@@ -685,7 +697,8 @@ def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, step
     assert (it.nx, it.ny) == (tile, tile) and (g.decomp.nx, g.decomp.ny) == (P, Q)
     # N > 1: the time-loop form of the distributed step -- the exchange of step k is joined by step k+1's
     # frame workgroups on the device, the caller's stream carries one launch per step; ONE join closes the loop
-    step = D.psy.invoke_jacobi5_dm_pipelined if world > 1 else D.psy.invoke_jacobi5
+    dm_step = D.psy.invoke_jacobi5_dm_pipelined if dm_form == "timeloop" else D.psy.invoke_jacobi5_dm
+    step = dm_step if world > 1 else D.psy.invoke_jacobi5
     L = D._cabi.lib()
     with torch.cuda.stream(stream):
         D.psy.hash_init(a, SEED, stream=stream)
@@ -707,7 +720,7 @@ def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, step
             D.copy_field(a, y, stream=stream)
             D.psy.invoke_jacobi5(y, x, stream=stream)
             y.halo_exchange(1, stream=stream, dirs=D._cabi.DIRS_EDGES_ONLY)
-            D.psy.invoke_jacobi5_dm_pipelined(b, a, stream=stream)
+            dm_step(b, a, stream=stream)
             D.psy.halo_join(g, stream=stream)
         stream.synchronize()
         ok = torch.tensor([1 if torch.equal(b.data, y.data) else 0], device="cuda")
@@ -756,7 +769,7 @@ def weak_scaling_tile(D, torch, dist, tile, alignment, world, P, Q, stream, step
            "DL_ESM_ALIGNMENT": alignment, "steps": steps, "value": round(cells * steps / wall / 1e6, 1),
            "unit": "Mcells/s", "ms_per_step": round(ms, 5), "hbm_gbs_per_gpu": round(gbs, 1),
            "frac_of_hbm_peak_per_gpu": round(gbs / HBM_PEAK_GBS, 4), "scaling": "weak",
-           "halo_exchange": "rccl send/recv of the four edges, overlapped" if world > 1 else "none (1 tile)",
+           "halo_exchange": f"rccl send/recv of the four edges, overlapped ({dm_form} form)" if world > 1 else "none (1 tile)",
            "dm_step_equals_stencil_plus_exchange": same, "checksum": D.field_checksum(a)}
     del a, b
     torch.cuda.empty_cache()
@@ -900,7 +913,7 @@ def peer_transport_dm(D, torch, dist, tile, alignment, world, P, Q, stream, step
         L.dlesm_set_tuning(b"dm_wait_seconds", old_wait or 600)      # (0 = the key was unset: the default)
         L.dlesm_set_tuning(b"dm_peer", 1)
         L.dlesm_set_tuning(b"dm_peer_exchange", 1)
-        L.dlesm_set_tuning(b"mailbox_fences", 0)
+        L.dlesm_set_tuning(b"mailbox_fences", 1)
         return obj
 
     err = None
@@ -935,24 +948,17 @@ def peer_transport_dm(D, torch, dist, tile, alignment, world, P, Q, stream, step
         gave_up = bool(L.dlesm_wait_timed_out(0))
         return gave_up, (not gave_up) and bool(torch.equal(x1.data, x2.data))
 
-    # first as measured everywhere (relaxed flag stores behind drained write-through payload stores); if that does not
-    # reproduce the RCCL halos on this machine, once more with the release / acquire fences (mailbox_fences = 1)
-    fences = 0
+    # the library's default: arrival flags as release / acquire pairs (mailbox_fences = 1, round 4)
+    fences = 1
     gave_up, same = selfcheck()
     ok = agree(same)
-    if not ok and agree(not gave_up):
-        fences = 1
-        L.dlesm_set_tuning(b"mailbox_fences", 1)
-        gave_up, same = selfcheck()
-        ok = agree(same)
     if not ok:
-        L.dlesm_set_tuning(b"mailbox_fences", 0)
         if not agree(not gave_up):      # acknowledge, so that the rest of the run still has a library to talk to
             D._cabi.check(L.dlesm_halo_plan_destroy(g._halo_plan))
             g._halo_plan = None
             L.dlesm_wait_timed_out(1)
         return leave({"error": "a wait for a neighbour's arrival flag gave up" if gave_up else
-                      "steps over the mailboxes differ from stencil + RCCL exchange on some rank (with and without fences)",
+                      "steps over the mailboxes differ from stencil + RCCL exchange on some rank",
                       "equals_stencil_plus_rccl_exchange": False})
     with torch.cuda.stream(stream):
         D.copy_field(a, b, stream=stream)
@@ -1110,6 +1116,8 @@ def main():
     for kv in args.tune:
         k, v = kv.split("=")
         L.dlesm_set_tuning(k.encode(), int(v))     # returns the previous value
+    if args.dm_form == "safe":
+        L.dlesm_set_tuning(b"dm_safe", 1)
     D._cabi.check(L.dlesm_init(local))             # after the knobs: the side stream's priority is one of them
     os.environ["DL_ESM_ALIGNMENT"] = str(args.alignment)
     stage(rank, world, "RCCL communicator (dlesm_comm_init)")
@@ -1136,9 +1144,11 @@ def main():
         a.halo_exchange(1, stream=stream)    # `in` starts with valid halos
     stream.synchronize()
 
-    # N > 1: the time-loop form of the distributed step -- the exchange of step k is joined by step k+1's
-    # frame workgroups on the device, the caller's stream carries one launch per step; ONE join closes the loop
-    step = D.psy.invoke_jacobi5_dm_pipelined if world > 1 else D.psy.invoke_jacobi5
+    # N > 1, --dm-form timeloop: the exchange of step k is joined by step k+1's frame workgroups on the device (flag poll,
+    # one agent-scope acquire, barrier), the caller's stream carries one launch per step; ONE join closes the loop.
+    # joined / safe: every step joins its own exchange (the closing join then finds nothing pending).
+    dm_step = D.psy.invoke_jacobi5_dm_pipelined if args.dm_form == "timeloop" else D.psy.invoke_jacobi5_dm
+    step = dm_step if world > 1 else D.psy.invoke_jacobi5
     stage(rank, world, "planning call")
     planned = False
     if not args.no_plan:
@@ -1168,21 +1178,30 @@ def main():
             D.psy.invoke_jacobi5_multi(o, i, fused, stream=stream)
     launches, warm_launches = args.steps // fused, -(-args.warmup // fused)
 
-    # N > 1: before timing anything, three overlapped distributed steps must reproduce, bit for
-    # bit on every rank, three plain "stencil, then halo exchange" steps from the same state
+    # N > 1: before timing anything, `--selfcheck-steps` (50) distributed steps in the TIMED form, issued back to back exactly
+    # as the timed loop issues them -- so that the halo lines each step reads are as warm in L1 / L2 as they will be there;
+    # a three-step check from a cold start cannot see a hand-over that only fails warm -- must reproduce, bit for bit on every
+    # rank, as many plain "stencil, then halo exchange" steps (kernel boundaries only) from the same state
     selfcheck = None
     dm_safe_fallback = False
+    a0 = None
     if world > 1 or args.force_dm_leg:
+        a0 = D.r2d_field(grid, D.GO_T_POINTS)                # the initial state, halos included: start of the dm_safe re-run below
+        with torch.cuda.stream(stream):
+            D.copy_field(a, a0, stream=stream)
+        nchk = max(3, args.selfcheck_steps)
+
         def run_selfcheck():
             x1, y1 = D.r2d_field(grid, D.GO_T_POINTS), D.r2d_field(grid, D.GO_T_POINTS)
             x2, y2 = D.r2d_field(grid, D.GO_T_POINTS), D.r2d_field(grid, D.GO_T_POINTS)
             with torch.cuda.stream(stream):
                 for f in (x1, y1, x2, y2):
                     D.copy_field(a, f, stream=stream)
-                for k in range(3):
-                    # two steps in the time-loop form (device-side join), the last one in the joined form
-                    (D.psy.invoke_jacobi5_dm_pipelined if k < 2 else D.psy.invoke_jacobi5_dm)(y1, x1, stream=stream)
+                for k in range(nchk):
+                    dm_step(y1, x1, stream=stream)
                     x1, y1 = y1, x1
+                D.psy.halo_join(grid, stream=stream)
+                for k in range(nchk):
                     D.psy.invoke_jacobi5(y2, x2, stream=stream)
                     y2.halo_exchange(1, stream=stream, dirs=D._cabi.DIRS_EDGES_ONLY)   # what the 5-point step exchanges
                     x2, y2 = y2, x2
@@ -1193,19 +1212,19 @@ def main():
             torch.cuda.empty_cache()
             return bool(int(ok[0]))
 
-        stage(rank, world, "self-check: distributed steps == stencil + exchange")
+        stage(rank, world, f"self-check: {nchk} distributed steps ({args.dm_form}) == {nchk} x (stencil + exchange)")
         selfcheck = run_selfcheck()
-        if not selfcheck:
-            # The one-launch / time-loop forms hand over through device flags and device-scope loads.
-            # If they do not reproduce stencil + exchange on this machine, fall back -- on every rank, the decision
-            # is collective -- to the conservative forms (events and kernel boundaries only, DLESM_DM_SAFE) and check
-            # again; the line then says so and the process leaves non-zero AFTER printing it.
+        if not selfcheck and args.dm_form != "safe":
+            # The one-launch / time-loop forms hand over through device flags.  If they do not reproduce
+            # stencil + exchange on this machine, fall back -- on every rank, the decision is collective -- to the
+            # conservative forms (events and kernel boundaries only, DLESM_DM_SAFE) and check again; the line then says so
+            # and the process leaves non-zero AFTER printing it.
             stage(rank, world, "self-check FAILED in the one-launch forms: falling back to DLESM_DM_SAFE")
             L.dlesm_set_tuning(b"dm_safe", 1)
             dm_safe_fallback = True
             selfcheck = run_selfcheck()
-            if not selfcheck:
-                raise SystemExit("bench.py: distributed step differs from stencil + exchange, in the conservative form too")
+        if not selfcheck:
+            raise SystemExit("bench.py: distributed step differs from stencil + exchange, in the conservative form too")
 
     def barrier():
         torch.cuda.synchronize()
@@ -1241,6 +1260,31 @@ def main():
         wall, ev_ms = float(tt[0]), float(tt[1])
     stage(rank, world, "global checksum (ncclAllReduce)")
     checksum = D.field_checksum(a)
+    # N > 1: the SAME warm-up + timed steps once more from the same initial state in the conservative form (DLESM_DM_SAFE:
+    # own frame launch, events, unpack into the field -- kernel boundaries only), untimed: the field the timed loop left
+    # behind must equal it bit for bit on every rank, and so must the global checksum
+    dm_rerun = None
+    if a0 is not None:
+        stage(rank, world, "re-run of the timed steps in DLESM_DM_SAFE, compared with what the timed loop left")
+        was_safe = L.dlesm_set_tuning(b"dm_safe", 1)
+        x, y = a0, D.r2d_field(grid, D.GO_T_POINTS)
+        with torch.cuda.stream(stream):
+            D.copy_field(x, y, stream=stream)
+            for _ in range(warm_launches + launches):
+                D.psy.invoke_jacobi5_dm(y, x, stream=stream)
+                x, y = y, x
+        stream.synchronize()
+        it_ = a.internal
+        cut = lambda f: f.data[it_.ystart - 2:it_.ystop + 1, it_.xstart - 2:it_.xstop + 1]      # noqa: E731  (internal + halo ring)
+        ok = torch.tensor([1 if torch.equal(cut(x), cut(a)) else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        cs_safe = D.field_checksum(x)
+        dm_rerun = {"steps": warm_launches + launches, "fields_equal_on_every_rank": bool(int(ok[0])),
+                    "checksum_dm_safe": cs_safe, "checksums_equal": cs_safe == checksum}
+        L.dlesm_set_tuning(b"dm_safe", was_safe)
+        del x, y, a0
+        a0 = None
+        torch.cuda.empty_cache()
     stage(rank, world, "secondary legs")
 
     cells_step = args.tile * args.tile * world
@@ -1262,13 +1306,20 @@ def main():
                                       "rccl send/recv of the four edges, overlapped; ") +
                                      ("CONSERVATIVE form (DLESM_DM_SAFE: own frame launch, event joins) after a failed "
                                       "self-check of the one-launch forms" if dm_safe_fallback else
-                                      "time-loop form (device-side join)"))
+                                      {"timeloop": "time-loop form: step k+1's frame workgroups join step k's exchange on the "
+                                                   "device -- flag poll, one agent-scope acquire + s_waitcnt, barrier, then the "
+                                                   "halo loads" + ("" if "dm_acquire=0" not in args.tune else
+                                                                   " -- ACQUIRE SWITCHED OFF (--tune dm_acquire=0): not a guide-valid hand-over"),
+                                       "joined": "joined form: every step joins its exchange on the caller's stream (flag-wait kernel)",
+                                       "safe": "DLESM_DM_SAFE: own frame launch, events, unpack into the field"}[args.dm_form]))
                    if world > 1 else "none (1 tile)",
                    "launch_shape": "planned (dlesm_stencil5_autotune_f64, before the warm-up)" if planned else "rule",
                    "planned_waves_tiles_rows_ntstores": list(shape)},
         "hbm_gbs_per_gpu": round(achieved, 1),
         "checksum": checksum, "dm_step_equals_stencil_plus_exchange": selfcheck,
-        "dm_safe_fallback": dm_safe_fallback,
+        "dm_form": args.dm_form if (world > 1 or args.force_dm_leg) else None,
+        "dm_selfcheck_steps": max(3, args.selfcheck_steps) if selfcheck is not None else None,
+        "dm_safe_fallback": dm_safe_fallback, "dm_safe_rerun": dm_rerun,
         # (the contract's vocabulary for the headline object is "hbm" | "mfma"; a tile small enough to ping-pong inside
         #  the 256 MiB Infinity Cache -- never the BASELINE headline -- is flagged beside it)
         "roofline": {"bound": "hbm", "infinity_cache_resident": grid.nx * grid.ny * 8 < (150 << 20),
@@ -1319,7 +1370,7 @@ def main():
             if not args.no_weak_tile and args.tile != WEAK_TILE:
                 stage(rank, world, "secondary leg: 8192^2 weak-scaling tile")
                 out["weak_scaling_tile"] = weak_scaling_tile(D, torch, dist, WEAK_TILE, args.alignment, world, P, Q,
-                                                             stream, args.steps)
+                                                             stream, args.steps, dm_form=args.dm_form)
             if not args.no_temporal_blocking:
                 stage(rank, world, "secondary leg: fused 8-step distributed form")
                 out["temporal_blocking"] = temporal_blocking_dm(D, torch, dist, args.tile, P, Q, stream, args.steps)
@@ -1412,6 +1463,8 @@ def main():
         sys.exit(5)
     if dm_safe_fallback:
         sys.exit(7)
+    if dm_rerun and not (dm_rerun["fields_equal_on_every_rank"] and dm_rerun["checksums_equal"]):
+        sys.exit(8)                                          # the timed loop and its DLESM_DM_SAFE re-run disagree: the line says so
 
 
 if __name__ == "__main__":

@@ -66,8 +66,23 @@ def test_bench_line_and_secondary_legs():
     assert f["config"]["fused_steps_per_launch"] == 4 and f["value"] > 0
 
 
+def test_reference_default_alignment():
+    """DL_ESM_ALIGNMENT unset is the reference's default (grid_mod.f90:349-369): ld = N + 3, odd for even N, so nx * ny is
+    odd -- round 3's `bench.py --alignment 1` left with status 5 because the copy-ceiling legs handed that odd count to a
+    sweep of 16-byte elements.  Every leg that times a copy ceiling must come back, headline and shallow-water alike."""
+    d = _bench("--alignment", "1", "--no-cpu-baseline", "--no-temporal-blocking", "--no-configs", "--no-weak-tile", "--no-peer")
+    assert d["config"]["ld"] % 2 == 1 and "secondary_legs_error" not in d, d.get("secondary_legs_error")
+    assert d["copy_ceiling"]["best_gbs"] > 0 and 0 < d["roofline"]["frac_of_copy_ceiling"] < 2, d["copy_ceiling"]
+    sw = d["shallow_water"]
+    assert "error" not in sw and sw["copy_ceiling"]["best_gbs"] > 0, sw
+    assert all("error" not in k and k["frac_of_copy_ceiling"] > 0 for k in sw["unfused"]["per_kernel"].values()), sw["unfused"]
+    assert "error" not in sw["with_time_smooth"] and sw["with_time_smooth"]["copy_ceiling"]["best_gbs"] > 0, sw["with_time_smooth"]
+
+
 def test_rehearsal_of_the_multi_gpu_secondary_leg():
     d = _bench("--force-dm-leg", "--no-cpu-baseline")
+    assert d["dm_form"] == "timeloop" and d["dm_selfcheck_steps"] == 50 and d["dm_step_equals_stencil_plus_exchange"] is True, d
+    assert d["dm_safe_rerun"]["fields_equal_on_every_rank"] is True and d["dm_safe_rerun"]["checksums_equal"] is True, d["dm_safe_rerun"]
     tb = d["temporal_blocking"]
     assert "error" not in tb, tb
     assert tb["halo_depth"] == 8 and tb["bit_identical_to_single_steps_plus_exchange"] is True
@@ -79,8 +94,8 @@ def test_rehearsal_of_the_multi_gpu_secondary_leg():
     assert sw["value"] > 0 and sw["dm_step_equals_step_plus_exchange"] is True, sw
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_multi_rank_bench_in_mailbox_mode(world):
+@pytest.mark.parametrize("world,form", [(2, "timeloop"), (4, "timeloop"), (2, "joined"), (2, "safe")])
+def test_multi_rank_bench_in_mailbox_mode(world, form):
     """`bench.py --gpus N` launched as the driver launches it (one process per rank, RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_* in the environment), N = 2 and 4 on the ONE GPU of this box: DLESM_TRANSPORT=mailbox takes the library to its
     mode without a communication library (RCCL refuses ranks that share a device), torch's group is gloo.  Every N > 1
@@ -99,7 +114,7 @@ def test_multi_rank_bench_in_mailbox_mode(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), DLESM_TRANSPORT="mailbox", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--tile", "2048",
-                                       "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], env=env,
+                                       "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--dm-form", form], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -117,6 +132,9 @@ def test_multi_rank_bench_in_mailbox_mode(world):
     d = json.loads(lines[0])
     assert KEYS - {"cpu_baseline"} <= set(d) and d["n_gpus"] == world and d["scaling"] == "weak" and d["value"] > 0, d
     assert d["dm_step_equals_stencil_plus_exchange"] is True and d["dm_safe_fallback"] is False, d
+    # round 4: the self-check is 50 back-to-back steps of the timed form; the timed loop's field == a DLESM_DM_SAFE re-run
+    assert d["dm_form"] == form and d["dm_selfcheck_steps"] == 50, d
+    assert d["dm_safe_rerun"]["fields_equal_on_every_rank"] is True and d["dm_safe_rerun"]["checksums_equal"] is True, d["dm_safe_rerun"]
     assert "MAILBOX MODE" in d["config"]["halo_exchange"] and d["config"]["decomposition"] in ("1x2", "2x2"), d["config"]
     assert "secondary_legs_error" not in d, d.get("secondary_legs_error")
     w, tb, sw = d["weak_scaling_tile"], d["temporal_blocking"], d["shallow_water_dm"]
