@@ -405,12 +405,25 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_framed(const double *__rest
 // payload -> flag is the one of jacobi5_tile_framed: every storing wave drains (`s_waitcnt vmcnt(0)`: the stores have
 // been acknowledged by the memory they went to), the workgroup's barrier, one device-scope counter increment per
 // workgroup, and the LAST arriver stores the flags.
-__device__ __forceinline__ void peer_frame_cell(long t, const double *__restrict__ in, double *__restrict__ out, int ld,
-                                                const PeerJob &pj)
+// 16 bytes into a mailbox with ONE system-scope store (`global_store_dwordx4 ... sc0 sc1`): over xGMI every store is its own
+// packet, and the guide prices an 8-byte sc1 store at 2.7x a 16-byte one per byte.  A volatile access through an
+// address-space-1 pointer is what the compiler lowers to exactly that instruction (checked in the ISA; a plain volatile
+// pointer gives flat_store); dst must be 16-byte aligned.
+typedef double pd2 __attribute__((ext_vector_type(2)));
+typedef double pd2a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void peer_store16(double *dst, double a, double b)
 {
-    int i, j;
-    frame_index(t, pj.fx0, pj.fx1, pj.fy0, pj.fy1, i, j);
-    const size_t o = (size_t)j * ld + i;
+    *(__attribute__((address_space(1))) volatile pd2 *)dst = pd2{a, b};
+}
+__device__ __forceinline__ void peer_store8(double *dst, double a)
+{
+    __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// one frame cell of the distributed Jacobi step: halo operands from the local mailbox while the previous step's strips
+// have not been unpacked (pj.virt), everything else from the field
+__device__ __forceinline__ double peer_cell_value(int i, int j, const double *__restrict__ in, int ld, const PeerJob &pj)
+{
     auto operand = [&](int oi, int oj, bool outside) {
         if (outside && pj.virt)
             for (int k = 0; k < pj.nin; k++) {
@@ -421,13 +434,72 @@ __device__ __forceinline__ void peer_frame_cell(long t, const double *__restrict
             }
         return in[(size_t)oj * ld + oi];          // inside the box, a fixed boundary cell, or halos already unpacked
     };
-    const double r = 0.25 * ((operand(i - 1, j, i == pj.fx0) + operand(i + 1, j, i == pj.fx1)) +
-                             (operand(i, j - 1, j == pj.fy0) + operand(i, j + 1, j == pj.fy1)));
-    out[o] = r;                                   // read by the next launch: an ordinary store
-    for (int k = 0; k < pj.nout; k++) {
-        const PeerJob::Out &m = pj.out[k];
-        if (i >= m.i0 && i < m.i0 + m.ni && j >= m.j0 && j < m.j0 + m.nj)     // the pack loop's order: j outer, i inner
-            __hip_atomic_store(m.dst + (size_t)(j - m.j0) * m.ni + (i - m.i0), r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return 0.25 * ((operand(i - 1, j, i == pj.fx0) + operand(i + 1, j, i == pj.fx1)) +
+                   (operand(i, j - 1, j == pj.fy0) + operand(i, j + 1, j == pj.fy1)));
+}
+
+// The frame workgroups of the peer step (round 4: WIDE stores into the neighbours' mailboxes).  Work items, numbered so
+// that the 64 items of a wave always lie in ONE section (sections are padded to the workgroup size):
+//   rows     south, north: an item = TWO adjacent cells of the row (i, i+1): one 16-byte store into out, and for every
+//            row strip that holds both at an even offset ONE 16-byte system-scope store into the neighbour's mailbox (a
+//            strip's slot starts on a 128-byte line); ragged ends and 1 x 1 corner strips take 8-byte stores;
+//   columns  west, east, over the FULL height (the two corner cells are computed again -- same operands, same bits -- so
+//            that a column strip is written by its column's lanes alone): an item = one cell, gathered at stride ld.  A
+//            column strip is contiguous in the mailbox (j order = the pack loop's order, parallel_comms_mod.f90:1678-1683),
+//            so the lane of an EVEN slot takes its upper neighbour's value by a wave shift (DPP, no LDS, no barrier) and
+//            stores both: a wave covers 512 bytes of the neighbour's memory with 32 stores instead of 64.
+// Per step and rank that halves the stores that cross xGMI: (w + h) 16-byte stores instead of 2 (w + h) 8-byte ones.
+// (A form that staged each column chunk in LDS and let half the lanes write it -- two barriers per turn, 8 KB of LDS on
+// every workgroup of the launch -- gave the same bits and cost the loop-back step 1 %; this one costs nothing.)
+__device__ __forceinline__ void peer_frame_wide(const double *__restrict__ in, double *__restrict__ out, int ld,
+                                                const PeerJob &pj, unsigned block)
+{
+    const int w = pj.fx1 - pj.fx0 + 1, h = pj.fy1 - pj.fy0 + 1, B = blockDim.x, tid = threadIdx.x, lane = tid & 63;
+    const int nrows = h > 1 ? 2 : 1, ncols = w > 1 ? 2 : 1;
+    const long rp = ((long)(w + 1) / 2 + B - 1) / B * B;         // pair items per row, padded to whole workgroup turns
+    const long cp = ((long)h + B - 1) / B * B;                   // cell items per column, likewise
+    const long row_items = nrows * rp, total = row_items + ncols * cp;
+    for (long base = (long)block * B; base < total; base += (long)pj.nblocks * B) {      // (uniform per workgroup)
+        if (base < row_items) {
+            const long t = base + tid;
+            const int r = (int)(t / rp), i = pj.fx0 + 2 * (int)(t - (long)r * rp), j = r == 0 ? pj.fy0 : pj.fy1;
+            const bool v0 = i <= pj.fx1, v1 = i + 1 <= pj.fx1;
+            if (!v0) continue;
+            const double a = peer_cell_value(i, j, in, ld, pj), b = v1 ? peer_cell_value(i + 1, j, in, ld, pj) : 0.0;
+            double *po = out + (size_t)j * ld + i;                // read by the next launch: ordinary stores
+            if (v1) *(pd2a8 *)po = pd2{a, b};
+            else po[0] = a;
+            for (int k = 0; k < pj.nout; k++) {
+                const PeerJob::Out &m = pj.out[k];
+                if (m.nj != 1 || j != m.j0) continue;             // (column strips: the column items below)
+                const bool in0 = i >= m.i0 && i < m.i0 + m.ni, in1 = v1 && i + 1 >= m.i0 && i + 1 < m.i0 + m.ni;
+                double *d = m.dst + (i - m.i0);
+                if (in0 && in1 && ((i - m.i0) & 1) == 0) peer_store16(d, a, b);
+                else {
+                    if (in0) peer_store8(d, a);
+                    if (in1) peer_store8(d + 1, b);
+                }
+            }
+        } else {
+            const long t = base - row_items + tid;
+            const int side = (int)(t / cp), i = side == 0 ? pj.fx0 : pj.fx1, j = pj.fy0 + (int)(t - (long)side * cp);
+            const bool valid = j <= pj.fy1;
+            const double v = valid ? peer_cell_value(i, j, in, ld, pj) : 0.0;
+            if (valid && j > pj.fy0 && j < pj.fy1) out[(size_t)j * ld + i] = v;   // (the corner cells are stored by the rows)
+            const double up = from_upper<true>(v);                // lane + 1's cell = row j + 1 (every lane of the wave is here)
+            for (int k = 0; k < pj.nout; k++) {
+                const PeerJob::Out &m = pj.out[k];
+                if (m.ni != 1 || m.nj == 1 || m.i0 != i) continue;
+                const int sl = j - m.j0;                         // this cell's slot in the strip
+                if (!valid || sl < 0 || sl >= m.nj) continue;
+                if ((sl & 1) == 0) {                             // even slot: 16 bytes with the upper neighbour, where there is one
+                    if (lane < 63 && j + 1 <= pj.fy1 && sl + 1 < m.nj) peer_store16(m.dst + sl, v, up);
+                    else peer_store8(m.dst + sl, v);
+                } else if (lane == 0 || sl == 0) {               // odd slot whose lower neighbour could not take it along
+                    peer_store8(m.dst + sl, v);
+                }
+            }
+        }
     }
 }
 
@@ -464,8 +536,11 @@ __device__ __forceinline__ void peer_wait_flags(const PeerJob::In *in, int n, un
     if (fenced) handover_acquire<true>();      // see peer_publish
 }
 
+// SGPR budget: a 256-thread workgroup is admitted 8 per CU only up to 80 SGPRs (82-96: 7; MI355X_MICROARCH.md, "Residency"),
+// and the occupancy of the whole launch -- the tile sweep included -- follows the kernel's count.  The frame code's message
+// tables took it to 86 and the 8192^2 loop-back step lost 0.9 %; capped, the compiler keeps the excess in VGPR lanes.
 template <int VEC, int R, int NT>
-__global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restrict__ in, double *__restrict__ out, int ld,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void jacobi5_tile_peer(const double *__restrict__ in, double *__restrict__ out, int ld,
                                                          int x0, int x1, int y0, int y1, int c_first, int nxw, int flags,
                                                          PeerJob pj)
 {
@@ -492,9 +567,7 @@ __global__ __launch_bounds__(1024) void jacobi5_tile_peer(const double *__restri
         if (threadIdx.x == 0) peer_wait_flags(pj.in, pj.nin, peer_seq_load(pj.seqw, pj.seq) - 1, pj.wait_ticks, pj.timed_out, pj.fenced != 0);   // (wait_seq == seq - 1)
         __syncthreads();
     }
-    const long total = frame_cells(pj.fx1 - pj.fx0 + 1, pj.fy1 - pj.fy0 + 1);
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)pj.nblocks * blockDim.x)
-        peer_frame_cell(t, in, out, ld, pj);
+    peer_frame_wide(in, out, ld, pj, blockIdx.x);
     __builtin_amdgcn_s_waitcnt(0);        // this wave's stores have been acknowledged ...
     __syncthreads();                      // ... and those of every wave of the group ...
     if (threadIdx.x == 0) {               // ... before the group is counted as done
