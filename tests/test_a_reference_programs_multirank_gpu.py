@@ -1,5 +1,5 @@
 """GPU test (-m gpu): the reference's OWN multi-rank test programs -- tests/dist_mem/{test_halos, test_gsum,
-test_reduction}.f90, compiled UNMODIFIED against this library's Fortran API layer (oracle/Makefile target `dropin`, built
+test_reduction}.f90, compiled UNMODIFIED against this library's Fortran API layer (tests/Makefile target `dropin`, built
 in the container that has /root/reference; the executables travel with the work tree like the library's .so) -- run
 with the rank counts and domain sizes of the reference's own Makefile (tests/dist_mem/Makefile:64-80: 10x4/np 2, 4x10/np 2,
 10x10/np 4 and 6; gsum 4x10/np 4, 6; reduction 10x10/np 4, 6).
@@ -22,7 +22,7 @@ import pytest
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
-DROP = os.path.join(ROOT, "oracle", "_dropin")
+DROP = os.path.join(ROOT, "tests", "_dropin")
 
 
 def _free_port():
@@ -36,7 +36,7 @@ def _run_ranks(exe, world, env_extra, args=()):
     assert not torch.cuda.is_initialized(), "run this file before any in-process GPU test"
     path = os.path.join(DROP, exe) if not os.path.isabs(exe) else exe
     if not os.path.exists(path):
-        pytest.skip(f"{path} not built (make -C oracle dropin, in a container that has /root/reference)")
+        pytest.skip(f"{path} not built (make -C tests dropin, in a container that has /root/reference)")
     port = _free_port()
     # a job token no earlier run can have used: a record left under the same port by a finished job is then never taken for ours
     job = f"pytest-{port}-{os.getpid()}-{time.time_ns()}"
