@@ -209,7 +209,7 @@ def jacobi_config(D, torch, stream, tile, alignment, steps, warmup=10):
 
 def copy_ceiling(D, torch, stream, srcs, dsts, n_doubles, launches=MIN_SECONDARY_LAUNCHES):
     """What a linear sweep with THIS many concurrent HBM streams reaches on THIS box, in THIS process: nread arrays
-    read once, nwrite arrays written once, nothing else (dlesm_stream_copy_f64: one 16-byte element per thread per
+    read once, nwrite arrays written once, nothing else (dlesm_lab_stream_copy_f64: one 16-byte element per thread per
     array, workgroups sweeping memory front to back), with default and with non-temporal stores.  The kernels'
     `frac_of_copy_ceiling` is measured against the better of the two.  srcs / dsts: device tensors (clobbered: dsts)."""
     L = D._cabi.lib()
@@ -228,7 +228,7 @@ def copy_ceiling(D, torch, stream, srcs, dsts, n_doubles, launches=MIN_SECONDARY
             for k in range(launches + 4):
                 if k == 4:
                     e0.record(stream)
-                D._cabi.check(L.dlesm_stream_copy_f64(nr, nw, sp, dp, n_doubles, nt, C.c_void_p(stream.cuda_stream)))
+                D._cabi.check_lab(D._cabi.lab().dlesm_lab_stream_copy_f64(nr, nw, sp, dp, n_doubles, nt, C.c_void_p(stream.cuda_stream)))
             e1.record(stream)
         stream.synchronize()
         ms = e0.elapsed_time(e1) / launches

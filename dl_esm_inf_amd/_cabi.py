@@ -146,8 +146,9 @@ PROTOTYPES = {
     "dlesm_checksum_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_d), _vp]),
     "dlesm_checksum_async_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "dlesm_hash_init_f64": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.c_uint64, C.c_int64, C.c_int64, _vp]),
-    "dlesm_stream_copy_f64": (_i, [_i, _i, C.POINTER(_vp), C.POINTER(_vp), C.c_size_t, _i, _vp]),
     "dlesm_set_tuning": (_i, [C.c_char_p, _i]),
+    "dlesm_tuning_class": (_i, [C.c_char_p]),
+    "dlesm_is_lab_build": (_i, []),
     "dlesm_comm_unique_id": (_i, [_vp]),
     "dlesm_comm_init": (_i, [_vp, _i, _i]),
     "dlesm_comm_finalize": (_i, []),
@@ -220,6 +221,45 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+# ---- measurement tooling (include/dlesm_lab.h): loaded NEXT TO the product library by bench.py, scripts/ and tests/ ----
+LAB_LIB_PATH = os.path.join(HERE, "lib", "libdlesm_lab.so")
+# the measurement build of the product's own sources (-DDLESM_LAB): what DLESM_HIP_LIB is pointed at to reach the
+# comparison-only kernels (LAB_NOTES.md); never loaded unless asked for
+LAB_BUILD_PATH = os.path.join(HERE, "lib", "libdlesm_hip_lab.so")
+LAB_PROTOTYPES = {
+    "dlesm_lab_last_error": (C.c_char_p, []),
+    "dlesm_lab_stream_copy_f64": (_i, [_i, _i, C.POINTER(_vp), C.POINTER(_vp), C.c_size_t, _i, _vp]),
+}
+_lab = None
+
+
+def lab():
+    """load libdlesm_lab.so: the copy-ceiling sweeps (no state shared with the product library)"""
+    global _lab
+    if _lab is not None:
+        return _lab
+    if not os.path.exists(LAB_LIB_PATH):
+        raise ImportError(f"{LAB_LIB_PATH} is missing (make -C dl_esm_inf_amd/csrc lab)")
+    lib()                                # the HIP runtime is in the process
+    L = C.CDLL(LAB_LIB_PATH)
+    for name, (res, args) in LAB_PROTOTYPES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lab = L
+    return L
+
+
+def check_lab(rc):
+    if rc != 0:
+        raise DlesmError(rc, lab().dlesm_lab_last_error().decode(errors="replace"))
+
+
+def is_lab_build():
+    """True when the library in this process is libdlesm_hip_lab.so (DLESM_HIP_LIB pointed at it)"""
+    return bool(lib().dlesm_is_lab_build())
 
 
 class PeerMatchDesc(C.Structure):

@@ -31,6 +31,15 @@ int ensure_device();
 hipStream_t side_stream();     // created by ensure_device()
 hipStream_t transfer_stream(); // for the non-blocking sync callbacks
 int tuning(const char *key, int fallback);
+// DLESM_LAB: the measurement build of the SAME sources (libdlesm_hip_lab.so): comparison-only kernels (the y-march and
+// LDS-staged Jacobi sweeps, taller / shorter wave tiles, shuffle instead of DPP, stacked and straight-line shallow-water
+// tiles, the pipeline form of the fused steps) and diagnostics that skip work are compiled only there; the product library
+// holds the forms it can reach by itself.  A LAB tuning key reads as its fallback in the product (dlesm_runtime.hip).
+#ifdef DLESM_LAB
+constexpr bool kLab = true;
+#else
+constexpr bool kLab = false;
+#endif
 // the process-wide pinned word a device-side wait raises when it gives up (checked by every device entry point)
 int *wait_timed_out_word();
 // forget what streams_run_concurrently has measured (a time-out was acknowledged, the runtime was finalised)

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void jacobi5x2_direct(const double *__restrict
     out[(size_t)j * ld + i] = 0.25 * ((T1(i - 1, j) + T1(i + 1, j)) + (T1(i, j - 1) + T1(i, j + 1)));
 }
 
+#ifdef DLESM_LAB      // the pipeline form (j5xt_march = 1): a comparison point, libdlesm_hip_lab.so only
 // ---------------------------------------------------------------------------------------------
 // The same T steps as a PIPELINE marching in y (no vertical redundancy): a wave owns 128 columns
 // and walks up a strip of rows; level s = 1..T keeps only its three newest rows in registers, and
@@ -274,6 +275,8 @@ static bool launch_xt_region(const double *in, double *out, int ld, int ny, cons
     return true;
 }
 
+#endif // DLESM_LAB
+
 template <int T, bool DPP>
 static void launch_xt(const double *in, double *out, int ld, int ny, const XtBoxes &b, int R, hipStream_t s)
 {
@@ -283,9 +286,13 @@ static void launch_xt(const double *in, double *out, int ld, int ny, const XtBox
     // measured best at 16384^2 (profiles/r01_sweep_fused.txt): 4, 6, 8, 8, 12, 16, 16 rows for
     // T = 2..8; capping the VGPRs for more waves per SIMD made no difference (2, 3, 4 waves tried)
     constexpr int best_rows[9] = {0, 8, 4, 6, 8, 8, 12, 16, 16};
+#ifdef DLESM_LAB
     if (R != 2 && R != 4 && R != 6 && R != 8 && R != 12 && R != 16) R = best_rows[T];
     if (T > 4 && R < 8) R = 8;                           // deep fusions: tall tiles only
     if (T < 4 && R > 8) R = 8;
+#else
+    R = best_rows[T];                                    // the product holds the measured-best height of each depth only
+#endif
     const int strips = (b.y1 - b.y0 + R) / R;
     // (XCD column bands -- XCD k takes tile columns [k*n/8, (k+1)*n/8) of every strip, so that every
     // vertical re-read is a hit in ITS L2 -- cut the fabric reads to 1.02x compulsory and were slower:
@@ -296,6 +303,7 @@ static void launch_xt(const double *in, double *out, int ld, int ny, const XtBox
 #define DLESM_XT(RR)                                                                                          \
     hipLaunchKernelGGL((jacobi5xt_tile<T, RR, DPP>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, ny, b, cb, \
                        nxw, 0.25)
+#ifdef DLESM_LAB
     switch (R) {
     case 2: if constexpr (T <= 4) DLESM_XT(2); break;
     case 4: if constexpr (T <= 4) DLESM_XT(4); break;
@@ -304,6 +312,9 @@ static void launch_xt(const double *in, double *out, int ld, int ny, const XtBox
     case 16: if constexpr (T >= 4) DLESM_XT(16); break;    // (24 rows spill: 71-224 VGPRs at T = 6..8)
     default: DLESM_XT(8); break;
     }
+#else
+    DLESM_XT(best_rows[T]);
+#endif
 #undef DLESM_XT
 }
 
@@ -371,6 +382,7 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
         return DLESM_OK;
     }
     const int R = tuning("j5xt_rows", 0);
+#ifdef DLESM_LAB
     const bool dpp = tuning("j5xt_dpp", 1);
     const bool march = tuning("j5xt_march", 0);
 #define DLESM_T(TT)                                                                             \
@@ -383,8 +395,13 @@ int launch_stencil5_multi(const double *in, double *out, int ld, int ny, int nst
                 launch_xt<TT, false>(in, out, ld, ny, b, R, s);                                 \
         }                                                                                       \
     } while (0)
+#else
+#define DLESM_T(TT) launch_xt<TT, true>(in, out, ld, ny, b, R, s)      // (DPP wave shifts, the tile form)
+#endif
     switch (nsteps) {
-    case 1: DLESM_T(1); break;
+#ifdef DLESM_LAB
+    case 1: DLESM_T(1); break;                           // (j5_kernel = 3: the single step through this tile shape)
+#endif
     case 2: DLESM_T(2); break;
     case 3: DLESM_T(3); break;
     case 4: DLESM_T(4); break;

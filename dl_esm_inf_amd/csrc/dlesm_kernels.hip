@@ -106,6 +106,7 @@ __device__ __forceinline__ void jacobi_row(const Vec<VEC> &south, const Vec<VEC>
     }
 }
 
+#ifdef DLESM_LAB      // the y-march sweep: a comparison point (j5_kernel = 1), libdlesm_hip_lab.so only
 // x0..x1, y0..y1: 0-based inclusive interior box.  c_first: first chunk holding an
 // interior column.  nxb: blocks per strip.  rows: strip height.
 //
@@ -211,6 +212,8 @@ __global__ __launch_bounds__(256) void jacobi5_march(const double *__restrict__ 
         j++;
     }
 }
+
+#endif // DLESM_LAB
 
 // ===========================================================================
 // 5-point Jacobi, linear tile sweep (the default).
@@ -689,6 +692,7 @@ __global__ void peer_flags_set_k(PeerFlagList fl, int n, unsigned long long seq,
     if (threadIdx.x == 0) peer_seq_advance(seqw, dseq, sticky);
 }
 
+#ifdef DLESM_LAB
 // LDS-staged form (j5_kernel = 2, the comparison point for "stage the tile and its halo ring in
 // LDS"): a workgroup of 64*T lanes stages rows jb-1..je+1 of a 128*T-column tile, plus the two
 // ring columns, in LDS (row pitch 2*blockDim+4 doubles, interior chunks 16-byte aligned at
@@ -741,6 +745,8 @@ __global__ __launch_bounds__(1024) void jacobi5_lds(const double *__restrict__ i
         }
     }
 }
+
+#endif // DLESM_LAB
 
 // Block shape of a linear tile sweep: waves per workgroup and (padded) wave tiles per row.
 // Workgroups go round-robin to the 8 XCDs, so the tile below a given tile runs on the XCD
@@ -818,7 +824,14 @@ template <int VEC, bool NT>
 static void launch_tile(const double *in, double *out, int ld, int x0, int x1, int y0, int y1, int R,
                         int flags, hipStream_t s, FrameJob *fj = nullptr, PeerJob *pj = nullptr)
 {
+#ifdef DLESM_LAB
     if (R != 1 && R != 2 && R != 3 && R != 4 && R != 6 && R != 12 && R != 16) R = 8;
+#else
+    // the product's tile heights: 2 or 3 rows with 16-byte lanes (the planning call chooses), 4 rows with the 8-byte-lane
+    // fall-back; the other heights were comparison points and live in libdlesm_hip_lab.so
+    if (VEC == 2) { if (R != 3) R = 2; }
+    else R = 4;
+#endif
     // tiles are anchored on a 128-byte line of the row (not on the first interior column), so
     // every wave access covers whole lines whatever the box: lanes left of x0 are masked
     const int c_first = (x0 / VEC) & ~(128 / (8 * VEC) - 1), c_last = x1 / VEC;
@@ -895,6 +908,7 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
 #define DLESM_TILE(RR)                                                                               \
     hipLaunchKernelGGL((jacobi5_tile<VEC, RR, (NT ? 3 : 0)>), dim3(grid), dim3(64 * tpb), 0, s, in, out, ld, x0, x1, \
                        y0, y1, c_first, nxw, flags)
+#ifdef DLESM_LAB
     switch (R) {
     case 1: DLESM_TILE(1); break;
     case 2: DLESM_TILE(2); break;
@@ -905,6 +919,14 @@ static void launch_tile(const double *in, double *out, int ld, int x0, int x1, i
     case 16: DLESM_TILE(16); break;
     default: DLESM_TILE(8); break;
     }
+#else
+    if constexpr (VEC == 2) {
+        if (R == 3) DLESM_TILE(3);
+        else DLESM_TILE(2);
+    } else {
+        DLESM_TILE(4);
+    }
+#endif
 #undef DLESM_TILE
 }
 
@@ -948,6 +970,7 @@ int check_box(const char *who, int ld, int ny, int xstart, int xstop, int ystart
     return DLESM_OK;
 }
 
+#ifdef DLESM_LAB
 template <int VEC, int U, bool NT, bool PIPE>
 static void launch_march_u(const double *in, double *out, int ld, int x0, int x1, int y0, int y1,
                            int rows, int flags, hipStream_t s)
@@ -994,6 +1017,8 @@ static int auto_rows(int ncols_vec, int height)
     return rows < 1 ? 1 : rows;
 }
 
+#endif // DLESM_LAB
+
 int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, int xstop, int ystart,
                     int ystop, hipStream_t s)
 {
@@ -1003,11 +1028,14 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
     const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
     // tuning bits -- 1: non-temporal loads/stores, 2: no register double buffering,
     // 4: force VEC=1, 8: diagnostic "no edge loads" (wrong results, profiling only)
-    const int variant = tuning("j5_variant", 0);
+    // (bits 1, 2 and 8 select comparison forms / a diagnostic: libdlesm_hip_lab.so only)
+    const int variant = tuning("j5_variant", 0) & (kLab ? ~0 : 0x14);
+    const int flags = (variant >> 3) & 1;
+#ifdef DLESM_LAB
     const bool nt = variant & 1;
     const bool pipe = !(variant & 2);
-    const int flags = (variant >> 3) & 1;
     const int unroll = tuning("j5_unroll", 4);
+#endif
     // 16-byte lanes are used on an odd leading dimension too (DL_ESM_ALIGNMENT unset or odd):
     // every other row is then only 8-byte aligned, which global_load/store_dwordx4 accept --
     // 72 % of HBM peak at 16384^2 against 67 % with 8-byte lanes (variant bit 16 turns it off).
@@ -1019,13 +1047,22 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
         // rows per tile: 2 for 16-byte lanes, 4 for the 8-byte-lane fallback (measured, scripts/size_probe.py)
         int R = tuning("j5_tile_rows", 0);
         if (R < 1) R = vec2 ? 2 : 4;
-        if (vec2) { if (nt) launch_tile<2, true>(in, out, ld, x0, x1, y0, y1, R, flags, s);
-                    else launch_tile<2, false>(in, out, ld, x0, x1, y0, y1, R, flags, s); }
-        else { if (nt) launch_tile<1, true>(in, out, ld, x0, x1, y0, y1, R, flags, s);
-               else launch_tile<1, false>(in, out, ld, x0, x1, y0, y1, R, flags, s); }
+#ifdef DLESM_LAB
+        if (nt) {
+            if (vec2) launch_tile<2, true>(in, out, ld, x0, x1, y0, y1, R, flags, s);
+            else launch_tile<1, true>(in, out, ld, x0, x1, y0, y1, R, flags, s);
+            DLESM_HIP_TRY(hipGetLastError());
+            return DLESM_OK;
+        }
+#endif
+        if (vec2) launch_tile<2, false>(in, out, ld, x0, x1, y0, y1, R, flags, s);
+        else launch_tile<1, false>(in, out, ld, x0, x1, y0, y1, R, flags, s);
         DLESM_HIP_TRY(hipGetLastError());
         return DLESM_OK;
     }
+#ifndef DLESM_LAB
+    return fail(DLESM_EINVAL, "stencil5: no such kernel in this library");      // (unreachable: j5_kernel reads 0 here)
+#else
     if (tuning("j5_kernel", 0) == 3 && vec2)   // the fused-step kernel's tile shape with one step
         return launch_stencil5_multi(in, out, ld, ny, 1, xstart, xstop, ystart, ystop, xstart, xstop, ystart, ystop,
                                      0, 0, 0, 0, s);
@@ -1064,6 +1101,7 @@ int launch_stencil5(const double *in, double *out, int ld, int ny, int xstart, i
 #undef DLESM_J5
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
+#endif // DLESM_LAB
 }
 
 // One wave parked on the frame flag: lane 0 sleeps until the flag reaches `seq`.  It holds one wave
@@ -1176,7 +1214,7 @@ int launch_stencil5_framed(const double *in, double *out, int ld, int ny, int xs
     if (int rc = check_box("dlesm_jacobi5_step_dm", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     DLESM_REQUIRE(in != nullptr && out != nullptr && in != out, "stencil5: null or aliased arrays");
     DLESM_REQUIRE(job.counter != nullptr && job.flag != nullptr, "stencil5 framed: no signal words");
-    const int variant = tuning("j5_variant", 0);
+    const int variant = tuning("j5_variant", 0) & (kLab ? ~0 : 0x14);
     const int x1i = xstop - 2;                                              // east end of the interior, 0-based
     const bool odd_ok = !(variant & 16) && x1i + 1 <= 2 * (ld / 2) - 1;
     const bool vec2 = !(variant & 4) && ((ld % 2 == 0) || odd_ok) && ((uintptr_t)in % 16 == 0) &&
@@ -1199,7 +1237,7 @@ int launch_stencil5_peer(const double *in, double *out, int ld, int ny, int xsta
     if (int rc = check_box("dlesm_jacobi5_step_dm", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     DLESM_REQUIRE(in != nullptr && out != nullptr && in != out, "stencil5: null or aliased arrays");
     DLESM_REQUIRE(job.counter != nullptr && job.nin <= PeerJob::MAXM && job.nout <= PeerJob::MAXM, "stencil5 peer: bad job");
-    const int variant = tuning("j5_variant", 0);
+    const int variant = tuning("j5_variant", 0) & (kLab ? ~0 : 0x14);
     const int x1i = xstop - 2;
     const bool odd_ok = !(variant & 16) && x1i + 1 <= 2 * (ld / 2) - 1;
     const bool vec2 = !(variant & 4) && ((ld % 2 == 0) || odd_ok) && ((uintptr_t)in % 16 == 0) &&
@@ -1647,7 +1685,7 @@ extern "C" int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld
     if (xstop < xstart || ystop < ystart) return DLESM_OK;
     if (int rc = launch_stencil5(in, out, ld, ny, xstart, xstop, ystart, ystop, s)) return rc;   // validates, warms
     const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
-    const int variant = tuning("j5_variant", 0);
+    const int variant = tuning("j5_variant", 0) & (kLab ? ~0 : 0x14);
     const bool odd_ok = !(variant & 16) && x1 + 1 <= 2 * (ld / 2) - 1;
     const bool vec2 = !(variant & 4) && ((ld % 2 == 0) || odd_ok) && ((uintptr_t)in % 16 == 0) &&
                       ((uintptr_t)out % 16 == 0);

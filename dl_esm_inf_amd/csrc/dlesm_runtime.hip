@@ -44,8 +44,47 @@ static bool dm_safe_nolock()
     return it != g_tuning.end() ? it->second != 0 : env;
 }
 
+// Every setting the library reads, by class (include/dlesm_hip.h, dlesm_set_tuning): USER = for host programs, HOOK = forces
+// a path the library also takes by itself (tests reach it on any input), LAB = comparison-only kernels and diagnostics
+// that exist in libdlesm_hip_lab.so only.  tests/test_cabi_host.py checks that every key the sources read is listed here.
+enum { KEY_USER = 0, KEY_HOOK = 1, KEY_LAB = 2 };
+static const struct { const char *key; int cls; } kKeys[] = {
+    // ---- USER
+    {"dm_safe", KEY_USER}, {"dm_wait_seconds", KEY_USER}, {"dm_peer", KEY_USER}, {"dm_peer_exchange", KEY_USER},
+    {"mailbox_fences", KEY_USER}, {"mailbox_fields", KEY_USER}, {"mailbox_gather_host", KEY_USER}, {"dm_acquire", KEY_USER},
+    {"j5_dm_corners", KEY_USER}, {"j5_nt_stores", KEY_USER}, {"j5_use_tuned", KEY_USER}, {"side_stream_priority", KEY_USER},
+    {"dm_graph_force", KEY_USER},
+    // ---- HOOK: launch shapes the planning calls choose from
+    {"j5_tpb", KEY_HOOK}, {"j5_pad_tiles", KEY_HOOK}, {"j5_autoshape", KEY_HOOK}, {"j5_skew", KEY_HOOK}, {"j5_tile_rows", KEY_HOOK},
+    {"j5_tune_rows", KEY_HOOK}, {"j5_share_plan", KEY_HOOK}, {"sw_nt", KEY_HOOK}, {"swk_nt", KEY_HOOK}, {"swk_ntl", KEY_HOOK},
+    {"cont_nt", KEY_HOOK}, {"sw_smooth_ntl", KEY_HOOK},
+    // ---- HOOK: fall-back kernels (unaligned bases, odd pitches, thin boxes) and the forms DLESM_DM_SAFE / a capture select
+    {"j5_variant", KEY_HOOK}, {"sw_kernel", KEY_HOOK}, {"swk_kernel", KEY_HOOK}, {"s9_kernel", KEY_HOOK}, {"j5m_kernel", KEY_HOOK},
+    {"cont_kernel", KEY_HOOK}, {"sw_thin_box", KEY_HOOK}, {"sw_wrap_fused", KEY_HOOK}, {"sw_smooth_fused", KEY_HOOK},
+    {"util_rowseg", KEY_HOOK}, {"util_rowlinear", KEY_HOOK}, {"util_gather_linear", KEY_HOOK},
+    {"j5_dm_fused", KEY_HOOK}, {"sw_dm_fused", KEY_HOOK}, {"s9_dm_fused", KEY_HOOK}, {"j5_dm_chain", KEY_HOOK}, {"sw_dm_chain", KEY_HOOK},
+    {"j5_dm_lazy_unpack", KEY_HOOK}, {"j5_dm_frame_pack", KEY_HOOK}, {"dm_flag_join", KEY_HOOK}, {"dm_aggregate", KEY_HOOK},
+    {"dm_aggregate_single", KEY_HOOK}, {"dm_peer_one_launch", KEY_HOOK}, {"dm_peer_join_fused", KEY_HOOK},
+    {"mailbox_finegrained", KEY_HOOK}, {"j5xt_dm_serial_from", KEY_HOOK}, {"dm_inject_timeout", KEY_HOOK},
+    // (tests only: sw_dm_frame = 0 is the ring as four thin boxes of the plain step, no kernel of its own; dm_skip_parts
+    //  switches parts of an RCCL exchange OFF -- results then come from the mailboxes or are wrong by design)
+    {"sw_dm_frame", KEY_HOOK}, {"dm_skip_parts", KEY_HOOK},
+    // ---- LAB
+    {"j5_kernel", KEY_LAB}, {"j5_rows", KEY_LAB}, {"j5_unroll", KEY_LAB}, {"j5_padw", KEY_LAB}, {"j5xt_rows", KEY_LAB}, {"j5xt_dpp", KEY_LAB},
+    {"j5xt_march", KEY_LAB}, {"j5xt_march_slots", KEY_LAB}, {"j5xt_march_ring", KEY_LAB}, {"j5xt_march_perm", KEY_LAB},
+    {"sw_tile_rows", KEY_LAB}, {"sw_dpp", KEY_LAB}, {"sw_stack", KEY_LAB}, {"sw_dm_diag", KEY_LAB},
+    {"dm_event_system_fence", KEY_LAB}, {"util_segp", KEY_LAB},
+};
+static int key_class(const char *key)
+{
+    for (const auto &k : kKeys)
+        if (!strcmp(k.key, key)) return k.cls;
+    return -1;
+}
+
 static int tuning_nolock(const char *key, int fallback)
 {
+    if (!kLab && key_class(key) == KEY_LAB) return fallback;      // the product library has no such form
     if (dm_safe_nolock())
         for (const char *k : kSafeOff)
             if (!strcmp(k, key)) return 0;
@@ -170,10 +209,23 @@ extern "C" int dlesm_finalize(void)
     return DLESM_OK;
 }
 
+extern "C" int dlesm_tuning_class(const char *key) { return key ? key_class(key) : -1; }
+extern "C" int dlesm_is_lab_build(void) { return kLab ? 1 : 0; }
+
 extern "C" int dlesm_set_tuning(const char *key, int value)
 {
     if (!key) return 0;
     std::lock_guard<std::mutex> lk(g_mu);
+    const int cls = key_class(key);
+    if (cls < 0 || (cls == KEY_LAB && !kLab)) {      // said once per key: a typo, or a lab key in the product library
+        static std::map<std::string, bool> said;
+        if (!said[key]) {
+            said[key] = true;
+            if (cls < 0) fprintf(stderr, "dlesm_set_tuning: unknown key \"%s\" (kept; nothing reads it)\n", key);
+            else fprintf(stderr, "dlesm_set_tuning: \"%s\" selects a comparison-only form that exists in libdlesm_hip_lab.so only: "
+                                 "ignored by this library\n", key);
+        }
+    }
     int prev = g_tuning.count(key) ? g_tuning[key] : 0;
     g_tuning[key] = value;
     // diagnostic: raise the process-wide time-out word exactly as a device-side wait that gives up does

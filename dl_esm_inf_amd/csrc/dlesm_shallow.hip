@@ -64,7 +64,7 @@ struct SwSmooth {
     double alpha;
     double *uo, *vo, *po;
 };
-__device__ __forceinline__ V2 pin_here(const V2 &a) { return V2{::dlesm::pin_here(a.x), ::dlesm::pin_here(a.y)}; }   // dlesm_internal.h
+[[maybe_unused]] __device__ __forceinline__ V2 pin_here(const V2 &a) { return V2{::dlesm::pin_here(a.x), ::dlesm::pin_here(a.y)}; }   // dlesm_internal.h
 // new time level stored non-temporally by default: +1.2 % at 8192^2 (profiles/r02_shallow_variants.txt)
 #define SW_NT_DEFAULT 2
 
@@ -573,7 +573,7 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
                          double *pnew, hipStream_t s, bool sw_offset, SwFrameJob *fj, int wrap, const double *smooth_alpha)
 {
     const int cb = sw_first_chunk(x0);
-    int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & 15;
+    int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & (kLab ? 15 : 3);      // (bits 4, 8: experiments, lab build only)
     SwSmooth sm{0.0, nullptr, nullptr, nullptr};
     if (smooth_alpha) sm = SwSmooth{*smooth_alpha, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold)};
     {
@@ -642,8 +642,10 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
         case 1: DLESM_SWS(1); break;
         case 2: DLESM_SWS(2); break;
         case 3: DLESM_SWS(3); break;
+#ifdef DLESM_LAB
         case 10: DLESM_SWS(10); break;
         case 11: DLESM_SWS(11); break;
+#endif
         default: DLESM_SWS(0); break;
         }
 #undef DLESM_SWS
@@ -667,6 +669,13 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
         default: DLESM_SW3(RR, DD, 0); break;                                                                  \
         }                                                                                                      \
     } while (0)
+#ifndef DLESM_LAB
+    // the product's form: two-row tiles, DPP wave shifts, the four cache policies the planning call chooses from;
+    // one- and three-row tiles, shuffles through LDS, stacked tiles, the straight-line and old-level-first forms were
+    // comparison points and live in libdlesm_hip_lab.so
+    (void)dpp;
+    DLESM_SW2(2, true);
+#else
 #define DLESM_SW(RR)                                                                                           \
     do {                                                                                                       \
         if (dpp) DLESM_SW2(RR, true);                                                                          \
@@ -689,9 +698,10 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     else if (R == 1) DLESM_SW(1);
     else if (R == 3) DLESM_SW(3);
     else DLESM_SW(2);
+#undef DLESM_SW
+#endif // DLESM_LAB
 #undef DLESM_SW2
 #undef DLESM_SW3
-#undef DLESM_SW
 }
 
 } // namespace dlesm

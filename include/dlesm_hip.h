@@ -418,16 +418,22 @@ int dlesm_checksum_async_f64(const double *f, int ld, int ny, int xstart, int xs
 int dlesm_hash_init_f64(double *f, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
                         uint64_t seed, int64_t gx0, int64_t gy0, void *stream);
 
-/* Diagnostic (no reference counterpart): a linear sweep that reads `nread` arrays once and writes `nwrite`
- * arrays once, n doubles each, one 16-byte element per thread per array -- the ceiling a kernel with that many
- * concurrent HBM streams is measured against in the same process (bench.py's copy_ceiling).  Combinations:
- * 1+1, 2+1, 3+1, 4+1, 6+3, 6+6 (written arrays may be read arrays: the in-place sweep of the filtered step), 8+1.  nt bit 0: the second half of the read arrays loaded non-temporally; bit 1:
- * non-temporal stores.  dst_k = (sum of the read arrays) + src_(k mod nread)   (1+1: a plain copy). */
-int dlesm_stream_copy_f64(int nread, int nwrite, const double *const *src, double *const *dst, size_t n,
-                          int nt, void *stream);
-
-/* kernel tuning knobs ("j5_rows", "j5_variant", ...) for benchmarking; returns previous value */
+/* (The measured copy ceilings of bench.py live in their own library, include/dlesm_lab.h: measurement tooling.)
+ *
+ * Settings, by name; returns the previous value (0 if the key had none).  Three classes (dlesm_tuning_class):
+ *   0  USER  what a host program may want to say ("Settings"): dm_safe, dm_wait_seconds, dm_peer,
+ *            dm_peer_exchange, mailbox_fences, mailbox_fields, mailbox_gather_host, dm_acquire, j5_dm_corners,
+ *            j5_nt_stores, j5_use_tuned, side_stream_priority, dm_graph_force.
+ *   1  HOOK  forces a path the library takes BY ITSELF for some inputs (an unaligned base, a capture, a planned launch
+ *            shape, DLESM_DM_SAFE ...) so that tests can reach it on any input; every setting computes the same bits.
+ *   2  LAB   selects a comparison-only kernel or a diagnostic that skips work: compiled into libdlesm_hip_lab.so only
+ *            (-DDLESM_LAB, the same sources); libdlesm_hip.so ignores such a key and says so once on stderr.
+ * An unknown key is reported on stderr (once) and kept. */
 int dlesm_set_tuning(const char *key, int value);
+/* 0 USER, 1 HOOK, 2 LAB, -1 unknown */
+int dlesm_tuning_class(const char *key);
+/* 1 in libdlesm_hip_lab.so (built with -DDLESM_LAB), 0 in the product library */
+int dlesm_is_lab_build(void);
 
 /* ------------------------------------------------------------------------
  * 5. Device-resident halo exchange over RCCL

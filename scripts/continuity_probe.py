@@ -29,7 +29,7 @@ n = (g.nx * g.ny) & ~1
 srcs = (C.c_void_p * 8)(*[f.device_ptr for f in CF[1:]] + [g.area_t_device.data_ptr()])
 dsts = (C.c_void_p * 1)(CF[0].device_ptr)
 for nt in (0, 2):
-    ms = timed(lambda: D._cabi.check(L.dlesm_stream_copy_f64(8, 1, srcs, dsts, n, nt, sp)))
+    ms = timed(lambda: D._cabi.check_lab(D._cabi.lab().dlesm_lab_stream_copy_f64(8, 1, srcs, dsts, n, nt, sp)))
     print(f"{tile}^2 stream copy 8 read + 1 written, nt={nt}: {ms:.4f} ms  {72 * n / ms / 1e6 / 80:.1f} % of 8 TB/s", flush=True)
 for nt in (0, 1, 2, 3):
     L.dlesm_set_tuning(b"cont_nt", nt)

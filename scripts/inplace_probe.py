@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Is an IN-PLACE stream (an array both read and written, as time_smooth's field_old) slower than the same bytes with a separate
-output?  Linear sweeps through dlesm_stream_copy_f64, 3 arrays read + 1 written, 8192^2 field shape."""
+output?  Linear sweeps through dlesm_lab_stream_copy_f64, 3 arrays read + 1 written, 8192^2 field shape."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, dl_esm_inf_amd as D
@@ -16,7 +16,7 @@ def timed(name, src, dst, nt, reps=30):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
             for _ in range(reps):
-                D._cabi.check(L.dlesm_stream_copy_f64(len(src), 1, sa, da, n, nt, sp))
+                D._cabi.check_lab(D._cabi.lab().dlesm_lab_stream_copy_f64(len(src), 1, sa, da, n, nt, sp))
             e1.record(s)
         s.synchronize()
         if rnd: best = min(best, e0.elapsed_time(e1) / reps)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round-3 measurements of BASELINE configs[3] (GOcean shallow water, 8192 x 8192 fp64, one MI355X), one process:
 
-  ceilings   linear sweeps with the same stream counts as the kernels (dlesm_stream_copy_f64), with / without nt
+  ceilings   linear sweeps with the same stream counts as the kernels (dlesm_lab_stream_copy_f64), with / without nt
   fused      the fused NE step under the code-generation variants of sw_nt (bit 0 nt loads of the old level, bit 1 nt
              stores, bit 2 old level requested first, bit 3 straight-line form) and sw_stack (tiles stacked per group)
   periodic   the SW-offset periodic model: step + two copy launches against the one-launch form
@@ -101,7 +101,7 @@ def main():
                 dst = (C.c_void_p * nw)(*[f.device_ptr.value for f in allf[6:6 + nw]])
                 for nt in (0, 2, 3, 1):
                     def go():
-                        D._cabi.check(L.dlesm_stream_copy_f64(nr, nw, src, dst, nfield, nt, C.c_void_p(s.cuda_stream)))
+                        D._cabi.check_lab(D._cabi.lab().dlesm_lab_stream_copy_f64(nr, nw, src, dst, nfield, nt, C.c_void_p(s.cuda_stream)))
                     ms = timed(go, args.steps)
                     gbs = 8.0 * (nr + nw) * nfield / ms / 1e6
                     out[f"{nr}r+{nw}w nt={nt}"] = {"ms": ms, "gbs": gbs, "frac": gbs / 8000.0}

@@ -38,6 +38,56 @@ def test_library_exports_every_declared_symbol():
     assert L.dlesm_version() == 310
 
 
+def test_lab_tool_library_exports_its_header():
+    """libdlesm_lab.so (measurement tooling loaded next to the product) == include/dlesm_lab.h == the ctypes table"""
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dlesm_lab.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(dlesm_lab_[a-z0-9_]+)\s*\(", txt)))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _cabi.LAB_LIB_PATH], text=True)
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and "dlesm_" in l)
+    assert exported == syms == sorted(_cabi.LAB_PROTOTYPES)
+
+
+def test_product_and_lab_build_export_the_same_entries():
+    """the lab build is the same sources with -DDLESM_LAB: same C ABI, more kernels behind it"""
+    def entries(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return sorted(l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("dlesm_"))
+    assert entries(_cabi.LIB_PATH) == entries(_cabi.LAB_BUILD_PATH) == _header_symbols()
+    assert os.path.getsize(_cabi.LIB_PATH) < 0.6 * os.path.getsize(_cabi.LAB_BUILD_PATH)      # the variants are the bulk of the code
+
+
+def test_integration_md_names_every_entry_of_the_product_library():
+    """the default .so exports only entries INTEGRATION.md names"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    named = set(re.findall(r"\bdlesm_[a-z0-9_]+", doc))
+    missing = [s_ for s_ in _header_symbols() if s_ not in named]
+    assert not missing, missing
+
+
+def test_tuning_keys_are_classified():
+    """every key the sources read is in the library's table (dlesm_tuning_class), the USER keys are the ones INTEGRATION.md
+    lists, and tests/conftest.py's rule for "needs the lab build" agrees with the library's LAB class"""
+    import conftest
+    src = ""
+    d = os.path.join(ROOT, "dl_esm_inf_amd", "csrc")
+    for f in os.listdir(d):
+        if f.endswith((".hip", ".cpp", ".h")):
+            src += open(os.path.join(d, f)).read()
+    keys = sorted(set(re.findall(r'tuning(?:_nolock)?\("([a-z0-9_]+)"', src)))
+    assert len(keys) > 50
+    cls = {k: L.dlesm_tuning_class(k.encode()) for k in keys}
+    assert not [k for k, c in cls.items() if c < 0], [k for k, c in cls.items() if c < 0]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    settings = doc[doc.index("## Settings"):]
+    settings = settings[:settings.index("\n## ", 5)] if "\n## " in settings[5:] else settings
+    for k, c in cls.items():
+        assert (f"`{k}`" in settings) == (c == 0), (k, c)
+    lab = {k for k, c in cls.items() if c == 2}
+    assert set(conftest._LAB_DEFAULTS) <= lab, set(conftest._LAB_DEFAULTS) - lab
+    for k in lab - {"j5_padw", "util_segp"}:          # (shape-cost weight, segment size: no test selects them)
+        assert k in conftest._LAB_DEFAULTS, k
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(_cabi.Region) == 24 and C.sizeof(_cabi.Subdomain) == 48
     assert C.sizeof(_cabi.Decomp) == 28

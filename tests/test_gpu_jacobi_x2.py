@@ -93,8 +93,9 @@ def test_fused_steps_bit_exact(D, nx, ny, alignment, nsteps, tune):
         _tune(D, DEFAULTS)
 
 
+@pytest.mark.parametrize("march", [0, 1], ids=["tile", "march"])      # (march: the pipeline form, libdlesm_hip_lab.so)
 @pytest.mark.parametrize("nsteps", STEPS)
-def test_fused_sub_boxes_and_grown_stage_boxes(D, nsteps):
+def test_fused_sub_boxes_and_grown_stage_boxes(D, nsteps, march):
     """the forms the distributed step uses: thin output boxes with the tile's stage boxes, stage
     boxes grown towards some sides (deep halos), empty boxes; refusals"""
     L = D._cabi.lib()
@@ -117,8 +118,8 @@ def test_fused_sub_boxes_and_grown_stage_boxes(D, nsteps):
     ]
     for box, ebox, grow in cases:
         want = _oracle_multi(hin, g.nx, nsteps, box, ebox, grow)
-        for march in (0, 1):            # tile kernel everywhere / marching kernel in the interior
-            _tune(D, dict(j5xt_march=march, j5xt_march_slots=64))
+        if True:                        # march = 0: tile kernel everywhere / 1: marching kernel in the interior (lab build)
+            _tune(D, dict(j5xt_march=march, j5xt_march_slots=64) if march else {})
             D.set_field(b, -7.0)
             D._cabi.check(L.dlesm_stencil5_multi_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, nsteps, *box, *ebox,
                                                      *grow, None))
@@ -156,8 +157,9 @@ def test_x2_entry_with_explicit_intermediate_box(D):
     assert L.dlesm_stencil5_x2_f64(a.device_ptr, b.device_ptr, g.nx, g.ny, *full, 1, 303, 2, 92, None) == D._cabi.EINVAL
 
 
+@pytest.mark.parametrize("march", [0, 1], ids=["tile", "march"])      # (march: the pipeline form, libdlesm_hip_lab.so)
 @pytest.mark.parametrize("n,alignment", [(4096, 64), (8192, None), (16384, 64)])
-def test_fused_equals_single_steps_full_size(D, n, alignment):
+def test_fused_equals_single_steps_full_size(D, n, alignment, march):
     import torch
     g = _grid(D, n, n, alignment)
     a, p, q, c = (D.r2d_field(g, D.GO_T_POINTS) for _ in range(4))
@@ -167,9 +169,9 @@ def test_fused_equals_single_steps_full_size(D, n, alignment):
     src, dst = a, p
     for nsteps in (1, 2, 3, 4, 5, 6, 7, 8):
         D.psy.invoke_jacobi5(dst, src)  # dst = J^nsteps(a)
-        for march in (0, 1):
+        if True:
             if nsteps > 1:
-                _tune(D, dict(j5xt_march=march))
+                _tune(D, dict(j5xt_march=march) if march else {})
                 D.psy.invoke_jacobi5_multi(c, a, nsteps)
                 torch.cuda.synchronize()
                 _tune(D, DEFAULTS)
