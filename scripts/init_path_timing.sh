@@ -17,14 +17,26 @@ amdflang -O2 -I dl_esm_inf_amd/fortran/build -J $B/ours scripts/init_path_timing
     -L dl_esm_inf_amd/lib -ldlesm_hip -L/opt/rocm/lib -lamdhip64 -lrccl -Wl,-rpath,$ROOT/dl_esm_inf_amd/lib -Wl,-rpath,/opt/rocm/lib \
     -o $B/ours/init.exe
 echo "host: $(nproc) cores, $(grep -m1 'model name' /proc/cpuinfo | cut -d: -f2 | sed 's/^ //'); 1 rank, 1 thread; DL_ESM_ALIGNMENT=${DL_ESM_ALIGNMENT:-unset}"
+REPS=${REPS:-5}
+printf "%-5s %6s  %-22s %-22s %s\n" build N "grid_init s (min-max)" "four fields s (min-max)" "checksum of a field of ones"
 for n in ${@:-4096 8192}; do
-  for who in ref ours; do
-    best=""
-    for rep in 1 2 3; do
-      line=$(OMP_NUM_THREADS=1 $B/$who/init.exe $n | grep "^N=")
-      best="$best
-$line"
+  for who in ref ours; do          # alternating runs, $REPS each: page-fault cost in this VM varies a lot from run to run
+    : > $B/$who.$n.txt
+  done
+  for rep in $(seq $REPS); do
+    for who in ref ours; do
+      OMP_NUM_THREADS=1 $B/$who/init.exe $n | grep "^N=" >> $B/$who.$n.txt
     done
-    echo "$who $(echo "$best" | grep N= | sort -t= -k6 -g | head -1)"
+  done
+  for who in ref ours; do
+    python3 - $who $n $B/$who.$n.txt <<'PY'
+import re, sys
+who, n, f = sys.argv[1:]
+g, ff, cs = [], [], set()
+for line in open(f):
+    m = re.search(r"grid_init_s=\s*([0-9.]+) four_fields_s=\s*([0-9.]+) checksum=\s*(\S+)", line)
+    g.append(float(m.group(1))); ff.append(float(m.group(2))); cs.add(m.group(3))
+print(f"{who:5s} {n:>6s}  {min(g):8.3f} - {max(g):8.3f}    {min(ff):8.3f} - {max(ff):8.3f}    {' '.join(sorted(cs))}")
+PY
   done
 done
