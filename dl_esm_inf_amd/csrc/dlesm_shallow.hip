@@ -325,19 +325,46 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
         put(pnew + o, r.pn);
         // the filtered old level is read by nobody before the next launch: ordinary stores
         if constexpr (SM) smooth_old_level(fj.alpha, o, u, v, p, r, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold));
-        for (int k = 0; k < fj.pk.n; k++)
-            if (fj.pk.holds(k, i, j)) {
+        if (fj.npeer) {
+            // A neighbour's mailbox: system scope (the bytes cross xGMI), 16 bytes per store where two cells are neighbours
+            // in the strip too (round 4, as jacobi5_tile_peer's frame).  Consecutive lanes hold consecutive frame cells --
+            // along a row, then up a column -- and a strip is contiguous in the mailbox in that same order, so a lane whose
+            // slot starts a 16-byte granule takes the upper lane's values by a wave shift (DPP) and stores both; the
+            // upper lane then stores nothing; odd ends, corners and granules split between two waves take 8-byte stores.
+            const int lane = threadIdx.x & 63;
+            const double upn = from_upper<true>(r.un), vpn = from_upper<true>(r.vn), ppn = from_upper<true>(r.pn);
+            int i2 = 0, j2 = 0, i0 = 0, j0 = 0;
+            const bool has_up = lane < 63 && t + 1 < total, has_lo = lane > 0 && t > 0;
+            if (has_up) frame_index(t + 1, fj.fx0, fj.fx1, fj.fy0, fj.fy1, i2, j2);
+            if (has_lo) frame_index(t - 1, fj.fx0, fj.fx1, fj.fy0, fj.fy1, i0, j0);
+            const double mine[3] = {r.un, r.vn, r.pn}, upper[3] = {upn, vpn, ppn};
+            for (int k = 0; k < fj.pk.n; k++) {
+                if (!fj.pk.holds(k, i, j)) continue;
                 double *b = fj.pk.at(k);
-                if (fj.npeer) {       // a neighbour's mailbox: system scope (the bytes cross xGMI)
-                    __hip_atomic_store(b + fj.pk.slot(k, 0, i, j), r.un, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(b + fj.pk.slot(k, 1, i, j), r.vn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(b + fj.pk.slot(k, 2, i, j), r.pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                } else {
+                const long s0 = fj.pk.slot(k, 0, i, j);
+                const bool up_next = has_up && fj.pk.holds(k, i2, j2) && fj.pk.slot(k, 0, i2, j2) == s0 + 1;
+                const bool lo_prev = has_lo && fj.pk.holds(k, i0, j0) && fj.pk.slot(k, 0, i0, j0) == s0 - 1;
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    double *d = b + fj.pk.slot(k, f, i, j);
+                    const bool starts_granule = ((uintptr_t)d & 15) == 0;
+                    typedef double sw_pd2 __attribute__((ext_vector_type(2)));
+                    if (starts_granule && up_next)
+                        *(__attribute__((address_space(1))) volatile sw_pd2 *)d = sw_pd2{mine[f], upper[f]};   // global_store_dwordx4 sc0 sc1
+                    else if (starts_granule || !lo_prev)
+                        __hip_atomic_store(d, mine[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // else: the second half of the lower lane's granule -- that lane has stored it
+                }
+            }
+        } else {
+            for (int k = 0; k < fj.pk.n; k++)
+                if (fj.pk.holds(k, i, j)) {
+                    double *b = fj.pk.at(k);
                     put(b + fj.pk.slot(k, 0, i, j), r.un);
                     put(b + fj.pk.slot(k, 1, i, j), r.vn);
                     put(b + fj.pk.slot(k, 2, i, j), r.pn);
                 }
-            }
+        }
     }
     __builtin_amdgcn_s_waitcnt(0);        // this wave's stores have been acknowledged ...
     __syncthreads();                      // ... and those of every wave of the group ...
