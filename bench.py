@@ -389,6 +389,10 @@ def shallow_water(D, torch, stream, alignment, tile=8192, steps=40, cpu_seconds=
         out["with_time_smooth"] = shallow_water_smooth(D, torch, stream, g, F, prm, tile, steps)
     except Exception as e:                                   # noqa: BLE001
         out["with_time_smooth"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        out["two_steps_per_launch"] = shallow_water_x2(D, torch, stream, g, F, prm, tile, steps, ms)
+    except Exception as e:                                   # noqa: BLE001
+        out["two_steps_per_launch"] = {"error": f"{type(e).__name__}: {e}"}
     del F, cur, old, new
     torch.cuda.empty_cache()
     try:
@@ -500,6 +504,61 @@ def shallow_water_unfused(D, torch, stream, g, F, prm, tile, steps, fused_ms):
                             "frac": round(32 * cells / (ts * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             **({"frac_of_copy_ceiling": round(32 * cells / (ts * 1e-3) / 1e9 / ceilings[3], 4)} if 3 in ceilings else {})},
             "fusion_speedup": round(ms / fused_ms, 3)}
+
+
+def shallow_water_x2(D, torch, stream, g, F, prm, tile, steps, fused_ms):
+    """Secondary object (never `value`): TWO leapfrog steps per launch (dlesm_shallow_step_x2_f64) -- six arrays
+    read and six written per two steps, 48 B/cell/step instead of 72 -- the one lever above the nine-stream ceiling the
+    fused step sits on.  First both new levels against two single steps on the full tile (bit for bit), then >= 24
+    launches with the four-level rotation, beside the 6-read + 6-written copy of the same arrays."""
+    names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
+    A = [F[n] for n in names]
+    for f in A[6:]:                                          # (the time-smooth leg before may have left anything here: a ring
+        D.copy_field(A[0], f, stream=stream)                 #  that holds finite values is all the comparison needs)
+    extra = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(6)]                  # level n+2, and three levels of the reference run
+    n2, ref = extra[:3], extra[3:]
+    with torch.cuda.stream(stream):
+        for f in extra:
+            D.copy_field(A[0], f, stream=stream)
+        ref1 = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(3)]
+        for f in ref1:
+            D.copy_field(A[0], f, stream=stream)
+        D.psy.invoke_shallow_step_x2(prm, *A, *n2, stream=stream)
+        D.psy.invoke_shallow_step(prm, *A[:6], *ref1, stream=stream)
+        D.psy.invoke_shallow_step(prm, *ref1, *A[:3], *ref, stream=stream)
+    stream.synchronize()
+    same = all(torch.equal(a.data, b.data) for a, b in zip(A[6:] + n2, ref1 + ref))
+    del ref1, ref
+    launches = max(MIN_SECONDARY_LAUNCHES, steps // 2)
+    cur, old, l1, l2 = A[:3], A[3:6], A[6:], n2
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        for k in range(launches + 4):
+            if k == 4:
+                e0.record(stream)
+            D.psy.invoke_shallow_step_x2(prm, *cur, *old, *l1, *l2, stream=stream)
+            cur, old, l1, l2 = l2, l1, old, cur
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    cells = tile * tile
+    gbs = 96 * cells / (ms * 1e-3) / 1e9
+    out = {"what": "two leapfrog steps per launch: levels n+1 and n+2 from n and n-1, six arrays read + six written",
+           "launches": launches, "time_steps": 2 * launches, "value": round(2 * cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s",
+           "ms_per_launch": round(ms, 5), "ms_per_step": round(ms / 2, 5),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_cell_per_launch": 96, "algorithmic_bytes_per_cell_per_step": 48,
+                        "kernel": "shallow_tile_x2<4,2> (four-row tiles, the four waves of a workgroup vertically adjacent)"},
+           "bit_identical_to_two_single_steps": bool(same), "speedup_per_step_vs_fused_step": round(2 * fused_ms / ms, 3)}
+    try:
+        cc = copy_ceiling(D, torch, stream, [f.data for f in cur + old], [f.data for f in l1 + l2], g.nx * g.ny)
+        out["copy_ceiling"] = cc
+        out["roofline"]["frac_of_copy_ceiling"] = round(gbs / cc["best_gbs"], 4)
+    except Exception as e:                                   # noqa: BLE001
+        out["copy_ceiling"] = {"error": f"{type(e).__name__}: {e}"}
+    del extra, n2
+    torch.cuda.empty_cache()
+    return out
 
 
 def shallow_water_smooth(D, torch, stream, g, F, prm, tile, steps, alpha=0.001):

@@ -61,6 +61,7 @@ static const struct { const char *key; int cls; } kKeys[] = {
     // ---- HOOK: fall-back kernels (unaligned bases, odd pitches, thin boxes) and the forms DLESM_DM_SAFE / a capture select
     {"j5_variant", KEY_HOOK}, {"sw_kernel", KEY_HOOK}, {"swk_kernel", KEY_HOOK}, {"s9_kernel", KEY_HOOK}, {"j5m_kernel", KEY_HOOK},
     {"cont_kernel", KEY_HOOK}, {"sw_thin_box", KEY_HOOK}, {"sw_wrap_fused", KEY_HOOK}, {"sw_smooth_fused", KEY_HOOK},
+    {"sw_x2_fused", KEY_HOOK},
     {"util_rowseg", KEY_HOOK}, {"util_rowlinear", KEY_HOOK}, {"util_gather_linear", KEY_HOOK},
     {"j5_dm_fused", KEY_HOOK}, {"sw_dm_fused", KEY_HOOK}, {"s9_dm_fused", KEY_HOOK}, {"j5_dm_chain", KEY_HOOK}, {"sw_dm_chain", KEY_HOOK},
     {"j5_dm_lazy_unpack", KEY_HOOK}, {"j5_dm_frame_pack", KEY_HOOK}, {"dm_flag_join", KEY_HOOK}, {"dm_aggregate", KEY_HOOK},
@@ -74,6 +75,7 @@ static const struct { const char *key; int cls; } kKeys[] = {
     {"j5xt_march", KEY_LAB}, {"j5xt_march_slots", KEY_LAB}, {"j5xt_march_ring", KEY_LAB}, {"j5xt_march_perm", KEY_LAB},
     {"sw_tile_rows", KEY_LAB}, {"sw_dpp", KEY_LAB}, {"sw_stack", KEY_LAB}, {"sw_dm_diag", KEY_LAB},
     {"dm_event_system_fence", KEY_LAB}, {"util_segp", KEY_LAB},
+    {"sw_x2_rows", KEY_LAB}, {"sw_x2_nt", KEY_LAB}, {"sw_x2_stack", KEY_LAB}, {"sw_x2_pad", KEY_LAB},
 };
 static int key_class(const char *key)
 {

@@ -1,0 +1,277 @@
+// TWO leapfrog steps of the shallow-water update (NE offset) per launch.
+//
+// The fused single step sits on the measured ceiling of its nine concurrent HBM streams (0.75 of peak = 1.03 x a plain
+// 6-read + 3-write copy); the only way to more cells per second is fewer bytes per time step.  With levels n (u, v, p) and
+// n-1 (uold, vold, pold) in memory, one launch of this kernel writes level n+1 AND level n+2:
+//
+//     level n+1 = step(level n,   level n-1)        on the box and, in registers only, one cell around each wave tile
+//     level n+2 = step(level n+1, level n)          on the box
+//
+// six arrays read once, six written once: 96 B/cell per TWO steps = 48 B/cell/step against 72.  Each stage is the expression
+// tree of the single step, operand for operand (the first stage evaluated redundantly on the one-cell rim of the tile, as
+// temporal blocking always does), so the two levels are bit-identical to two calls of dlesm_shallow_step_f64.
+//
+// Wave tile: 62 output lanes x 2 doubles x R rows, as shallow_tile.  A lane holds two columns, so the ONE halo lane per side
+// the single step needs already covers the two columns two steps need: stage 1 is valid on columns 1 .. 126 of the wave's
+// 128, stage 2 on the 124 columns of lanes 1 .. 62.  Vertically the tile loads rows jb-2 .. jb+R+1 of level n and rows
+// jb-1 .. jb+R of level n-1.  Cells of level n+1 that lie OUTSIDE the box (the fixed boundary ring of a non-periodic model)
+// are not computed: they are what the level-n+1 arrays hold there, loaded by the tiles that touch the edge of the box only.
+//
+// Level n+2 cannot go into the arrays of level n-1 in place, as the filtered step's old level does: stage 1 reads level n-1
+// one cell around the tile, i.e. cells a neighbouring tile would be overwriting.  Four time levels, twelve arrays.
+#include <cstdint>
+
+#include "dlesm_internal.h"
+#include "dlesm_device.h"
+
+namespace dlesm {
+
+namespace {
+
+typedef double x2_d2 __attribute__((ext_vector_type(2)));
+struct W2 { double x, y; };
+
+template <bool NT>
+__device__ __forceinline__ W2 xld(const double *p)
+{
+    x2_d2 t = NT ? __builtin_nontemporal_load((const x2_d2 *)p) : *(const x2_d2 *)p;
+    return W2{t.x, t.y};
+}
+template <bool NT>
+__device__ __forceinline__ void xst(double *p, const W2 &v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(x2_d2{v.x, v.y}, (x2_d2 *)p);
+    else *(x2_d2 *)p = x2_d2{v.x, v.y};
+}
+__device__ __forceinline__ W2 east(const W2 &a) { return W2{a.y, from_upper<true>(a.x)}; }
+__device__ __forceinline__ W2 west(const W2 &a) { return W2{from_lower<true>(a.y), a.x}; }
+#define XW(ex, ey) W2{(ex), (ey)}
+
+// One step on register rows: U, V, P hold NR + 2 rows (index k = row r0 - 1 + k), the old level NR rows (index k - 1 = row
+// r0 - 1 + k, k = 1 .. NR); the new level comes out for those NR rows.  The expression trees of shallow_tile_body
+// (dlesm_shallow.hip) = DESIGN.md section 6, operand for operand.
+template <int NR>
+__device__ __forceinline__ void sw_step_rows(const dlesm_sw_params &q, const W2 (&U)[NR + 2], const W2 (&V)[NR + 2], const W2 (&P)[NR + 2],
+                                             const W2 (&UO)[NR], const W2 (&VO)[NR], const W2 (&PO)[NR], W2 (&UN)[NR], W2 (&VN)[NR],
+                                             W2 (&PN)[NR])
+{
+    W2 Pe[NR + 2], Ve[NR + 1], Uw[NR + 2];
+#pragma unroll
+    for (int k = 0; k < NR + 2; k++) Pe[k] = east(P[k]);
+#pragma unroll
+    for (int k = 0; k < NR + 1; k++) Ve[k] = east(V[k]);
+#pragma unroll
+    for (int k = 1; k < NR + 2; k++) Uw[k] = west(U[k]);
+    W2 CU[NR + 2], CV[NR + 1], Z[NR + 1], H[NR + 2];
+#pragma unroll
+    for (int k = 1; k < NR + 2; k++) {
+        CU[k] = XW(0.5 * (Pe[k].x + P[k].x) * U[k].x, 0.5 * (Pe[k].y + P[k].y) * U[k].y);
+        H[k] = XW(P[k].x + 0.25 * (U[k].x * U[k].x + Uw[k].x * Uw[k].x + V[k].x * V[k].x + V[k - 1].x * V[k - 1].x),
+                  P[k].y + 0.25 * (U[k].y * U[k].y + Uw[k].y * Uw[k].y + V[k].y * V[k].y + V[k - 1].y * V[k - 1].y));
+    }
+#pragma unroll
+    for (int k = 0; k < NR + 1; k++) {
+        CV[k] = XW(0.5 * (P[k + 1].x + P[k].x) * V[k].x, 0.5 * (P[k + 1].y + P[k].y) * V[k].y);
+        Z[k] = XW((q.fsdx * (Ve[k].x - V[k].x) - q.fsdy * (U[k + 1].x - U[k].x)) / (P[k].x + Pe[k].x + Pe[k + 1].x + P[k + 1].x),
+                  (q.fsdx * (Ve[k].y - V[k].y) - q.fsdy * (U[k + 1].y - U[k].y)) / (P[k].y + Pe[k].y + Pe[k + 1].y + P[k + 1].y));
+    }
+    W2 CUw[NR + 2], Zw[NR + 1], CVe[NR + 1], He[NR + 1];
+#pragma unroll
+    for (int k = 1; k < NR + 2; k++) CUw[k] = west(CU[k]);
+#pragma unroll
+    for (int k = 1; k < NR + 1; k++) Zw[k] = west(Z[k]);
+#pragma unroll
+    for (int k = 0; k < NR + 1; k++) CVe[k] = east(CV[k]);
+#pragma unroll
+    for (int k = 1; k < NR + 1; k++) He[k] = east(H[k]);
+#pragma unroll
+    for (int k = 1; k <= NR; k++) {
+        UN[k - 1] = XW(UO[k - 1].x + q.tdts8 * (Z[k].x + Z[k - 1].x) * (CVe[k].x + CV[k].x + CV[k - 1].x + CVe[k - 1].x) -
+                           q.tdtsdx * (He[k].x - H[k].x),
+                       UO[k - 1].y + q.tdts8 * (Z[k].y + Z[k - 1].y) * (CVe[k].y + CV[k].y + CV[k - 1].y + CVe[k - 1].y) -
+                           q.tdtsdx * (He[k].y - H[k].y));
+        VN[k - 1] = XW(VO[k - 1].x - q.tdts8 * (Z[k].x + Zw[k].x) * (CU[k + 1].x + CUw[k + 1].x + CUw[k].x + CU[k].x) -
+                           q.tdtsdy * (H[k + 1].x - H[k].x),
+                       VO[k - 1].y - q.tdts8 * (Z[k].y + Zw[k].y) * (CU[k + 1].y + CUw[k + 1].y + CUw[k].y + CU[k].y) -
+                           q.tdtsdy * (H[k + 1].y - H[k].y));
+        PN[k - 1] = XW(PO[k - 1].x - q.tdtsdx * (CU[k].x - CUw[k].x) - q.tdtsdy * (CV[k].x - CV[k - 1].x),
+                       PO[k - 1].y - q.tdtsdx * (CU[k].y - CUw[k].y) - q.tdtsdy * (CV[k].y - CV[k - 1].y));
+    }
+}
+
+struct X2Arrays {
+    const double *u, *v, *p;          // level n   (3 x 3 footprint, two cells deep)
+    const double *uo, *vo, *po;       // level n-1 (read at the cell, one cell around the tile)
+    double *u1, *v1, *p1;             // level n+1 (written on the box; its ring is READ by the tiles on the edge of the box)
+    double *u2, *v2, *p2;             // level n+2 (written on the box)
+};
+
+// NTM bit 0: level n-1 loaded non-temporally; bit 1: both new levels stored non-temporally; bit 2: every row load of the tile is
+// issued before the first use (a scheduling barrier behind the load block: without it the compiler, short of registers,
+// interleaves loads and arithmetic and a wave goes through ten dependent memory round trips with five loads in flight)
+template <int R, int NTM>
+__global__ __launch_bounds__(512) void shallow_tile_x2(dlesm_sw_params q, int ld, int ny, int x0, int x1, int y0, int y1, int cb, int nxw,
+                                                       int stack, X2Arrays a)
+{
+    const int lane = threadIdx.x & 63;
+    int xw, strip;
+    if (stack) {      // the waves of a workgroup are VERTICALLY adjacent tiles: the rows two of them share are requested by one CU
+        xw = blockIdx.x % nxw;
+        strip = (blockIdx.x / nxw) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    } else {
+        const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        xw = w % nxw, strip = w / nxw;
+    }
+    const int jb = y0 + strip * R;
+    if (jb > y1) return;
+    const int je = jb + R - 1 < y1 ? jb + R - 1 : y1;
+    const int c = cb + xw * 62 - 1 + lane;             // this lane's chunk (2 columns)
+    if (c - lane + 1 > x1 / 2) return;                 // idle padding tile
+    const int c_ld = ld / 2 - 1;
+    const int cl = c < 0 ? 0 : (c > c_ld ? c_ld : c);  // halo / trailing lanes: any valid chunk
+    const bool out_lane = lane >= 1 && lane <= 62 && c <= c_ld;
+    const bool m0 = out_lane && 2 * c >= x0 && 2 * c <= x1;
+    const bool m1 = out_lane && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
+    const size_t col = (size_t)cl * 2;
+    auto rowclamp = [&](int jj) { return jj < 0 ? 0 : (jj > ny - 1 ? ny - 1 : jj); };   // (rows off the array: loaded, never used)
+
+    // level n: rows jb-2 .. jb+R+1 (index k); level n-1: rows jb-1 .. jb+R (index k)
+    W2 U[R + 4], V[R + 4], P[R + 4], UO[R + 2], VO[R + 2], PO[R + 2];
+#pragma unroll
+    for (int k = 0; k < R + 4; k++) {
+        const size_t o = (size_t)rowclamp(jb - 2 + k) * ld + col;
+        U[k] = xld<false>(a.u + o);
+        V[k] = xld<false>(a.v + o);
+        P[k] = xld<false>(a.p + o);
+    }
+#pragma unroll
+    for (int k = 0; k < R + 2; k++) {
+        const size_t o = (size_t)rowclamp(jb - 1 + k) * ld + col;
+        UO[k] = xld<(NTM & 1) != 0>(a.uo + o);
+        VO[k] = xld<(NTM & 1) != 0>(a.vo + o);
+        PO[k] = xld<(NTM & 1) != 0>(a.po + o);
+    }
+    if constexpr ((NTM & 4) != 0) __builtin_amdgcn_sched_barrier(0);
+    // stage 1: level n+1 on rows jb-1 .. jb+R (index k), every lane's two columns
+    W2 U1[R + 2], V1[R + 2], P1[R + 2];
+    sw_step_rows<R + 2>(q, U, V, P, UO, VO, PO, U1, V1, P1);
+    // cells of level n+1 outside the box are the fixed ring the level-n+1 arrays hold: only tiles on the edge of the box
+    // (wave-uniform test) load them
+    const int c0 = c - lane;                            // lane 0's chunk
+    const bool rim = jb - 1 < y0 || jb + R > y1 || 2 * c0 < x0 || 2 * c0 + 127 > x1;
+    if (rim) {
+#pragma unroll
+        for (int k = 0; k < R + 2; k++) {
+            const int jj = jb - 1 + k;
+            const size_t o = (size_t)rowclamp(jj) * ld + col;
+            const W2 ru = xld<false>(a.u1 + o), rv = xld<false>(a.v1 + o), rp = xld<false>(a.p1 + o);
+            const bool rin = jj >= y0 && jj <= y1;
+            const bool i0 = rin && 2 * c >= x0 && 2 * c <= x1, i1 = rin && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
+            U1[k] = XW(i0 ? U1[k].x : ru.x, i1 ? U1[k].y : ru.y);
+            V1[k] = XW(i0 ? V1[k].x : rv.x, i1 ? V1[k].y : rv.y);
+            P1[k] = XW(i0 ? P1[k].x : rp.x, i1 ? P1[k].y : rp.y);
+        }
+    }
+    // stage 2: level n+2 on rows jb .. jb+R-1 from level n+1 (rows jb-1 .. jb+R) and level n (rows jb .. jb+R-1) as the old one
+    W2 U2[R], V2[R], P2[R], UC[R], VC[R], PC[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) { UC[k] = U[k + 2]; VC[k] = V[k + 2]; PC[k] = P[k + 2]; }
+    sw_step_rows<R>(q, U1, V1, P1, UC, VC, PC, U2, V2, P2);
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int jj = jb + k;
+        if (jj > je) break;
+        const size_t o = (size_t)jj * ld + (size_t)c * 2;
+        if (m0 && m1) {
+            xst<(NTM & 2) != 0>(a.u1 + o, U1[k + 1]);
+            xst<(NTM & 2) != 0>(a.v1 + o, V1[k + 1]);
+            xst<(NTM & 2) != 0>(a.p1 + o, P1[k + 1]);
+            xst<(NTM & 2) != 0>(a.u2 + o, U2[k]);
+            xst<(NTM & 2) != 0>(a.v2 + o, V2[k]);
+            xst<(NTM & 2) != 0>(a.p2 + o, P2[k]);
+        } else {
+            if (m0) { a.u1[o] = U1[k + 1].x; a.v1[o] = V1[k + 1].x; a.p1[o] = P1[k + 1].x; a.u2[o] = U2[k].x; a.v2[o] = V2[k].x; a.p2[o] = P2[k].x; }
+            if (m1) { a.u1[o + 1] = U1[k + 1].y; a.v1[o + 1] = V1[k + 1].y; a.p1[o + 1] = P1[k + 1].y;
+                      a.u2[o + 1] = U2[k].y; a.v2[o + 1] = V2[k].y; a.p2[o + 1] = P2[k].y; }
+        }
+    }
+}
+
+} // namespace
+
+} // namespace dlesm
+
+using namespace dlesm;
+
+// Two leapfrog steps, one launch (NE offset, fixed boundary ring): level n+1 into (unew, vnew, pnew), level n+2 into
+// (unew2, vnew2, pnew2) -- bit for bit what
+//     dlesm_shallow_step_f64(q, ..., u, v, p, uold, vold, pold, unew, vnew, pnew);
+//     dlesm_shallow_step_f64(q, ..., unew, vnew, pnew, u, v, p, unew2, vnew2, pnew2);
+// leave behind, INCLUDING what the second call reads outside the box: the ring of unew, vnew, pnew (which no step writes) must
+// hold the boundary values before the call, as for the two calls.  Arrays that miss the conditions of the wave-tile kernel
+// (16-byte aligned bases; an even leading dimension or a box that ends inside the last whole 2-column chunk) take those two calls.
+extern "C" int dlesm_shallow_step_x2_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                                         const double *u, const double *v, const double *p, const double *uold, const double *vold,
+                                         const double *pold, double *unew, double *vnew, double *pnew, double *unew2, double *vnew2,
+                                         double *pnew2, void *stream)
+{
+    clear_error();
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(q && u && v && p && uold && vold && pold && unew && vnew && pnew && unew2 && vnew2 && pnew2, "null pointer");
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("dlesm_shallow_step_x2_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    const double *all[12] = {u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2};
+    for (int i = 0; i < 12; i++)
+        for (int j = i + 1; j < 12; j++)
+            DLESM_REQUIRE(all[i] != all[j], "dlesm_shallow_step_x2_f64: the twelve arrays must be distinct (arguments %d and %d are not)", i, j);
+    bool aligned = ld % 2 == 0 || (xstop - 1) + 1 <= 2 * (ld / 2) - 1;
+    for (const double *f : all) aligned = aligned && ((uintptr_t)f % 16 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (!aligned || tuning("sw_kernel", 0) != 0 || !tuning("sw_x2_fused", 1)) {      // the definition: two single steps
+        if (int rc = dlesm_shallow_step_f64(q, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, unew, vnew, pnew, stream)) return rc;
+        return dlesm_shallow_step_f64(q, ld, ny, xstart, xstop, ystart, ystop, unew, vnew, pnew, u, v, p, unew2, vnew2, pnew2, stream);
+    }
+    const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
+    const int cb = (x0 / 2) & ~7;                        // tiles anchored on a 128-byte line of the row, as shallow_tile
+    // The shape measured best at 8192^2 (scripts/shallow_x2_probe.py, profiles/r04_shallow_x2.txt): four-row tiles; the four
+    // waves of a workgroup are four VERTICALLY adjacent tiles, so that of the (R+4)/R = 2 x re-read of level n only the two
+    // rows above and below a 16-row band come from another workgroup (the same tiles dealt row-major to the workgroups, as
+    // every single-step sweep does, leave half of the re-reads to other XCDs: 1.53 against 1.22 ms); new levels stored
+    // non-temporally, level n-1 loaded with the default policy (its halo rows ARE re-read; non-temporal: 1.47 ms).
+    // sw_x2_rows / _nt / _stack / _pad select the comparison forms (lab build).
+    int R = 4, nt = 2, stack = 4, pad = 0;
+    if (kLab) {
+        R = tuning("sw_x2_rows", 4);
+        if (R != 2 && R != 6) R = 4;
+        nt = tuning("sw_x2_nt", 2) & 7;
+        stack = tuning("sw_x2_stack", 4);
+        pad = tuning("sw_x2_pad", 0);
+    }
+    int nxw = (x1 / 2 - cb + 62) / 62, tpb = 4;
+    if (stack) {
+        nxw += pad;
+        tpb = stack == 2 ? 2 : stack == 8 ? 8 : 4;
+    } else {
+        choose_block_shape(&nxw, &tpb);
+        if (tpb > 8) tpb = 8;
+    }
+    const int strips = (y1 - y0 + R) / R;
+    const unsigned grid = stack ? (unsigned)((long)nxw * ((strips + tpb - 1) / tpb)) : (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
+    X2Arrays a{u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2};
+#define DLESM_X2(RR, NN) hipLaunchKernelGGL((shallow_tile_x2<RR, NN>), dim3(grid), dim3(64 * tpb), 0, s, *q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a)
+#ifdef DLESM_LAB
+#define DLESM_X2R(RR)                                                                                                  \
+    switch (nt) {                                                                                                      \
+    case 0: DLESM_X2(RR, 0); break; case 3: DLESM_X2(RR, 3); break; case 4: DLESM_X2(RR, 4); break;                   \
+    case 6: DLESM_X2(RR, 6); break; case 7: DLESM_X2(RR, 7); break; default: DLESM_X2(RR, 2); break;                  \
+    }
+    if (R == 2) { DLESM_X2R(2) } else if (R == 6) { DLESM_X2R(6) } else { DLESM_X2R(4) }
+#undef DLESM_X2R
+#else
+    (void)nt;
+    DLESM_X2(4, 2);
+#endif
+#undef DLESM_X2
+    DLESM_HIP_TRY(hipGetLastError());
+    return DLESM_OK;
+}

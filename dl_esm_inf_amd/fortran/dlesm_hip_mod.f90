@@ -215,6 +215,14 @@ module dlesm_hip_mod
        type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, stream
        integer(c_int) :: rc
      end function
+     function dlesm_shallow_step_x2_f64(params, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, &
+          unew, vnew, pnew, unew2, vnew2, pnew2, stream) bind(C, name="dlesm_shallow_step_x2_f64") result(rc)
+       import :: c_int, c_ptr, c_sw_params
+       type(c_sw_params), intent(in) :: params
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2, stream
+       integer(c_int) :: rc
+     end function
      function dlesm_shallow_step_smooth_f64(params, alpha, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
           uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_step_smooth_f64") result(rc)
        import :: c_int, c_ptr, c_sw_params, c_double

@@ -57,6 +57,7 @@ module dlesm_psy_mod
   public :: invoke_compute_unew, invoke_compute_vnew, invoke_compute_pnew, invoke_time_smooth
   public :: invoke_shallow_step_sw_periodic, plan_shallow_step_sw, invoke_periodic_halos_multi
   public :: invoke_shallow_step_smooth, invoke_shallow_step_sw_smooth_periodic, invoke_shallow_step_smooth_dm
+  public :: invoke_shallow_step_x2
 
 contains
 
@@ -382,6 +383,28 @@ contains
                                        field_device_data(unew), field_device_data(vnew), field_device_data(pnew), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_shallow_step_smooth: ' // dlesm_error_text())
   end subroutine invoke_shallow_step_smooth
+
+  !> TWO leapfrog steps in one launch (NE offset, fixed boundary ring): level n+1 into unew, vnew, pnew and level n+2 into
+  !! unew2, vnew2, pnew2 -- == invoke_shallow_step(prm, u, v, p, uold, vold, pold, unew, vnew, pnew) followed by
+  !! invoke_shallow_step(prm, unew, vnew, pnew, u, v, p, unew2, vnew2, pnew2), bit for bit, at 48 instead of 72 B/cell/step.
+  !! Twelve distinct fields; afterwards rotate (cur, old, new1, new2) <- (new2, new1, old, cur).
+  subroutine invoke_shallow_step_x2(prm, u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2)
+    type(c_sw_params), intent(in) :: prm
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    call need_device(unew2);  call need_device(vnew2);  call need_device(pnew2)
+    rc = dlesm_shallow_step_x2_f64(prm, int(p%grid%nx, c_int), int(p%grid%ny, c_int), &
+                                   int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                                   int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                                   field_device_data(u), field_device_data(v), field_device_data(p), &
+                                   field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                   field_device_data(unew), field_device_data(vnew), field_device_data(pnew), &
+                                   field_device_data(unew2), field_device_data(vnew2), field_device_data(pnew2), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_x2: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_x2
 
   !> The same for the SW-offset periodic model: update, filter and the periodic images of the new and of the filtered old
   !! level in ONE launch -- a whole time step of the GOcean `shallow` benchmark.

@@ -150,6 +150,16 @@ def invoke_shallow_step(params, u, v, p, uold, vold, pold, unew, vnew, pnew, str
                                              pnew.device_ptr, _stream_ptr(stream)))
 
 
+def invoke_shallow_step_x2(params, u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2, stream=None):
+    """TWO leapfrog steps in one launch (dlesm_shallow_step_x2_f64): level n+1 into unew / vnew / pnew, level n+2 into
+    unew2 / vnew2 / pnew2 -- the bits of two invoke_shallow_step calls at 48 instead of 72 B/cell/step.  Time loop:
+    (cur, old, new1, new2) <- (new2, new1, old, cur) after every call."""
+    g, it = p.grid, p.internal
+    check(_cabi.lib().dlesm_shallow_step_x2_f64(C.byref(params), g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop,
+                                                *[f.device_ptr for f in (u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2)],
+                                                _stream_ptr(stream)))
+
+
 def invoke_shallow_step_sw(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
     """the SW-offset form (the GOcean `shallow` staggering); periodic models follow it with
     apply_periodic_halos on the three new fields"""

@@ -330,6 +330,19 @@ int dlesm_shallow_step_sw_periodic_f64(const dlesm_sw_params *params, int ld, in
                                        const double *uold, const double *vold, const double *pold,
                                        double *unew, double *vnew, double *pnew, void *stream);
 
+/* TWO leapfrog steps per launch (NE offset, fixed boundary ring): level n+1 into unew / vnew / pnew and
+ * level n+2 into unew2 / vnew2 / pnew2, bit for bit what
+ *     dlesm_shallow_step_f64(..., u, v, p, uold, vold, pold, unew, vnew, pnew);
+ *     dlesm_shallow_step_f64(..., unew, vnew, pnew, u, v, p, unew2, vnew2, pnew2);
+ * leave behind -- six arrays read and six written per TWO steps, 48 B/cell/step instead of 72.  As for those two calls the ring of
+ * unew, vnew, pnew outside the box (which no step writes) must hold the boundary values before the call.  Twelve distinct
+ * arrays (level n+2 cannot overwrite level n-1 in place: the first stage reads it one cell around each tile).  The PSy-layer
+ * loop nests it replaces: two passes of the un-fused GOcean kernel sequence (infrastructure_mod.f90:13-41 for the form). */
+int dlesm_shallow_step_x2_f64(const dlesm_sw_params *q, int ld, int ny, int xstart, int xstop, int ystart, int ystop,
+                              const double *u, const double *v, const double *p, const double *uold, const double *vold,
+                              const double *pold, double *unew, double *vnew, double *pnew, double *unew2, double *vnew2,
+                              double *pnew2, void *stream);
+
 /* One WHOLE time step of the GOcean leapfrog in one launch: the u/v/h update AND the Asselin filter of the old level
  * (the benchmark's time_smooth kernel), from values the lanes already hold --
  *     unew, vnew, pnew <- step(u, v, p, uold, vold, pold);   uold <- u + alpha*(unew - 2*u + uold)   (likewise vold, pold; in place)

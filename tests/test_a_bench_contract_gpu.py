@@ -48,6 +48,9 @@ def test_bench_line_and_secondary_legs():
     ts = sw["with_time_smooth"]
     assert "error" not in ts and ts["bit_identical_to_step_plus_time_smooth"] is True and ts["roofline"]["algorithmic_bytes_per_cell"] == 96, ts
     assert sw["copy_ceiling"]["best_gbs"] > 0 and 0 < sw["roofline"]["frac_of_copy_ceiling"] < 2, sw
+    x2 = sw["two_steps_per_launch"]          # round 4: two leapfrog steps per launch, 48 B/cell/step
+    assert "error" not in x2 and x2["bit_identical_to_two_single_steps"] is True and x2["value"] > 0, x2
+    assert x2["roofline"]["algorithmic_bytes_per_cell_per_step"] == 48 and x2["copy_ceiling"]["best_gbs"] > 0, x2
     assert sw["sw_offset_periodic"]["one_launch_equals_step_plus_halo_copies"] is True, sw["sw_offset_periodic"]
     assert d["copy_ceiling"]["best_gbs"] > 0 and 0 < d["roofline"]["frac_of_copy_ceiling"] < 2, d["copy_ceiling"]
     lb = d["dm_loopback"]        # round 3: the distributed step over the peer transport beside the RCCL form, loop-back

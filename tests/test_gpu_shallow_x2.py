@@ -1,0 +1,176 @@
+"""GPU tests (-m gpu): two leapfrog steps of the shallow-water update per launch (dlesm_shallow_step_x2_f64, DESIGN.md
+section 5.4) against the ORACLE's step applied twice with the leapfrog rotation -- every bit of both new levels, ring cells
+included -- on shapes that exercise the rim handling (tiles on every edge of the box, one-tile boxes, boxes narrower than a wave
+tile, odd leading dimensions, heights that are not a multiple of the tile height), the forced fall-back (two single steps), time
+loops of several double steps against single steps, and the full-size configuration against the single-step kernel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+SEED = 20261004 + 40
+NAMES = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew", "unew2", "vnew2", "pnew2"]
+
+
+@pytest.fixture(scope="module")
+def D():
+    import torch
+    import dl_esm_inf_amd as d
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    d.parallel_init(0, 1)
+    return d
+
+
+def _grid(D, nx, ny, alignment):
+    import os
+    if alignment is None:
+        os.environ.pop("DL_ESM_ALIGNMENT", None)
+    else:
+        os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_EXTERNAL, D.GO_BC_EXTERNAL, D.GO_BC_NONE), D.GO_OFFSET_NE)
+    g.decompose(nx, ny)
+    D.grid_init(g, 1.0, 1.0)
+    return g
+
+
+def _fields(D, g, seed=SEED):
+    """twelve fields; levels n and n-1 are hash data in physically sane ranges over the WHOLE array; the boundary ring of every
+    level holds the same fixed values (what a non-periodic model keeps there): the ring of u / v / p"""
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    F = {n: D.r2d_field(g, pts[n[0]]) for n in NAMES}
+    for k, n in enumerate(NAMES[:6]):
+        D.psy.hash_init(F[n], seed + k)
+        F[n].data.mul_(0.1)
+        F[n].data.add_(1.0 if n[0] == "p" else -0.05)
+    for k, n in enumerate(NAMES[6:]):
+        D.copy_field(F[NAMES[k % 3]], F[n])          # ring = the ring of level n; the interior is overwritten by the step
+    it = F["p"].internal
+    for k, n in enumerate(NAMES[3:6]):               # ... and level n-1 has that ring too (its interior stays its own)
+        keep = F[n].data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop].clone()
+        D.copy_field(F[NAMES[k]], F[n])
+        F[n].data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop] = keep
+    return F
+
+
+def _oracle_two_steps(prm, g, box, H):
+    """level n+1 and n+2 by two oracle steps (the second reads the first's output incl. its untouched ring)"""
+    n1 = [H[n].copy() for n in NAMES[6:9]]
+    n2 = [H[n].copy() for n in NAMES[9:]]
+    O.sw_step(prm, g.nx, box, H["u"], H["v"], H["p"], H["uold"], H["vold"], H["pold"], *n1)
+    O.sw_step(prm, g.nx, box, *n1, H["u"], H["v"], H["p"], *n2)
+    return n1, n2
+
+
+CASES = [(5, 4, None), (5, 4, 2), (1, 1, 2), (2, 1, 2), (1, 3, 2), (64, 48, 8), (123, 3, 2), (124, 5, 2), (125, 2, 2), (126, 7, 64),
+         (127, 9, None), (257, 129, None), (300, 70, 64), (1000, 37, 64), (2100, 33, 64), (4000, 9, 2), (8000, 9, 64)]
+
+
+TUNES = [dict(), dict(sw_x2_stack=0), dict(sw_x2_rows=2, sw_x2_nt=7), dict(sw_x2_rows=6, sw_x2_nt=6, sw_x2_stack=8), dict(sw_x2_nt=3, sw_x2_stack=2, sw_x2_pad=3),
+         dict(sw_x2_rows=2, sw_x2_nt=0, sw_x2_stack=0)]      # (all but the first: comparison forms, libdlesm_hip_lab.so)
+X2_DEFAULTS = dict(sw_x2_rows=4, sw_x2_nt=2, sw_x2_stack=4, sw_x2_pad=0)
+
+
+@pytest.mark.parametrize("tune", TUNES, ids=lambda t: "-".join(f"{k[6:]}{v}" for k, v in t.items()) or "default")
+@pytest.mark.parametrize("nx,ny,alignment", CASES)
+def test_two_steps_per_launch_match_the_oracle(D, nx, ny, alignment, tune):
+    import torch
+    L = D._cabi.lib()
+    g = _grid(D, nx, ny, alignment)
+    F = _fields(D, g)
+    prm = D.psy.shallow_params(1.0e5, 0.9e5, 40.0)
+    H = {n: F[n].get_data() for n in NAMES}
+    box = F["p"].internal.box()
+    n1, n2 = _oracle_two_steps(prm, g, box, H)
+    for k, v in tune.items():
+        L.dlesm_set_tuning(k.encode(), v)
+    try:
+        D.psy.invoke_shallow_step_x2(prm, *[F[n] for n in NAMES])
+        torch.cuda.synchronize()
+    finally:
+        for k in tune:
+            L.dlesm_set_tuning(k.encode(), X2_DEFAULTS[k])
+    for name, want in zip(NAMES[6:], n1 + n2):
+        got = F[name].get_data()
+        assert np.array_equal(got, want), (name, int(np.count_nonzero(got != want)), np.argwhere(got != want)[:4])
+    for n in NAMES[:6]:                              # the inputs are untouched
+        assert np.array_equal(F[n].get_data(), H[n]), n
+
+
+@pytest.mark.parametrize("nx,ny,alignment", [(300, 70, 64), (127, 9, None)])
+def test_forced_fallback_is_two_single_steps(D, nx, ny, alignment):
+    import torch
+    L = D._cabi.lib()
+    g = _grid(D, nx, ny, alignment)
+    F = _fields(D, g, SEED + 100)
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 60.0)
+    H = {n: F[n].get_data() for n in NAMES}
+    n1, n2 = _oracle_two_steps(prm, g, F["p"].internal.box(), H)
+    for key in (b"sw_x2_fused", b"sw_kernel"):
+        for n in NAMES[6:]:
+            F[n].set_data(H[n])
+        L.dlesm_set_tuning(key, 0 if key == b"sw_x2_fused" else 1)
+        try:
+            D.psy.invoke_shallow_step_x2(prm, *[F[n] for n in NAMES])
+            torch.cuda.synchronize()
+        finally:
+            L.dlesm_set_tuning(key, 1 if key == b"sw_x2_fused" else 0)
+        for name, want in zip(NAMES[6:], n1 + n2):
+            assert np.array_equal(F[name].get_data(), want), (key, name)
+
+
+def test_refusals(D):
+    L = D._cabi.lib()
+    g = _grid(D, 64, 48, 8)
+    F = _fields(D, g)
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 60.0)
+    it = F["p"].internal
+    ptrs = [F[n].device_ptr for n in NAMES]
+    call = lambda p_, box: L.dlesm_shallow_step_x2_f64(C.byref(prm), g.nx, g.ny, *box, *p_, None)      # noqa: E731
+    assert call(ptrs, it.box()) == 0
+    aliased = list(ptrs)
+    aliased[9] = aliased[3]                           # level n+2 into the arrays of level n-1: refused (not in place)
+    assert call(aliased, it.box()) == D._cabi.EINVAL and b"distinct" in L.dlesm_last_error()
+    assert call(ptrs, (1, it.xstop, it.ystart, it.ystop)) == D._cabi.EINVAL          # no room for the stencil ring
+    assert call(ptrs, (5, 4, it.ystart, it.ystop)) == 0                              # an empty box: a zero-trip loop nest
+
+
+@pytest.mark.parametrize("nx,ny,alignment,pairs", [(257, 129, None, 3), (640, 200, 64, 4)])
+def test_time_loop_of_double_steps_equals_single_steps(D, nx, ny, alignment, pairs):
+    """2 x pairs leapfrog steps: double steps with the four-level rotation against single steps with the three-level one"""
+    import torch
+    g = _grid(D, nx, ny, alignment)
+    A = _fields(D, g, SEED + 7)
+    B = _fields(D, g, SEED + 7)
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 30.0)
+    cur, old, n1, n2 = ([A[n] for n in NAMES[k:k + 3]] for k in (0, 3, 6, 9))
+    for _ in range(pairs):
+        D.psy.invoke_shallow_step_x2(prm, *cur, *old, *n1, *n2)
+        cur, old, n1, n2 = n2, n1, old, cur
+    c, o, n = ([B[q] for q in NAMES[k:k + 3]] for k in (0, 3, 6))
+    for _ in range(2 * pairs):
+        D.psy.invoke_shallow_step(prm, *c, *o, *n)
+        c, o, n = n, c, o
+    torch.cuda.synchronize()
+    for x, y in zip(cur + old, c + o):
+        assert torch.equal(x.data, y.data)
+
+
+def test_full_size_equals_two_single_steps(D):
+    """BASELINE configs[3]'s size: 8192^2, alignment 64, both new levels against the single-step kernel"""
+    import torch
+    g = _grid(D, 8192, 8192, 64)
+    F = _fields(D, g, SEED + 9)
+    chk = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(6)]
+    for x, n in zip(chk, NAMES[6:]):
+        D.copy_field(F[n], x)
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 90.0)
+    D.psy.invoke_shallow_step_x2(prm, *[F[n] for n in NAMES])
+    D.psy.invoke_shallow_step(prm, *[F[n] for n in NAMES[:6]], *chk[:3])
+    D.psy.invoke_shallow_step(prm, *chk[:3], *[F[n] for n in NAMES[:3]], *chk[3:])
+    torch.cuda.synchronize()
+    for x, n in zip(chk, NAMES[6:]):
+        assert torch.equal(x.data, F[n].data), n
