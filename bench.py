@@ -568,6 +568,7 @@ def shallow_water_smooth(D, torch, stream, g, F, prm, tile, steps, alpha=0.001):
     (u <- unew; uold keeps the filtered u) between steps."""
     names = ["u", "v", "p", "uold", "vold", "pold", "unew", "vnew", "pnew"]
     cells = tile * tile
+    it_box = F["p"].internal.box()
     with torch.cuda.stream(stream):
         for k, n in enumerate(names[:6]):
             D.psy.hash_init(F[n], SEED + k, stream=stream)
@@ -602,6 +603,60 @@ def shallow_water_smooth(D, torch, stream, g, F, prm, tile, steps, alpha=0.001):
             e1.record(stream)
         stream.synchronize()
         res[label] = e0.elapsed_time(e1) / steps
+    # round 4: TWO whole filtered time steps per launch (dlesm_shallow_step_smooth_x2_f64: level n+2 and the filtered level n+1
+    # from level n and the filtered level n-1; six arrays read + six written per two steps = 48 B/cell/step); checked against
+    # two one-launch filtered steps from the same state with every array carrying the same boundary ring, then >= 24 launches
+    x2 = None
+    try:
+        ex = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(3)]
+        A = [F[n] for n in names]
+        with torch.cuda.stream(stream):
+            for k, n in enumerate(names[:6]):
+                D.psy.hash_init(F[n], SEED + k, stream=stream)
+                F[n].data.add_(1.0 if n[0] == "p" else -0.5)
+            for k in range(3):                               # one ring for every level: u's, v's, p's
+                keep = A[3 + k].data[it_box[2] - 1:it_box[3], it_box[0] - 1:it_box[1]].clone()
+                D.copy_field(A[k], A[3 + k], stream=stream)
+                A[3 + k].data[it_box[2] - 1:it_box[3], it_box[0] - 1:it_box[1]] = keep
+                D.copy_field(A[k], A[6 + k], stream=stream)
+                D.copy_field(A[k], ex[k], stream=stream)
+            ref = [D.r2d_field(g, D.GO_T_POINTS) for _ in range(9)]
+            for k in range(9):
+                D.copy_field(A[k], ref[k], stream=stream)
+            D.psy.invoke_shallow_step_smooth_x2(prm, alpha, *A[:6], *A[6:], *ex, stream=stream)      # n+2 -> A[6:9], filtered n+1 -> ex
+            rc, ro, rn = ref[:3], ref[3:6], ref[6:]
+            for _ in range(2):
+                D.psy.invoke_shallow_step_smooth(prm, alpha, *rc, *ro, *rn, stream=stream)
+                rc, rn = rn, rc
+        stream.synchronize()
+        cut = lambda f: f.data[it_box[2] - 1:it_box[3], it_box[0] - 1:it_box[1]]      # noqa: E731
+        same2 = all(bool(torch.equal(cut(a), cut(b))) for a, b in zip(A[6:] + ex, rc + ro))
+        del ref, rc, ro, rn
+        torch.cuda.empty_cache()
+        launches = max(MIN_SECONDARY_LAUNCHES, steps // 2)
+        cur, old, n2, o2 = A[:3], A[3:6], A[6:], ex
+        with torch.cuda.stream(stream):
+            for k in range(launches + 4):
+                if k == 4:
+                    e0.record(stream)
+                D.psy.invoke_shallow_step_smooth_x2(prm, alpha, *cur, *old, *n2, *o2, stream=stream)
+                cur, old, n2, o2 = n2, o2, cur, old
+            e1.record(stream)
+        stream.synchronize()
+        ms2 = e0.elapsed_time(e1) / launches
+        g2 = 96 * cells / (ms2 * 1e-3) / 1e9
+        x2 = {"what": "two whole filtered time steps per launch: level n+2 and the filtered level n+1 from level n and the filtered level n-1",
+              "launches": launches, "time_steps": 2 * launches, "value": round(2 * cells / (ms2 * 1e-3) / 1e6, 1), "unit": "Mcells/s",
+              "ms_per_launch": round(ms2, 5), "ms_per_step": round(ms2 / 2, 5),
+              "roofline": {"bound": "hbm", "achieved": round(g2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g2 / HBM_PEAK_GBS, 4),
+                           "algorithmic_bytes_per_cell_per_launch": 96, "algorithmic_bytes_per_cell_per_step": 48,
+                           "kernel": "shallow_tile_x2<2,6,smooth> (two-row tiles, every load issued first, four vertically adjacent tiles per workgroup)"},
+              "bit_identical_to_two_one_launch_filtered_steps": bool(same2),
+              "speedup_per_step_vs_one_launch_filtered_step": round(2 * res["one_launch"] / ms2, 3),
+              "speedup_per_step_vs_step_plus_three_time_smooth": round(2 * res["step_plus_three_time_smooth"] / ms2, 3)}
+        del ex
+    except Exception as e:                                   # noqa: BLE001
+        x2 = {"error": f"{type(e).__name__}: {e}"}
     ms = res["one_launch"]
     gbs = 96 * cells / (ms * 1e-3) / 1e9
     # the ceiling of THIS stream count in the same process: six arrays read, six written, three of them in place (the old
@@ -613,7 +668,7 @@ def shallow_water_smooth(D, torch, stream, g, F, prm, tile, steps, alpha=0.001):
         cc_frac = round(gbs / cc["best_gbs"], 4)
     except Exception as e:      # noqa: BLE001  (a diagnostic must not cost the leg)
         cc, cc_frac = {"error": f"{type(e).__name__}: {e}"}, None
-    return {"copy_ceiling": cc, "frac_of_copy_ceiling": cc_frac,
+    return {"copy_ceiling": cc, "frac_of_copy_ceiling": cc_frac, "two_steps_per_launch": x2,
             "workload": f"one whole leapfrog step incl. the Asselin filter (time_smooth) of the old level, {tile}x{tile} fp64, "
                         "one launch per time step", "steps": steps,
             "value": round(cells / (ms * 1e-3) / 1e6, 1), "unit": "Mcells/s", "ms_per_step": round(ms, 5),

@@ -109,9 +109,14 @@ struct X2Arrays {
 // NTM bit 0: level n-1 loaded non-temporally; bit 1: both new levels stored non-temporally; bit 2: every row load of the tile is
 // issued before the first use (a scheduling barrier behind the load block: without it the compiler, short of registers,
 // interleaves loads and arithmetic and a wave goes through ten dependent memory round trips with five loads in flight)
-template <int R, int NTM>
-__global__ __launch_bounds__(512) void shallow_tile_x2(dlesm_sw_params q, int ld, int ny, int x0, int x1, int y0, int y1, int cb, int nxw,
-                                                       int stack, X2Arrays a)
+// SM: the Asselin filter of the GOcean leapfrog (time_smooth) after EACH of the two steps, as dlesm_shallow_step_smooth_f64
+// applies it after one: the old level the second stage uses is the filtered level n, and what is stored besides level n+2 is the
+// FILTERED level n+1 (into u1, v1, p1) -- the unfiltered one never leaves the registers.  The filter is cell-local, so it
+// costs no halo.  The ring of level n+1 is then taken from level n (u, v, p): a non-periodic model keeps the same fixed
+// boundary values at every time level, and no array holds an unfiltered level n+1 to read it from.
+template <int R, int NTM, bool SM = false>
+__global__ __launch_bounds__(256) void shallow_tile_x2(dlesm_sw_params q, int ld, int ny, int x0, int x1, int y0, int y1, int cb, int nxw,
+                                                       int stack, X2Arrays a, double alpha)
 {
     const int lane = threadIdx.x & 63;
     int xw, strip;
@@ -164,7 +169,9 @@ __global__ __launch_bounds__(512) void shallow_tile_x2(dlesm_sw_params q, int ld
         for (int k = 0; k < R + 2; k++) {
             const int jj = jb - 1 + k;
             const size_t o = (size_t)rowclamp(jj) * ld + col;
-            const W2 ru = xld<false>(a.u1 + o), rv = xld<false>(a.v1 + o), rp = xld<false>(a.p1 + o);
+            W2 ru, rv, rp;
+            if constexpr (SM) { ru = U[k + 1]; rv = V[k + 1]; rp = P[k + 1]; (void)o; }      // (level n's ring, already in registers)
+            else { ru = xld<false>(a.u1 + o); rv = xld<false>(a.v1 + o); rp = xld<false>(a.p1 + o); }
             const bool rin = jj >= y0 && jj <= y1;
             const bool i0 = rin && 2 * c >= x0 && 2 * c <= x1, i1 = rin && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
             U1[k] = XW(i0 ? U1[k].x : ru.x, i1 ? U1[k].y : ru.y);
@@ -175,8 +182,24 @@ __global__ __launch_bounds__(512) void shallow_tile_x2(dlesm_sw_params q, int ld
     // stage 2: level n+2 on rows jb .. jb+R-1 from level n+1 (rows jb-1 .. jb+R) and level n (rows jb .. jb+R-1) as the old one
     W2 U2[R], V2[R], P2[R], UC[R], VC[R], PC[R];
 #pragma unroll
-    for (int k = 0; k < R; k++) { UC[k] = U[k + 2]; VC[k] = V[k + 2]; PC[k] = P[k + 2]; }
+    for (int k = 0; k < R; k++) {
+        UC[k] = U[k + 2]; VC[k] = V[k + 2]; PC[k] = P[k + 2];
+        if constexpr (SM) {   // time_smooth after step 1: field_old = field + alpha*(field_new - 2*field + field_old), the tile's own cells
+            UC[k] = XW(U[k + 2].x + alpha * (U1[k + 1].x - 2.0 * U[k + 2].x + UO[k + 1].x), U[k + 2].y + alpha * (U1[k + 1].y - 2.0 * U[k + 2].y + UO[k + 1].y));
+            VC[k] = XW(V[k + 2].x + alpha * (V1[k + 1].x - 2.0 * V[k + 2].x + VO[k + 1].x), V[k + 2].y + alpha * (V1[k + 1].y - 2.0 * V[k + 2].y + VO[k + 1].y));
+            PC[k] = XW(P[k + 2].x + alpha * (P1[k + 1].x - 2.0 * P[k + 2].x + PO[k + 1].x), P[k + 2].y + alpha * (P1[k + 1].y - 2.0 * P[k + 2].y + PO[k + 1].y));
+        }
+    }
     sw_step_rows<R>(q, U1, V1, P1, UC, VC, PC, U2, V2, P2);
+    if constexpr (SM) {       // time_smooth after step 2: what is stored as the (filtered) level n+1
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const W2 fu = XW(U1[k + 1].x + alpha * (U2[k].x - 2.0 * U1[k + 1].x + UC[k].x), U1[k + 1].y + alpha * (U2[k].y - 2.0 * U1[k + 1].y + UC[k].y));
+            const W2 fv = XW(V1[k + 1].x + alpha * (V2[k].x - 2.0 * V1[k + 1].x + VC[k].x), V1[k + 1].y + alpha * (V2[k].y - 2.0 * V1[k + 1].y + VC[k].y));
+            const W2 fp = XW(P1[k + 1].x + alpha * (P2[k].x - 2.0 * P1[k + 1].x + PC[k].x), P1[k + 1].y + alpha * (P2[k].y - 2.0 * P1[k + 1].y + PC[k].y));
+            U1[k + 1] = fu; V1[k + 1] = fv; P1[k + 1] = fp;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < R; k++) {
         const int jj = jb + k;
@@ -199,6 +222,65 @@ __global__ __launch_bounds__(512) void shallow_tile_x2(dlesm_sw_params q, int ld
 
 } // namespace
 
+} // namespace dlesm
+
+namespace dlesm {
+namespace {
+// the wave-tile launch of both entries below; alpha != nullptr: the filtered form
+static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart, int ystop, X2Arrays a, const double *alpha,
+                      hipStream_t s)
+{
+    const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
+    const int cb = (x0 / 2) & ~7;                        // tiles anchored on a 128-byte line of the row, as shallow_tile
+    // The shape measured best at 8192^2 (scripts/shallow_x2_probe.py, profiles/r04_shallow_x2.txt): four-row tiles; the four
+    // waves of a workgroup are four VERTICALLY adjacent tiles, so that of the (R+4)/R = 2 x re-read of level n only the two
+    // rows above and below a 16-row band come from another workgroup (the same tiles dealt row-major to the workgroups, as
+    // every single-step sweep does, leave half of the re-reads to other XCDs: 1.53 against 1.22 ms); new levels stored
+    // non-temporally, level n-1 loaded with the default policy (its halo rows ARE re-read; non-temporal: 1.47 ms).
+    // sw_x2_rows / _nt / _stack / _pad select the comparison forms (lab build).
+    // The filtered form keeps level n-1 live through the first stage (the filter needs it again) and does not fit four-row
+    // tiles into 256 VGPRs (spills to AGPRs at one wave per SIMD: 2.34 ms); two-row tiles with every load issued first:
+    // 1.33 ms per two filtered steps against 2 x 1.19 ms for two one-launch filtered steps (same box).
+    int R = alpha ? 2 : 4, nt = alpha ? 6 : 2, stack = 4, pad = 0;
+    if (kLab) {
+        R = tuning("sw_x2_rows", R);
+        if (R != 2 && R != 6) R = 4;
+        nt = tuning("sw_x2_nt", nt) & 7;
+        stack = tuning("sw_x2_stack", 4);
+        pad = tuning("sw_x2_pad", 0);
+    }
+    int nxw = (x1 / 2 - cb + 62) / 62, tpb = 4;
+    if (stack) {
+        nxw += pad;
+        tpb = stack == 2 ? 2 : 4;
+    } else {
+        choose_block_shape(&nxw, &tpb);
+        if (tpb > 4) tpb = 4;
+    }
+    const int strips = (y1 - y0 + R) / R;
+    const unsigned grid = stack ? (unsigned)((long)nxw * ((strips + tpb - 1) / tpb)) : (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
+    const double al = alpha ? *alpha : 0.0;
+#define DLESM_X2(RR, NN)                                                                                                                                  \
+    do {                                                                                                                                                  \
+        if (alpha) hipLaunchKernelGGL((shallow_tile_x2<RR, NN, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al); \
+        else hipLaunchKernelGGL((shallow_tile_x2<RR, NN, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);    \
+    } while (0)
+#ifdef DLESM_LAB
+#define DLESM_X2R(RR)                                                                                                  \
+    switch (nt) {                                                                                                      \
+    case 0: DLESM_X2(RR, 0); break; case 3: DLESM_X2(RR, 3); break; case 4: DLESM_X2(RR, 4); break;                   \
+    case 6: DLESM_X2(RR, 6); break; case 7: DLESM_X2(RR, 7); break; default: DLESM_X2(RR, 2); break;                  \
+    }
+    if (R == 2) { DLESM_X2R(2) } else if (R == 6) { DLESM_X2R(6) } else { DLESM_X2R(4) }
+#undef DLESM_X2R
+#else
+    (void)nt;
+    if (alpha) hipLaunchKernelGGL((shallow_tile_x2<2, 6, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
+    else hipLaunchKernelGGL((shallow_tile_x2<4, 2, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
+#endif
+#undef DLESM_X2
+}
+} // namespace
 } // namespace dlesm
 
 using namespace dlesm;
@@ -231,47 +313,58 @@ extern "C" int dlesm_shallow_step_x2_f64(const dlesm_sw_params *q, int ld, int n
         if (int rc = dlesm_shallow_step_f64(q, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, unew, vnew, pnew, stream)) return rc;
         return dlesm_shallow_step_f64(q, ld, ny, xstart, xstop, ystart, ystop, unew, vnew, pnew, u, v, p, unew2, vnew2, pnew2, stream);
     }
-    const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
-    const int cb = (x0 / 2) & ~7;                        // tiles anchored on a 128-byte line of the row, as shallow_tile
-    // The shape measured best at 8192^2 (scripts/shallow_x2_probe.py, profiles/r04_shallow_x2.txt): four-row tiles; the four
-    // waves of a workgroup are four VERTICALLY adjacent tiles, so that of the (R+4)/R = 2 x re-read of level n only the two
-    // rows above and below a 16-row band come from another workgroup (the same tiles dealt row-major to the workgroups, as
-    // every single-step sweep does, leave half of the re-reads to other XCDs: 1.53 against 1.22 ms); new levels stored
-    // non-temporally, level n-1 loaded with the default policy (its halo rows ARE re-read; non-temporal: 1.47 ms).
-    // sw_x2_rows / _nt / _stack / _pad select the comparison forms (lab build).
-    int R = 4, nt = 2, stack = 4, pad = 0;
-    if (kLab) {
-        R = tuning("sw_x2_rows", 4);
-        if (R != 2 && R != 6) R = 4;
-        nt = tuning("sw_x2_nt", 2) & 7;
-        stack = tuning("sw_x2_stack", 4);
-        pad = tuning("sw_x2_pad", 0);
-    }
-    int nxw = (x1 / 2 - cb + 62) / 62, tpb = 4;
-    if (stack) {
-        nxw += pad;
-        tpb = stack == 2 ? 2 : stack == 8 ? 8 : 4;
-    } else {
-        choose_block_shape(&nxw, &tpb);
-        if (tpb > 8) tpb = 8;
-    }
-    const int strips = (y1 - y0 + R) / R;
-    const unsigned grid = stack ? (unsigned)((long)nxw * ((strips + tpb - 1) / tpb)) : (unsigned)(((long)nxw * strips + tpb - 1) / tpb);
-    X2Arrays a{u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2};
-#define DLESM_X2(RR, NN) hipLaunchKernelGGL((shallow_tile_x2<RR, NN>), dim3(grid), dim3(64 * tpb), 0, s, *q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a)
-#ifdef DLESM_LAB
-#define DLESM_X2R(RR)                                                                                                  \
-    switch (nt) {                                                                                                      \
-    case 0: DLESM_X2(RR, 0); break; case 3: DLESM_X2(RR, 3); break; case 4: DLESM_X2(RR, 4); break;                   \
-    case 6: DLESM_X2(RR, 6); break; case 7: DLESM_X2(RR, 7); break; default: DLESM_X2(RR, 2); break;                  \
-    }
-    if (R == 2) { DLESM_X2R(2) } else if (R == 6) { DLESM_X2R(6) } else { DLESM_X2R(4) }
-#undef DLESM_X2R
-#else
-    (void)nt;
-    DLESM_X2(4, 2);
-#endif
-#undef DLESM_X2
+    launch_x2(*q, ld, ny, xstart, xstop, ystart, ystop, X2Arrays{u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2}, nullptr, s);
     DLESM_HIP_TRY(hipGetLastError());
     return DLESM_OK;
+}
+
+// Two FILTERED leapfrog steps, one launch: two whole time steps of the GOcean loop (update + time_smooth of the old level, twice).
+// With levels n (u, v, p) and n-1 (uold, vold, pold: the filtered one, as the loop keeps it) it leaves level n+2 in
+// (unew2, vnew2, pnew2) and the FILTERED level n+1 in (uold2, vold2, pold2) -- what two calls of dlesm_shallow_step_smooth_f64
+// with the usual rotation leave as the new current and old levels -- at 6 arrays read + 6 written per TWO steps: 48 B/cell/step
+// against 96 for the one-launch filtered step and 168 for step + three filter launches.  The inputs are not modified; the ring of
+// the unfiltered level n+1 the second stage reads outside the box is taken from u, v, p (a fixed boundary ring is the same at
+// every time level).  Time loop: ping-pong (cur, old) <-> (unew2.., uold2..).  Arrays that miss the wave-tile conditions take the
+// definition through three stream-ordered scratch arrays.
+extern "C" int dlesm_shallow_step_smooth_x2_f64(const dlesm_sw_params *q, double alpha, int ld, int ny, int xstart, int xstop, int ystart,
+                                                int ystop, const double *u, const double *v, const double *p, const double *uold,
+                                                const double *vold, const double *pold, double *unew2, double *vnew2, double *pnew2,
+                                                double *uold2, double *vold2, double *pold2, void *stream)
+{
+    clear_error();
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(q && u && v && p && uold && vold && pold && unew2 && vnew2 && pnew2 && uold2 && vold2 && pold2, "null pointer");
+    if (xstop < xstart || ystop < ystart) return DLESM_OK;
+    if (int rc = check_box("dlesm_shallow_step_smooth_x2_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
+    const double *all[12] = {u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2};
+    for (int i = 0; i < 12; i++)
+        for (int j = i + 1; j < 12; j++)
+            DLESM_REQUIRE(all[i] != all[j], "dlesm_shallow_step_smooth_x2_f64: the twelve arrays must be distinct (arguments %d and %d are not)", i, j);
+    bool aligned = ld % 2 == 0 || (xstop - 1) + 1 <= 2 * (ld / 2) - 1;
+    for (const double *f : all) aligned = aligned && ((uintptr_t)f % 16 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (aligned && tuning("sw_kernel", 0) == 0 && tuning("sw_x2_fused", 1)) {
+        // (X2Arrays: u1.. = where the stored level n+1 goes -- here the filtered one; u2.. = level n+2)
+        launch_x2(*q, ld, ny, xstart, xstop, ystart, ystop, X2Arrays{u, v, p, uold, vold, pold, uold2, vold2, pold2, unew2, vnew2, pnew2}, &alpha, s);
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
+    // the definition: old2 <- old; T <- ring of u (the level-n+1 ring); step_smooth(u, old2 -> filtered n, T = n+1);
+    // step_smooth(T, old2 -> filtered n+1, new2 = n+2)
+    const size_t bytes = (size_t)ld * ny * sizeof(double);
+    double *t[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 3; k++)
+        if (hipMallocAsync((void **)&t[k], bytes, s) != hipSuccess) {
+            for (int q2 = 0; q2 < k; q2++) (void)hipFreeAsync(t[q2], s);
+            return fail(DLESM_EHIP, "dlesm_shallow_step_smooth_x2_f64: no scratch memory for the intermediate time level");
+        }
+    const double *src[6] = {uold, vold, pold, u, v, p};
+    double *dst[6] = {uold2, vold2, pold2, t[0], t[1], t[2]};
+    int rc = DLESM_OK;
+    for (int k = 0; k < 6 && !rc; k++)
+        if (hipMemcpyAsync(dst[k], src[k], bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(DLESM_EHIP, "dlesm_shallow_step_smooth_x2_f64: copy failed");
+    if (!rc) rc = dlesm_shallow_step_smooth_f64(q, alpha, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold2, vold2, pold2, t[0], t[1], t[2], stream);
+    if (!rc) rc = dlesm_shallow_step_smooth_f64(q, alpha, ld, ny, xstart, xstop, ystart, ystop, t[0], t[1], t[2], uold2, vold2, pold2, unew2, vnew2, pnew2, stream);
+    for (int k = 0; k < 3; k++) (void)hipFreeAsync(t[k], s);
+    return rc;
 }

@@ -223,6 +223,15 @@ module dlesm_hip_mod
        type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2, stream
        integer(c_int) :: rc
      end function
+     function dlesm_shallow_step_smooth_x2_f64(params, alpha, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, &
+          unew2, vnew2, pnew2, uold2, vold2, pold2, stream) bind(C, name="dlesm_shallow_step_smooth_x2_f64") result(rc)
+       import :: c_int, c_ptr, c_sw_params, c_double
+       type(c_sw_params), intent(in) :: params
+       real(c_double), value :: alpha
+       integer(c_int), value :: ld, ny, xstart, xstop, ystart, ystop
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2, stream
+       integer(c_int) :: rc
+     end function
      function dlesm_shallow_step_smooth_f64(params, alpha, ld, ny, xstart, xstop, ystart, ystop, u, v, p, &
           uold, vold, pold, unew, vnew, pnew, stream) bind(C, name="dlesm_shallow_step_smooth_f64") result(rc)
        import :: c_int, c_ptr, c_sw_params, c_double

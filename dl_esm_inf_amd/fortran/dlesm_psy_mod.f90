@@ -57,7 +57,7 @@ module dlesm_psy_mod
   public :: invoke_compute_unew, invoke_compute_vnew, invoke_compute_pnew, invoke_time_smooth
   public :: invoke_shallow_step_sw_periodic, plan_shallow_step_sw, invoke_periodic_halos_multi
   public :: invoke_shallow_step_smooth, invoke_shallow_step_sw_smooth_periodic, invoke_shallow_step_smooth_dm
-  public :: invoke_shallow_step_x2
+  public :: invoke_shallow_step_x2, invoke_shallow_step_smooth_x2
 
 contains
 
@@ -405,6 +405,29 @@ contains
                                    field_device_data(unew2), field_device_data(vnew2), field_device_data(pnew2), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_shallow_step_x2: ' // dlesm_error_text())
   end subroutine invoke_shallow_step_x2
+
+  !> TWO whole time steps of the GOcean leapfrog (update + Asselin filter of the old level, twice) in one launch (NE offset):
+  !! level n+2 into unew2, vnew2, pnew2 and the filtered level n+1 into uold2, vold2, pold2; u .. pold are not modified.
+  !! == two invoke_shallow_step_smooth calls with the usual rotation, bit for bit, at 48 instead of 96 B/cell/step.
+  !! Time loop: ping-pong (u, v, p, uold, vold, pold) <-> (unew2, vnew2, pnew2, uold2, vold2, pold2).
+  subroutine invoke_shallow_step_smooth_x2(prm, alpha, u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2)
+    type(c_sw_params), intent(in) :: prm
+    real(go_wp), intent(in) :: alpha
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew2);  call need_device(vnew2);  call need_device(pnew2)
+    call need_device(uold2);  call need_device(vold2);  call need_device(pold2)
+    rc = dlesm_shallow_step_smooth_x2_f64(prm, alpha, int(p%grid%nx, c_int), int(p%grid%ny, c_int), &
+                                          int(p%internal%xstart, c_int), int(p%internal%xstop, c_int), &
+                                          int(p%internal%ystart, c_int), int(p%internal%ystop, c_int), &
+                                          field_device_data(u), field_device_data(v), field_device_data(p), &
+                                          field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                          field_device_data(unew2), field_device_data(vnew2), field_device_data(pnew2), &
+                                          field_device_data(uold2), field_device_data(vold2), field_device_data(pold2), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_smooth_x2: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_smooth_x2
 
   !> The same for the SW-offset periodic model: update, filter and the periodic images of the new and of the filtered old
   !! level in ONE launch -- a whole time step of the GOcean `shallow` benchmark.

@@ -160,6 +160,15 @@ def invoke_shallow_step_x2(params, u, v, p, uold, vold, pold, unew, vnew, pnew, 
                                                 _stream_ptr(stream)))
 
 
+def invoke_shallow_step_smooth_x2(params, alpha, u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2, stream=None):
+    """TWO filtered leapfrog steps (update + time_smooth, twice) in one launch (dlesm_shallow_step_smooth_x2_f64): level n+2 into
+    unew2.., the filtered level n+1 into uold2..; inputs untouched.  Time loop: ping-pong (cur, old) <-> (unew2.., uold2..)."""
+    g, it = p.grid, p.internal
+    check(_cabi.lib().dlesm_shallow_step_smooth_x2_f64(
+        C.byref(params), alpha, g.nx, g.ny, it.xstart, it.xstop, it.ystart, it.ystop,
+        *[f.device_ptr for f in (u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2)], _stream_ptr(stream)))
+
+
 def invoke_shallow_step_sw(params, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
     """the SW-offset form (the GOcean `shallow` staggering); periodic models follow it with
     apply_periodic_halos on the three new fields"""

@@ -342,6 +342,16 @@ int dlesm_shallow_step_x2_f64(const dlesm_sw_params *q, int ld, int ny, int xsta
                               const double *u, const double *v, const double *p, const double *uold, const double *vold,
                               const double *pold, double *unew, double *vnew, double *pnew, double *unew2, double *vnew2,
                               double *pnew2, void *stream);
+/* ... and with the Asselin filter after EACH step: two whole time steps of the GOcean loop (update + time_smooth of the old level,
+ * twice) in one launch.  In: level n (u, v, p) and the filtered level n-1 (uold, vold, pold), both untouched.  Out: level n+2 in
+ * unew2 / vnew2 / pnew2 and the FILTERED level n+1 in uold2 / vold2 / pold2 -- the new current and old levels two calls of
+ * dlesm_shallow_step_smooth_f64 with the usual rotation leave, bit for bit, provided the boundary ring is the same at every time
+ * level (the ring of the unfiltered level n+1, which no array holds, is taken from u, v, p).  48 B/cell/step against 96 for the
+ * one-launch filtered step.  Time loop: ping-pong (u.., uold..) <-> (unew2.., uold2..). */
+int dlesm_shallow_step_smooth_x2_f64(const dlesm_sw_params *q, double alpha, int ld, int ny, int xstart, int xstop, int ystart,
+                                     int ystop, const double *u, const double *v, const double *p, const double *uold,
+                                     const double *vold, const double *pold, double *unew2, double *vnew2, double *pnew2,
+                                     double *uold2, double *vold2, double *pold2, void *stream);
 
 /* One WHOLE time step of the GOcean leapfrog in one launch: the u/v/h update AND the Asselin filter of the old level
  * (the benchmark's time_smooth kernel), from values the lanes already hold --

@@ -48,6 +48,8 @@ def test_bench_line_and_secondary_legs():
     ts = sw["with_time_smooth"]
     assert "error" not in ts and ts["bit_identical_to_step_plus_time_smooth"] is True and ts["roofline"]["algorithmic_bytes_per_cell"] == 96, ts
     assert sw["copy_ceiling"]["best_gbs"] > 0 and 0 < sw["roofline"]["frac_of_copy_ceiling"] < 2, sw
+    tx2 = ts["two_steps_per_launch"]         # ... and two whole FILTERED time steps per launch
+    assert "error" not in tx2 and tx2["bit_identical_to_two_one_launch_filtered_steps"] is True and tx2["value"] > 0, tx2
     x2 = sw["two_steps_per_launch"]          # round 4: two leapfrog steps per launch, 48 B/cell/step
     assert "error" not in x2 and x2["bit_identical_to_two_single_steps"] is True and x2["value"] > 0, x2
     assert x2["roofline"]["algorithmic_bytes_per_cell_per_step"] == 48 and x2["copy_ceiling"]["best_gbs"] > 0, x2

@@ -174,3 +174,39 @@ def test_full_size_equals_two_single_steps(D):
     torch.cuda.synchronize()
     for x, n in zip(chk, NAMES[6:]):
         assert torch.equal(x.data, F[n].data), n
+
+
+# ---- with the Asselin filter after each step: two whole time steps of the GOcean loop per launch --------------------------------
+@pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (64, 48, 8), (127, 9, None), (257, 129, None), (300, 70, 64), (1000, 37, 64), (2100, 33, 64)])
+@pytest.mark.parametrize("fallback", [False, True])
+def test_two_filtered_steps_per_launch(D, nx, ny, alignment, fallback):
+    """dlesm_shallow_step_smooth_x2_f64 against the one-launch filtered step applied twice with the loop's rotation (itself checked
+    against the oracle's loop nests in tests/test_gpu_shallow_kernels.py), and a longer ping-pong loop against that loop"""
+    import torch
+    L = D._cabi.lib()
+    g = _grid(D, nx, ny, alignment)
+    alpha = 0.001
+    prm = D.psy.shallow_params(1.0e5, 0.9e5, 40.0)
+    A, B = _fields(D, g, SEED + 21), _fields(D, g, SEED + 21)
+    a_cur, a_old, a_n2, a_o2 = ([A[n] for n in NAMES[k:k + 3]] for k in (0, 3, 6, 9))
+    for src, dst in zip(a_cur, a_o2):                 # every array of the run carries the same boundary ring
+        D.copy_field(src, dst)
+    b_cur, b_old, b_new = ([B[n] for n in NAMES[k:k + 3]] for k in (0, 3, 6))
+    L.dlesm_set_tuning(b"sw_x2_fused", 0 if fallback else 1)
+    try:
+        for pair in range(3):
+            keep = [f.data.clone() for f in a_cur + a_old]
+            D.psy.invoke_shallow_step_smooth_x2(prm, alpha, *a_cur, *a_old, *a_n2, *a_o2)
+            torch.cuda.synchronize()
+            assert all(torch.equal(k, f.data) for k, f in zip(keep, a_cur + a_old)), "inputs modified"
+            a_cur, a_old, a_n2, a_o2 = a_n2, a_o2, a_cur, a_old
+            for _ in range(2):
+                D.psy.invoke_shallow_step_smooth(prm, alpha, *b_cur, *b_old, *b_new)
+                b_cur, b_old, b_new = b_new, b_old, b_cur          # uold already holds the filtered former current
+            torch.cuda.synchronize()
+            it = A["p"].internal
+            cut = lambda f: f.data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop]      # noqa: E731
+            for x, y in zip(a_cur + a_old, b_cur + b_old):
+                assert torch.equal(cut(x), cut(y)), (pair, int((cut(x) != cut(y)).sum()))
+    finally:
+        L.dlesm_set_tuning(b"sw_x2_fused", 1)
