@@ -234,8 +234,9 @@ static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int 
     const int cb = (x0 / 2) & ~7;                        // tiles anchored on a 128-byte line of the row, as shallow_tile
     // The shape measured best at 8192^2 (scripts/shallow_x2_probe.py, profiles/r04_shallow_x2.txt): four-row tiles; the four
     // waves of a workgroup are four VERTICALLY adjacent tiles, so that of the (R+4)/R = 2 x re-read of level n only the two
-    // rows above and below a 16-row band come from another workgroup (the same tiles dealt row-major to the workgroups, as
-    // every single-step sweep does, leave half of the re-reads to other XCDs: 1.53 against 1.22 ms); new levels stored
+    // rows above and below a 16-row band come from another workgroup -- there is no tile-to-XCD mapping to get wrong (the
+    // same tiles dealt row-major under the Jacobi sweep's shape rule: 1.53 against 1.22 ms at 8192^2, within 1-7 % at
+    // 2048^2 .. 6144^2 and 12288^2, profiles/r04_shallow_x2.txt); new levels stored
     // non-temporally, level n-1 loaded with the default policy (its halo rows ARE re-read; non-temporal: 1.47 ms).
     // sw_x2_rows / _nt / _stack / _pad select the comparison forms (lab build).
     // The filtered form keeps level n-1 live through the first stage (the filter needs it again) and does not fit four-row
