@@ -252,11 +252,17 @@ extern "C" int dlesm_field_create(int ld, int ny, dlesm_field **out)
     const size_t bytes = (size_t)ld * (size_t)ny * sizeof(double);
     double *p = nullptr;
     DLESM_HIP_TRY(hipMalloc((void **)&p, bytes));
-    // "explicitly set all elements to 0" (field_mod.f90:357-376)
-    hipError_t e = hipMemset(p, 0, bytes);
+    // "explicitly set all elements to 0" (field_mod.f90:357-376) -- and the fill has LANDED when this returns.  hipMemset of
+    // device memory is enqueued on the null stream and returns at once: behind a kernel that is still running there it ran
+    // AFTER the (blocking, transfer-stream) upload of field_to_device and zeroed what had just been uploaded (found in round 4
+    // by the Fortran two-step test, whose reference fields go to the device while the kernel under test is running; the
+    // Python constructor had the same fault in round 3).  So: on the transfer stream -- the stream every later upload of this
+    // field uses -- and waited for, which does not wait for the caller's kernels.
+    hipError_t e = hipMemsetAsync(p, 0, bytes, transfer_stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(transfer_stream());
     if (e != hipSuccess) {
         (void)hipFree(p);
-        return fail(DLESM_EHIP, "hipMemset failed: %s", hipGetErrorString(e));
+        return fail(DLESM_EHIP, "zero-fill of a new field failed: %s", hipGetErrorString(e));
     }
     dlesm_field *f = new dlesm_field{DLESM_FIELD_MAGIC, p, ld, ny, true};
     *out = f;

@@ -107,6 +107,7 @@ program ftest_device
 
   ! ---- (3) one shallow-water step through the PSy layer ------------------------
   call shallow_step(model_grid)
+  call shallow_two_steps(model_grid)
   call free_field(a);  call free_field(b);  call free_field(test_field)
   call gocean_finalise()
 
@@ -147,6 +148,90 @@ contains
        call free_field(f(k))
     end do
   end subroutine shallow_step
+
+  !> invoke_shallow_step_x2 / invoke_shallow_step_smooth_x2 (two leapfrog steps per launch) against two single-step calls through
+  !! the same layer, every internal cell of both levels that come out: prints "G: x2 <cells that differ: plain> <filtered>"
+  subroutine shallow_two_steps(g)
+    type(grid_type), intent(in), target :: g
+    type(r2d_field), target :: f(12), r(9)
+    type(c_sw_params) :: prm
+    real(go_wp), parameter :: alpha = 0.001_go_wp
+    integer :: k, bad, badf, ptype(3)
+    ptype = (/ GO_U_POINTS, GO_V_POINTS, GO_T_POINTS /)
+    prm = shallow_params(1.0e5_go_wp, 1.0e5_go_wp, 40.0_go_wp)
+    do k = 1, 12
+       f(k) = r2d_field(g, ptype(mod(k - 1, 3) + 1))
+       if (k <= 9) r(k) = r2d_field(g, ptype(mod(k - 1, 3) + 1))
+    end do
+    ! plain: f(1:3) level n, f(4:6) level n-1 -> f(7:9) level n+1, f(10:12) level n+2
+    call make_levels()
+    call invoke_shallow_step_x2(prm, f(1), f(2), f(3), f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11), f(12))
+    call invoke_shallow_step(prm, r(1), r(2), r(3), r(4), r(5), r(6), r(7), r(8), r(9))          ! r(7:9) = n+1
+    call invoke_shallow_step(prm, r(7), r(8), r(9), r(1), r(2), r(3), r(4), r(5), r(6))          ! r(4:6) = n+2
+    bad = 0
+    do k = 1, 3
+       bad = bad + differ(f(6 + k), r(6 + k)) + differ(f(9 + k), r(3 + k))
+    end do
+    ! filtered: -> f(7:9) level n+2, f(10:12) the filtered level n+1; reference: two one-launch filtered steps, the loop's rotation
+    call make_levels()
+    call invoke_shallow_step_smooth_x2(prm, alpha, f(1), f(2), f(3), f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11), f(12))
+    call invoke_shallow_step_smooth(prm, alpha, r(1), r(2), r(3), r(4), r(5), r(6), r(7), r(8), r(9))      ! r(7:9) = n+1, r(4:6) = filtered n
+    call invoke_shallow_step_smooth(prm, alpha, r(7), r(8), r(9), r(4), r(5), r(6), r(1), r(2), r(3))      ! r(1:3) = n+2, r(4:6) = filtered n+1
+    badf = 0
+    do k = 1, 3
+       badf = badf + differ(f(6 + k), r(k)) + differ(f(9 + k), r(3 + k))
+    end do
+    write(*, '("G: x2 ",I0,1x,I0)') bad, badf
+    do k = 1, 12
+       call free_field(f(k))
+       if (k <= 9) call free_field(r(k))
+    end do
+  contains
+    !> levels n and n-1 from the counter hash in sane ranges; ONE boundary ring for every level (that of u, v, p)
+    subroutine make_levels()
+      integer :: q
+      real(go_wp), pointer :: d(:,:), c(:,:)
+      do q = 1, 6
+         call invoke_hash_init(f(q), int(30 + q, c_int64_t))
+         d => f(q)%get_data()
+         d = 0.1_go_wp * d
+         if (mod(q, 3) == 0) then
+            d = d + 1.0_go_wp
+         else
+            d = d - 0.05_go_wp
+         end if
+      end do
+      do q = 4, 6
+         d => f(q)%data
+         c => f(q - 3)%data
+         associate (it => f(q)%internal)
+           d(:it%xstart - 1, :) = c(:it%xstart - 1, :);  d(it%xstop + 1:, :) = c(it%xstop + 1:, :)
+           d(:, :it%ystart - 1) = c(:, :it%ystart - 1);  d(:, it%ystop + 1:) = c(:, it%ystop + 1:)
+         end associate
+      end do
+      do q = 7, 12
+         d => f(q)%get_data()
+         d = f(mod(q - 1, 3) + 1)%data
+      end do
+      do q = 1, 12
+         call f(q)%write_to_device()
+      end do
+      do q = 1, 9
+         d => r(q)%get_data()
+         d = f(q)%data
+         call r(q)%write_to_device()
+      end do
+    end subroutine make_levels
+    integer function differ(a1, b1)
+      type(r2d_field), intent(inout), target :: a1, b1
+      real(go_wp), pointer :: da(:,:), db(:,:)
+      da => a1%get_data()
+      db => b1%get_data()
+      associate (it => a1%internal)
+        differ = count(da(it%xstart:it%xstop, it%ystart:it%ystop) /= db(it%xstart:it%xstop, it%ystart:it%ystop))
+      end associate
+    end function differ
+  end subroutine shallow_two_steps
 
   !> a grid built WITH a T mask (-1/0/1 pattern, as ftest_dump's tmask mode): nsteps masked Jacobi
   !! steps through the PSy layer, which hands the kernel grid%tmask_device

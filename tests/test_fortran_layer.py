@@ -254,6 +254,8 @@ def test_fortran_device_io_and_jacobi_on_gpu(exe):
     cs9 = O.lib().orc_checksum(b9, ld, 2, nx + 1, 2, ny + 1)
     row = [float(x) for x in g["s9"][0]]
     assert abs(row[0] - cs9) <= 1e-12 * cs9 and row[1:] == [b9[1, 1], b9[ny, nx]]
+    # (3b) two leapfrog steps per launch through the Fortran wrappers == two single-step calls (plain and filtered forms)
+    assert ints(g["x2"][0]) == [0, 0]
     # (3) one fused shallow-water step launched from Fortran == oracle
     import ctypes as C
     H = []
