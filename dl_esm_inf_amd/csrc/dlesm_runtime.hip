@@ -345,6 +345,14 @@ extern "C" void dlesm_read_from_device(void *from, void *to, int startx, int sta
 extern "C" void dlesm_write_to_device(void *from, void *to, int startx, int starty, int nx, int ny,
                                       bool blocking)
 {
+    // The upload runs on the library's transfer stream, which is ordered against nothing the caller has launched: a kernel
+    // that still reads (or writes) this field on one of the caller's streams must have finished before the host copy
+    // replaces it -- the reference's device is synchronous (tests/device_computation/test_device_io.f90), so a host program
+    // written against it expects exactly that.  Uploads are initialisation / set_data traffic, never inside a time step.
+    if (hipDeviceSynchronize() != hipSuccess) {
+        fail(DLESM_EHIP, "hipDeviceSynchronize failed");
+        die("dlesm_write_to_device");
+    }
     if (copy_patch((const dlesm_field *)to, (double *)from, startx, starty, nx, ny, true, blocking))
         die("dlesm_write_to_device");
 }
