@@ -187,6 +187,8 @@ PROTOTYPES = {
     "dlesm_jacobi5_multi_step_dm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dlesm_shallow_step_x2_f64": (_i, [C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 12 + [_vp]),
     "dlesm_shallow_step_smooth_x2_f64": (_i, [C.POINTER(SwParams), _d, _i, _i, _i, _i, _i, _i] + [_vp] * 12 + [_vp]),
+    "dlesm_shallow_step_sw_x2_periodic_f64": (_i, [C.POINTER(SwParams), _i, _i, C.POINTER(Region), _i, _i] + [_vp] * 12 + [_vp]),
+    "dlesm_shallow_step_sw_smooth_x2_periodic_f64": (_i, [C.POINTER(SwParams), _d, _i, _i, C.POINTER(Region), _i, _i] + [_vp] * 12 + [_vp]),
     "dlesm_shallow_step_dm": (_i, [_vp, C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_shallow_step_dm_pipelined": (_i, [_vp, C.POINTER(SwParams), _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),
     "dlesm_shallow_step_smooth_dm": (_i, [_vp, C.POINTER(SwParams), _d, _i, _i, _i, _i, _i, _i] + [_vp] * 9 + [_vp]),

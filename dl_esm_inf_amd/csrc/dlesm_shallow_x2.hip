@@ -99,6 +99,57 @@ __device__ __forceinline__ void sw_step_rows(const dlesm_sw_params &q, const W2 
     }
 }
 
+// The same for the SW-offset staggering (shallow_tile_sw's expression trees, operand for operand): cu, cv, z look
+// west / south, h looks east / north.
+template <int NR>
+__device__ __forceinline__ void sw_step_rows_sw(const dlesm_sw_params &q, const W2 (&U)[NR + 2], const W2 (&V)[NR + 2], const W2 (&P)[NR + 2],
+                                                const W2 (&UO)[NR], const W2 (&VO)[NR], const W2 (&PO)[NR], W2 (&UN)[NR], W2 (&VN)[NR],
+                                                W2 (&PN)[NR])
+{
+    W2 Pw[NR + 2], Vw[NR + 2], Ue[NR + 1];
+#pragma unroll
+    for (int k = 0; k < NR + 2; k++) Pw[k] = west(P[k]);
+#pragma unroll
+    for (int k = 1; k < NR + 2; k++) Vw[k] = west(V[k]);
+#pragma unroll
+    for (int k = 0; k < NR + 1; k++) Ue[k] = east(U[k]);
+    W2 CU[NR + 1], H[NR + 1], CV[NR + 2], Z[NR + 2];
+#pragma unroll
+    for (int k = 0; k < NR + 1; k++) {
+        CU[k] = XW(0.5 * (P[k].x + Pw[k].x) * U[k].x, 0.5 * (P[k].y + Pw[k].y) * U[k].y);
+        H[k] = XW(P[k].x + 0.25 * (Ue[k].x * Ue[k].x + U[k].x * U[k].x + V[k + 1].x * V[k + 1].x + V[k].x * V[k].x),
+                  P[k].y + 0.25 * (Ue[k].y * Ue[k].y + U[k].y * U[k].y + V[k + 1].y * V[k + 1].y + V[k].y * V[k].y));
+    }
+#pragma unroll
+    for (int k = 1; k < NR + 2; k++) {
+        CV[k] = XW(0.5 * (P[k].x + P[k - 1].x) * V[k].x, 0.5 * (P[k].y + P[k - 1].y) * V[k].y);
+        Z[k] = XW((q.fsdx * (V[k].x - Vw[k].x) - q.fsdy * (U[k].x - U[k - 1].x)) / (Pw[k - 1].x + P[k - 1].x + P[k].x + Pw[k].x),
+                  (q.fsdx * (V[k].y - Vw[k].y) - q.fsdy * (U[k].y - U[k - 1].y)) / (Pw[k - 1].y + P[k - 1].y + P[k].y + Pw[k].y));
+    }
+    W2 CUe[NR + 1], Ze[NR + 1], CVw[NR + 2], Hw[NR + 1];
+#pragma unroll
+    for (int k = 0; k < NR + 1; k++) CUe[k] = east(CU[k]);
+#pragma unroll
+    for (int k = 1; k < NR + 1; k++) Ze[k] = east(Z[k]);
+#pragma unroll
+    for (int k = 1; k < NR + 2; k++) CVw[k] = west(CV[k]);
+#pragma unroll
+    for (int k = 1; k < NR + 1; k++) Hw[k] = west(H[k]);
+#pragma unroll
+    for (int k = 1; k <= NR; k++) {
+        UN[k - 1] = XW(UO[k - 1].x + q.tdts8 * (Z[k + 1].x + Z[k].x) * (CV[k + 1].x + CVw[k + 1].x + CVw[k].x + CV[k].x) -
+                           q.tdtsdx * (H[k].x - Hw[k].x),
+                       UO[k - 1].y + q.tdts8 * (Z[k + 1].y + Z[k].y) * (CV[k + 1].y + CVw[k + 1].y + CVw[k].y + CV[k].y) -
+                           q.tdtsdx * (H[k].y - Hw[k].y));
+        VN[k - 1] = XW(VO[k - 1].x - q.tdts8 * (Ze[k].x + Z[k].x) * (CUe[k].x + CU[k].x + CU[k - 1].x + CUe[k - 1].x) -
+                           q.tdtsdy * (H[k].x - H[k - 1].x),
+                       VO[k - 1].y - q.tdts8 * (Ze[k].y + Z[k].y) * (CUe[k].y + CU[k].y + CU[k - 1].y + CUe[k - 1].y) -
+                           q.tdtsdy * (H[k].y - H[k - 1].y));
+        PN[k - 1] = XW(PO[k - 1].x - q.tdtsdx * (CUe[k].x - CU[k].x) - q.tdtsdy * (CV[k + 1].x - CV[k].x),
+                       PO[k - 1].y - q.tdtsdx * (CUe[k].y - CU[k].y) - q.tdtsdy * (CV[k + 1].y - CV[k].y));
+    }
+}
+
 struct X2Arrays {
     const double *u, *v, *p;          // level n   (3 x 3 footprint, two cells deep)
     const double *uo, *vo, *po;       // level n-1 (read at the cell, one cell around the tile)
@@ -220,6 +271,108 @@ __global__ __launch_bounds__(256) void shallow_tile_x2(dlesm_sw_params q, int ld
     }
 }
 
+// The SW-offset, DOUBLY PERIODIC model (the GOcean `shallow` benchmark's configuration), two steps per launch.  Nothing is a
+// fixed ring here: level n+1 one cell outside the box is the periodic image of level n+1 inside, i.e. the first stage's
+// result on level-n operands that lie TWO cells outside the box -- one more than the halos hold.  So a chunk (or a row) that
+// lies wholly beyond the halo is loaded from where it is the image of: column i < x0 - 1 from i + Lx, i > x1 + 1 from i - Lx,
+// rows likewise (16-byte loads at whatever 8-byte alignment the shift leaves); the halo cells themselves are read where they
+// are.  The first stage then computes the images with the operands the opposite edge's tile uses: the same bits.  Both levels
+// that come out are stored with their periodic images (shallow_tile_sw's rule: x pair first, then the y pair over the widened
+// columns, field_mod.f90:1394-1464).  Precondition beyond the single step's: level n-1 carries valid halos too (the first stage
+// needs it one cell around the tile); every step entry of this library that writes a level writes its images.
+template <int R, int NTM, bool SM>
+__global__ __launch_bounds__(256) void shallow_tile_sw_x2(dlesm_sw_params q, int ld, int ny, int x0, int x1, int y0, int y1, int cb, int nxw,
+                                                          X2Arrays a, double alpha)
+{
+    const int lane = threadIdx.x & 63;
+    const int xw = blockIdx.x % nxw;                     // (four vertically adjacent tiles per workgroup, as shallow_tile_x2)
+    const int strip = (blockIdx.x / nxw) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int jb = y0 + strip * R;
+    if (jb > y1) return;
+    const int je = jb + R - 1 < y1 ? jb + R - 1 : y1;
+    const int c = cb + xw * 62 - 1 + lane;
+    if (c - lane + 1 > x1 / 2) return;
+    const int Lx = x1 - x0 + 1, Ly = y1 - y0 + 1;
+    const bool out_lane = lane >= 1 && lane <= 62;
+    const bool m0 = out_lane && 2 * c >= x0 && 2 * c <= x1;
+    const bool m1 = out_lane && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
+    // this lane's two columns, from where they are the periodic image of when they lie wholly beyond the halo
+    long colw = 2L * c;
+    if (2 * c + 1 < x0) colw += Lx;                      // (x0 - 2, x0 - 1) -> (x1 - 1, x1); the halo cell x0 - 1 holds x1's value anyway
+    else if (2 * c > x1) colw -= Lx;
+    if (colw < 0) colw = 0;                              // lanes further out than any output lane needs: any valid address
+    if (colw > ld - 2) colw = ld - 2;
+    auto roww = [&](int jj) {                            // rows beyond the halo rows likewise; anything else clamped into the array
+        if (jj < y0 - 1) jj += Ly;
+        else if (jj > y1 + 1) jj -= Ly;
+        return jj < 0 ? 0 : (jj > ny - 1 ? ny - 1 : jj);
+    };
+    typedef double x2_d2a8 __attribute__((ext_vector_type(2), aligned(8)));
+    auto ldw = [&](const double *f, int jj) {
+        const x2_d2a8 t = *(const x2_d2a8 *)(f + (size_t)roww(jj) * ld + colw);
+        return W2{t.x, t.y};
+    };
+    W2 U[R + 4], V[R + 4], P[R + 4], UO[R + 2], VO[R + 2], PO[R + 2];
+#pragma unroll
+    for (int k = 0; k < R + 4; k++) { U[k] = ldw(a.u, jb - 2 + k); V[k] = ldw(a.v, jb - 2 + k); P[k] = ldw(a.p, jb - 2 + k); }
+#pragma unroll
+    for (int k = 0; k < R + 2; k++) { UO[k] = ldw(a.uo, jb - 1 + k); VO[k] = ldw(a.vo, jb - 1 + k); PO[k] = ldw(a.po, jb - 1 + k); }
+    if constexpr ((NTM & 4) != 0) __builtin_amdgcn_sched_barrier(0);
+    W2 U1[R + 2], V1[R + 2], P1[R + 2];
+    sw_step_rows_sw<R + 2>(q, U, V, P, UO, VO, PO, U1, V1, P1);
+    W2 U2[R], V2[R], P2[R], UC[R], VC[R], PC[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        UC[k] = U[k + 2]; VC[k] = V[k + 2]; PC[k] = P[k + 2];
+        if constexpr (SM) {
+            UC[k] = XW(U[k + 2].x + alpha * (U1[k + 1].x - 2.0 * U[k + 2].x + UO[k + 1].x), U[k + 2].y + alpha * (U1[k + 1].y - 2.0 * U[k + 2].y + UO[k + 1].y));
+            VC[k] = XW(V[k + 2].x + alpha * (V1[k + 1].x - 2.0 * V[k + 2].x + VO[k + 1].x), V[k + 2].y + alpha * (V1[k + 1].y - 2.0 * V[k + 2].y + VO[k + 1].y));
+            PC[k] = XW(P[k + 2].x + alpha * (P1[k + 1].x - 2.0 * P[k + 2].x + PO[k + 1].x), P[k + 2].y + alpha * (P1[k + 1].y - 2.0 * P[k + 2].y + PO[k + 1].y));
+        }
+    }
+    // (the filtered level n is needed ONE CELL AROUND the tile as the second stage's old level?  No: a step reads its old level
+    //  at the cell itself only, and the second stage runs on the tile's own cells.)
+    sw_step_rows_sw<R>(q, U1, V1, P1, UC, VC, PC, U2, V2, P2);
+    if constexpr (SM) {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const W2 fu = XW(U1[k + 1].x + alpha * (U2[k].x - 2.0 * U1[k + 1].x + UC[k].x), U1[k + 1].y + alpha * (U2[k].y - 2.0 * U1[k + 1].y + UC[k].y));
+            const W2 fv = XW(V1[k + 1].x + alpha * (V2[k].x - 2.0 * V1[k + 1].x + VC[k].x), V1[k + 1].y + alpha * (V2[k].y - 2.0 * V1[k + 1].y + VC[k].y));
+            const W2 fp = XW(P1[k + 1].x + alpha * (P2[k].x - 2.0 * P1[k + 1].x + PC[k].x), P1[k + 1].y + alpha * (P2[k].y - 2.0 * P1[k + 1].y + PC[k].y));
+            U1[k + 1] = fu; V1[k + 1] = fv; P1[k + 1] = fp;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int jj = jb + k;
+        if (jj > je) break;
+        const int image_n = jj == y0 ? y1 + 1 : -1, image_s = jj == y1 ? y0 - 1 : -1;
+        auto store3 = [&](double *fu, double *fv, double *fp, const W2 &x, const W2 &y, const W2 &z) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int jr = r == 0 ? jj : r == 1 ? image_n : image_s;
+                if (jr < 0) continue;
+                const size_t row = (size_t)jr * ld, o = row + (size_t)c * 2;
+                if (m0 && m1) {
+                    xst<(NTM & 2) != 0>(fu + o, x);
+                    xst<(NTM & 2) != 0>(fv + o, y);
+                    xst<(NTM & 2) != 0>(fp + o, z);
+                } else {
+                    if (m0) { fu[o] = x.x; fv[o] = y.x; fp[o] = z.x; }
+                    if (m1) { fu[o + 1] = x.y; fv[o + 1] = y.y; fp[o + 1] = z.y; }
+                }
+                const int i0 = 2 * c, i1 = 2 * c + 1;      // the first / last internal column also goes to the opposite halo column
+                if (m0 && i0 == x0) { fu[row + x1 + 1] = x.x; fv[row + x1 + 1] = y.x; fp[row + x1 + 1] = z.x; }
+                if (m1 && i1 == x0) { fu[row + x1 + 1] = x.y; fv[row + x1 + 1] = y.y; fp[row + x1 + 1] = z.y; }
+                if (m0 && i0 == x1) { fu[row + x0 - 1] = x.x; fv[row + x0 - 1] = y.x; fp[row + x0 - 1] = z.x; }
+                if (m1 && i1 == x1) { fu[row + x0 - 1] = x.y; fv[row + x0 - 1] = y.y; fp[row + x0 - 1] = z.y; }
+            }
+        };
+        store3(a.u1, a.v1, a.p1, U1[k + 1], V1[k + 1], P1[k + 1]);
+        store3(a.u2, a.v2, a.p2, U2[k], V2[k], P2[k]);
+    }
+}
+
 } // namespace
 
 } // namespace dlesm
@@ -280,6 +433,20 @@ static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int 
     else hipLaunchKernelGGL((shallow_tile_x2<4, 2, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
 #endif
 #undef DLESM_X2
+}
+// the SW-offset doubly periodic form (shallow_tile_sw_x2): four vertically adjacent tiles per workgroup; tile heights and load
+// order as launch_x2 chose them for the NE forms
+static void launch_sw_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int xstop, int ystart, int ystop, X2Arrays a, const double *alpha,
+                         hipStream_t s)
+{
+    const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
+    const int cb = (x0 / 2) & ~7;
+    const int nxw = (x1 / 2 - cb + 62) / 62, tpb = 4;
+    const int R = alpha ? 2 : 4;
+    const int strips = (y1 - y0 + R) / R;
+    const unsigned grid = (unsigned)((long)nxw * ((strips + tpb - 1) / tpb));
+    if (alpha) hipLaunchKernelGGL((shallow_tile_sw_x2<2, 6, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, a, *alpha);
+    else hipLaunchKernelGGL((shallow_tile_sw_x2<4, 2, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, a, 0.0);
 }
 } // namespace
 } // namespace dlesm
@@ -366,6 +533,92 @@ extern "C" int dlesm_shallow_step_smooth_x2_f64(const dlesm_sw_params *q, double
         if (hipMemcpyAsync(dst[k], src[k], bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(DLESM_EHIP, "dlesm_shallow_step_smooth_x2_f64: copy failed");
     if (!rc) rc = dlesm_shallow_step_smooth_f64(q, alpha, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold2, vold2, pold2, t[0], t[1], t[2], stream);
     if (!rc) rc = dlesm_shallow_step_smooth_f64(q, alpha, ld, ny, xstart, xstop, ystart, ystop, t[0], t[1], t[2], uold2, vold2, pold2, unew2, vnew2, pnew2, stream);
+    for (int k = 0; k < 3; k++) (void)hipFreeAsync(t[k], s);
+    return rc;
+}
+
+// ---- the SW-offset, doubly periodic model (the GOcean `shallow` benchmark's configuration) --------------------------------------
+static int sw_x2_common(const char *who, const dlesm_region *internal, int ld, int ny, const double *const (&all)[12], bool *aligned)
+{
+    DLESM_REQUIRE(internal != nullptr, "null pointer");
+    for (const double *f : all) DLESM_REQUIRE(f != nullptr, "null pointer");
+    if (int rc = check_box(who, ld, ny, internal->xstart, internal->xstop, internal->ystart, internal->ystop, 1)) return rc;
+    for (int i = 0; i < 12; i++)
+        for (int j = i + 1; j < 12; j++)
+            DLESM_REQUIRE(all[i] != all[j], "%s: the twelve arrays must be distinct (arguments %d and %d are not)", who, i, j);
+    *aligned = ld % 2 == 0 || (internal->xstop - 1) + 1 <= 2 * (ld / 2) - 1;
+    for (const double *f : all) *aligned = *aligned && ((uintptr_t)f % 16 == 0);
+    return DLESM_OK;
+}
+
+// Two steps of the SW-offset periodic model per launch: == two calls of dlesm_shallow_step_sw_periodic_f64 (level n+1 with its
+// periodic images into unew.., level n+2 with its images into unew2..).  Beyond what those calls ask for, level n-1 must carry
+// valid periodic halos too (every step entry of this library that writes a level writes its images).  Anything but a doubly
+// periodic box, or arrays that miss the wave-tile conditions, takes the two calls.
+extern "C" int dlesm_shallow_step_sw_x2_periodic_f64(const dlesm_sw_params *q, int ld, int ny, const dlesm_region *internal, int bc_x,
+                                                     int bc_y, const double *u, const double *v, const double *p, const double *uold,
+                                                     const double *vold, const double *pold, double *unew, double *vnew, double *pnew,
+                                                     double *unew2, double *vnew2, double *pnew2, void *stream)
+{
+    clear_error();
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(q != nullptr, "null pointer");
+    const double *all[12] = {u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2};
+    bool aligned = false;
+    if (int rc = sw_x2_common("dlesm_shallow_step_sw_x2_periodic_f64", internal, ld, ny, all, &aligned)) return rc;
+    if (internal->xstop < internal->xstart || internal->ystop < internal->ystart) return DLESM_OK;
+    const bool both = bc_x == DLESM_BC_PERIODIC && bc_y == DLESM_BC_PERIODIC;
+    // (a box narrower or lower than two cells has images that wrap more than once: the two calls)
+    if (aligned && both && internal->nx >= 2 && internal->ny >= 2 && tuning("sw_kernel", 0) == 0 && tuning("sw_x2_fused", 1)) {
+        launch_sw_x2(*q, ld, ny, internal->xstart, internal->xstop, internal->ystart, internal->ystop,
+                     X2Arrays{u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2}, nullptr, (hipStream_t)stream);
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
+    if (int rc = dlesm_shallow_step_sw_periodic_f64(q, ld, ny, internal, bc_x, bc_y, u, v, p, uold, vold, pold, unew, vnew, pnew, stream)) return rc;
+    return dlesm_shallow_step_sw_periodic_f64(q, ld, ny, internal, bc_x, bc_y, unew, vnew, pnew, u, v, p, unew2, vnew2, pnew2, stream);
+}
+
+// Two WHOLE time steps of the GOcean `shallow` benchmark per launch: update + time_smooth of the old level + periodic images,
+// twice.  In: level n and the filtered level n-1, with valid periodic halos, untouched.  Out: level n+2 (unew2..) and the filtered
+// level n+1 (uold2..), each with its periodic images: what two calls of dlesm_shallow_step_sw_smooth_periodic_f64 with the loop's
+// rotation leave as the new current and old levels, bit for bit, at 48 instead of 96 B/cell/step.  Ping-pong between the two sextets.
+extern "C" int dlesm_shallow_step_sw_smooth_x2_periodic_f64(const dlesm_sw_params *q, double alpha, int ld, int ny,
+                                                            const dlesm_region *internal, int bc_x, int bc_y, const double *u,
+                                                            const double *v, const double *p, const double *uold, const double *vold,
+                                                            const double *pold, double *unew2, double *vnew2, double *pnew2,
+                                                            double *uold2, double *vold2, double *pold2, void *stream)
+{
+    clear_error();
+    if (int rc = ensure_device()) return rc;
+    DLESM_REQUIRE(q != nullptr, "null pointer");
+    const double *all[12] = {u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2};
+    bool aligned = false;
+    if (int rc = sw_x2_common("dlesm_shallow_step_sw_smooth_x2_periodic_f64", internal, ld, ny, all, &aligned)) return rc;
+    if (internal->xstop < internal->xstart || internal->ystop < internal->ystart) return DLESM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool both = bc_x == DLESM_BC_PERIODIC && bc_y == DLESM_BC_PERIODIC;
+    if (aligned && both && internal->nx >= 2 && internal->ny >= 2 && tuning("sw_kernel", 0) == 0 && tuning("sw_x2_fused", 1)) {
+        launch_sw_x2(*q, ld, ny, internal->xstart, internal->xstop, internal->ystart, internal->ystop,
+                     X2Arrays{u, v, p, uold, vold, pold, uold2, vold2, pold2, unew2, vnew2, pnew2}, &alpha, s);
+        DLESM_HIP_TRY(hipGetLastError());
+        return DLESM_OK;
+    }
+    // the definition, through three stream-ordered scratch arrays for the unfiltered level n+1
+    const size_t bytes = (size_t)ld * ny * sizeof(double);
+    double *t[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 3; k++)
+        if (hipMallocAsync((void **)&t[k], bytes, s) != hipSuccess) {
+            for (int q2 = 0; q2 < k; q2++) (void)hipFreeAsync(t[q2], s);
+            return fail(DLESM_EHIP, "dlesm_shallow_step_sw_smooth_x2_periodic_f64: no scratch memory for the intermediate time level");
+        }
+    const double *src[3] = {uold, vold, pold};
+    double *dst[3] = {uold2, vold2, pold2};
+    int rc = DLESM_OK;
+    for (int k = 0; k < 3 && !rc; k++)
+        if (hipMemcpyAsync(dst[k], src[k], bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(DLESM_EHIP, "dlesm_shallow_step_sw_smooth_x2_periodic_f64: copy failed");
+    if (!rc) rc = dlesm_shallow_step_sw_smooth_periodic_f64(q, alpha, ld, ny, internal, bc_x, bc_y, u, v, p, uold2, vold2, pold2, t[0], t[1], t[2], stream);
+    if (!rc) rc = dlesm_shallow_step_sw_smooth_periodic_f64(q, alpha, ld, ny, internal, bc_x, bc_y, t[0], t[1], t[2], uold2, vold2, pold2, unew2, vnew2, pnew2, stream);
     for (int k = 0; k < 3; k++) (void)hipFreeAsync(t[k], s);
     return rc;
 }

@@ -223,6 +223,25 @@ module dlesm_hip_mod
        type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2, stream
        integer(c_int) :: rc
      end function
+     function dlesm_shallow_step_sw_x2_periodic_f64(params, ld, ny, internal, bc_x, bc_y, u, v, p, uold, vold, pold, &
+          unew, vnew, pnew, unew2, vnew2, pnew2, stream) bind(C, name="dlesm_shallow_step_sw_x2_periodic_f64") result(rc)
+       import :: c_int, c_ptr, c_sw_params, c_region
+       type(c_sw_params), intent(in) :: params
+       integer(c_int), value :: ld, ny, bc_x, bc_y
+       type(c_region), intent(in) :: internal
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2, stream
+       integer(c_int) :: rc
+     end function
+     function dlesm_shallow_step_sw_smooth_x2_periodic_f64(params, alpha, ld, ny, internal, bc_x, bc_y, u, v, p, uold, vold, pold, &
+          unew2, vnew2, pnew2, uold2, vold2, pold2, stream) bind(C, name="dlesm_shallow_step_sw_smooth_x2_periodic_f64") result(rc)
+       import :: c_int, c_ptr, c_sw_params, c_region, c_double
+       type(c_sw_params), intent(in) :: params
+       real(c_double), value :: alpha
+       integer(c_int), value :: ld, ny, bc_x, bc_y
+       type(c_region), intent(in) :: internal
+       type(c_ptr), value :: u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2, stream
+       integer(c_int) :: rc
+     end function
      function dlesm_shallow_step_smooth_x2_f64(params, alpha, ld, ny, xstart, xstop, ystart, ystop, u, v, p, uold, vold, pold, &
           unew2, vnew2, pnew2, uold2, vold2, pold2, stream) bind(C, name="dlesm_shallow_step_smooth_x2_f64") result(rc)
        import :: c_int, c_ptr, c_sw_params, c_double

@@ -58,6 +58,7 @@ module dlesm_psy_mod
   public :: invoke_shallow_step_sw_periodic, plan_shallow_step_sw, invoke_periodic_halos_multi
   public :: invoke_shallow_step_smooth, invoke_shallow_step_sw_smooth_periodic, invoke_shallow_step_smooth_dm
   public :: invoke_shallow_step_x2, invoke_shallow_step_smooth_x2
+  public :: invoke_shallow_step_sw_x2_periodic, invoke_shallow_step_sw_smooth_x2_periodic
 
 contains
 
@@ -428,6 +429,56 @@ contains
                                           field_device_data(uold2), field_device_data(vold2), field_device_data(pold2), c_null_ptr)
     if (rc /= 0) call gocean_stop('invoke_shallow_step_smooth_x2: ' // dlesm_error_text())
   end subroutine invoke_shallow_step_smooth_x2
+
+  !> Two steps of the SW-offset periodic model in one launch (== two invoke_shallow_step_sw_periodic calls): level n+1 with its
+  !! periodic images into unew .. pnew, level n+2 with its images into unew2 .. pnew2.
+  subroutine invoke_shallow_step_sw_x2_periodic(prm, u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2)
+    type(c_sw_params), intent(in) :: prm
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2
+    type(c_region) :: cint
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew);  call need_device(vnew);  call need_device(pnew)
+    call need_device(unew2);  call need_device(vnew2);  call need_device(pnew2)
+    associate (it => p%internal)
+      cint = c_region(it%nx, it%ny, it%xstart, it%xstop, it%ystart, it%ystop)
+    end associate
+    rc = dlesm_shallow_step_sw_x2_periodic_f64(prm, int(p%grid%nx, c_int), int(p%grid%ny, c_int), cint, &
+                                               int(p%grid%boundary_conditions(1), c_int), int(p%grid%boundary_conditions(2), c_int), &
+                                               field_device_data(u), field_device_data(v), field_device_data(p), &
+                                               field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                               field_device_data(unew), field_device_data(vnew), field_device_data(pnew), &
+                                               field_device_data(unew2), field_device_data(vnew2), field_device_data(pnew2), c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_sw_x2_periodic: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_sw_x2_periodic
+
+  !> TWO whole time steps of the GOcean `shallow` benchmark in one launch: update, Asselin filter of the old level and periodic
+  !! images, twice.  Level n+2 into unew2 .. pnew2, the filtered level n+1 into uold2 .. pold2 (both with their images); u .. pold
+  !! are not modified.  == two invoke_shallow_step_sw_smooth_periodic calls with the loop's rotation, at 48 instead of 96 B/cell/step.
+  subroutine invoke_shallow_step_sw_smooth_x2_periodic(prm, alpha, u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2)
+    type(c_sw_params), intent(in) :: prm
+    real(go_wp), intent(in) :: alpha
+    type(r2d_field), intent(inout), target :: u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2
+    type(c_region) :: cint
+    integer(c_int) :: rc
+    call need_device(u);  call need_device(v);  call need_device(p)
+    call need_device(uold);  call need_device(vold);  call need_device(pold)
+    call need_device(unew2);  call need_device(vnew2);  call need_device(pnew2)
+    call need_device(uold2);  call need_device(vold2);  call need_device(pold2)
+    associate (it => p%internal)
+      cint = c_region(it%nx, it%ny, it%xstart, it%xstop, it%ystart, it%ystop)
+    end associate
+    rc = dlesm_shallow_step_sw_smooth_x2_periodic_f64(prm, alpha, int(p%grid%nx, c_int), int(p%grid%ny, c_int), cint, &
+                                                      int(p%grid%boundary_conditions(1), c_int), &
+                                                      int(p%grid%boundary_conditions(2), c_int), &
+                                                      field_device_data(u), field_device_data(v), field_device_data(p), &
+                                                      field_device_data(uold), field_device_data(vold), field_device_data(pold), &
+                                                      field_device_data(unew2), field_device_data(vnew2), field_device_data(pnew2), &
+                                                      field_device_data(uold2), field_device_data(vold2), field_device_data(pold2), &
+                                                      c_null_ptr)
+    if (rc /= 0) call gocean_stop('invoke_shallow_step_sw_smooth_x2_periodic: ' // dlesm_error_text())
+  end subroutine invoke_shallow_step_sw_smooth_x2_periodic
 
   !> The same for the SW-offset periodic model: update, filter and the periodic images of the new and of the filtered old
   !! level in ONE launch -- a whole time step of the GOcean `shallow` benchmark.

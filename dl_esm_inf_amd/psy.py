@@ -283,6 +283,23 @@ def invoke_shallow_step_sw_periodic(params, u, v, p, uold, vold, pold, unew, vne
                                                          vnew.device_ptr, pnew.device_ptr, _stream_ptr(stream)))
 
 
+def invoke_shallow_step_sw_x2_periodic(params, u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2, stream=None):
+    """two steps of the SW-offset periodic model in one launch (== two invoke_shallow_step_sw_periodic calls)"""
+    g = p.grid
+    check(_cabi.lib().dlesm_shallow_step_sw_x2_periodic_f64(
+        C.byref(params), g.nx, g.ny, C.byref(p.internal), g.boundary_conditions[0], g.boundary_conditions[1],
+        *[f.device_ptr for f in (u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2)], _stream_ptr(stream)))
+
+
+def invoke_shallow_step_sw_smooth_x2_periodic(params, alpha, u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2, stream=None):
+    """two WHOLE time steps of the GOcean `shallow` benchmark (update + time_smooth + periodic images, twice) in one launch:
+    level n+2 into unew2.., the filtered level n+1 into uold2..; ping-pong between the two sextets"""
+    g = p.grid
+    check(_cabi.lib().dlesm_shallow_step_sw_smooth_x2_periodic_f64(
+        C.byref(params), float(alpha), g.nx, g.ny, C.byref(p.internal), g.boundary_conditions[0], g.boundary_conditions[1],
+        *[f.device_ptr for f in (u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2)], _stream_ptr(stream)))
+
+
 def invoke_shallow_step_smooth(params, alpha, u, v, p, uold, vold, pold, unew, vnew, pnew, stream=None):
     """one whole leapfrog step of the GOcean benchmark in one launch (NE offset): the u/v/h update + time_smooth of the
     old level in place (== invoke_shallow_step + 3 x invoke_time_smooth, bit for bit).  Afterwards rotate u <- unew."""

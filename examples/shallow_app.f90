@@ -13,7 +13,10 @@
 !!                benchmark's time loop has it; uold <- smoothed u, u <- unew by rotation
 !!   3  fused + time_smooth: ONE launch per time step (invoke_shallow_step_sw_smooth_periodic: update, Asselin filter of the
 !!                old level, periodic images of both levels)
-!! Modes 0 and 1 print the same bits; so do modes 2 and 3.
+!!   4  TWO whole time steps per launch (invoke_shallow_step_sw_smooth_x2_periodic: update, filter and periodic images, twice;
+!!                48 instead of 96 B/cell/step); the loop ping-pongs between two sextets of fields, an odd last step is one
+!!                mode-3 launch
+!! Modes 0 and 1 print the same bits; so do modes 2, 3 and 4.
 !!     shallow_app.exe N NSTEPS [MODE]
 program shallow_app
   use iso_c_binding
@@ -27,11 +30,11 @@ program shallow_app
   character(len=32) :: arg
   integer :: n, nsteps, step, k, rate, t0, t1, mode
   type(grid_type), target :: model_grid
-  type(r2d_field), target :: f(9)          ! u v p | uold vold pold | unew vnew pnew
+  type(r2d_field), target :: f(12)         ! u v p | uold vold pold | unew vnew pnew | (mode 4) the second old level
   type(r2d_field), target :: cu, cv, z, h  ! the intermediates of the per-kernel forms
   real(go_wp), parameter :: dt = 90.0_go_wp, alpha = 0.001_go_wp
   real(go_wp) :: tdt
-  integer :: ptype(9), cur(3), old(3), new(3), tmp(3)
+  integer :: ptype(12), cur(3), old(3), new(3), tmp(3), od2(3)
   real(go_wp), pointer :: d(:,:)
   real(go_wp) :: secs
 
@@ -52,8 +55,8 @@ program shallow_app
   call model_grid%decompose(n, n)
   call grid_init(model_grid, 1.0e5_go_wp, 1.0e5_go_wp)
   ptype = (/ GO_U_POINTS, GO_V_POINTS, GO_T_POINTS, GO_U_POINTS, GO_V_POINTS, GO_T_POINTS, &
-             GO_U_POINTS, GO_V_POINTS, GO_T_POINTS /)
-  do k = 1, 9
+             GO_U_POINTS, GO_V_POINTS, GO_T_POINTS, GO_U_POINTS, GO_V_POINTS, GO_T_POINTS /)
+  do k = 1, merge(12, 9, mode == 4)
      f(k) = r2d_field(model_grid, ptype(k))
   end do
   ! initial state: counter hash on the internal region (u, v in [-0.5,0.5), p in [1,2)), periodic halos,
@@ -70,8 +73,9 @@ program shallow_app
      call invoke_periodic_halos(f(k))
      call invoke_copy(f(k + 3), f(k))
      call invoke_copy(f(k + 6), f(k))
+     if (mode == 4) call invoke_copy(f(k + 9), f(k))
   end do
-  cur = (/1, 2, 3/);  old = (/4, 5, 6/);  new = (/7, 8, 9/)
+  cur = (/1, 2, 3/);  old = (/4, 5, 6/);  new = (/7, 8, 9/);  od2 = (/10, 11, 12/)
   if (mode == 1 .or. mode == 2) then
      cu = r2d_field(model_grid, GO_U_POINTS);  cv = r2d_field(model_grid, GO_V_POINTS)
      z = r2d_field(model_grid, GO_F_POINTS);   h = r2d_field(model_grid, GO_T_POINTS)
@@ -87,6 +91,22 @@ program shallow_app
   call device_sync()
   call system_clock(t0, rate)
   do step = 1, nsteps
+     if (mode == 4) then
+        if (mod(step, 2) == 0) cycle                       ! (the launch of the odd step before has done this one too)
+        if (step < nsteps) then
+           call invoke_shallow_step_sw_smooth_x2_periodic(shallow_params(model_grid%dx, model_grid%dy, dt), alpha, &
+                                                          f(cur(1)), f(cur(2)), f(cur(3)), f(old(1)), f(old(2)), f(old(3)), &
+                                                          f(new(1)), f(new(2)), f(new(3)), f(od2(1)), f(od2(2)), f(od2(3)))
+           tmp = cur;  cur = new;  new = tmp               ! level n+2 is current, the filtered level n+1 the old one:
+           tmp = old;  old = od2;  od2 = tmp               ! ping-pong between the two sextets
+        else                                               ! an odd number of steps: the last one on its own
+           call invoke_shallow_step_sw_smooth_periodic(shallow_params(model_grid%dx, model_grid%dy, dt), alpha, &
+                                                       f(cur(1)), f(cur(2)), f(cur(3)), f(old(1)), f(old(2)), f(old(3)), &
+                                                       f(new(1)), f(new(2)), f(new(3)))
+           tmp = cur;  cur = new;  new = tmp
+        end if
+        cycle
+     end if
      if (mode == 0) then
         call invoke_shallow_step_sw_periodic(shallow_params(model_grid%dx, model_grid%dy, dt), &
                                              f(cur(1)), f(cur(2)), f(cur(3)), f(old(1)), f(old(2)), f(old(3)), &

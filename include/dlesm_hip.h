@@ -352,6 +352,20 @@ int dlesm_shallow_step_smooth_x2_f64(const dlesm_sw_params *q, double alpha, int
                                      int ystop, const double *u, const double *v, const double *p, const double *uold,
                                      const double *vold, const double *pold, double *unew2, double *vnew2, double *pnew2,
                                      double *uold2, double *vold2, double *pold2, void *stream);
+/* The same two entries for the SW-offset, doubly periodic model -- the configuration of the GOcean `shallow` benchmark
+ * (field_mod.f90:675-751, 1394-1464): == two calls of dlesm_shallow_step_sw_periodic_f64 / dlesm_shallow_step_sw_smooth_periodic_f64
+ * with the loop's rotation, periodic images of every level that comes out included.  Level n+1 one cell outside the box is the
+ * image of level n+1 inside, so the first stage reads level n TWO cells outside the box from where it is the image of.  Beyond
+ * the single steps' preconditions: level n-1 carries valid periodic halos as well. */
+int dlesm_shallow_step_sw_x2_periodic_f64(const dlesm_sw_params *q, int ld, int ny, const dlesm_region *internal, int bc_x, int bc_y,
+                                          const double *u, const double *v, const double *p, const double *uold, const double *vold,
+                                          const double *pold, double *unew, double *vnew, double *pnew, double *unew2,
+                                          double *vnew2, double *pnew2, void *stream);
+int dlesm_shallow_step_sw_smooth_x2_periodic_f64(const dlesm_sw_params *q, double alpha, int ld, int ny, const dlesm_region *internal,
+                                                 int bc_x, int bc_y, const double *u, const double *v, const double *p,
+                                                 const double *uold, const double *vold, const double *pold, double *unew2,
+                                                 double *vnew2, double *pnew2, double *uold2, double *vold2, double *pold2,
+                                                 void *stream);
 
 /* One WHOLE time step of the GOcean leapfrog in one launch: the u/v/h update AND the Asselin filter of the old level
  * (the benchmark's time_smooth kernel), from values the lanes already hold --

@@ -275,8 +275,9 @@ def test_fortran_device_io_and_jacobi_on_gpu(exe):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["fused", "seven-kernels", "seven-kernels+time_smooth", "fused+time_smooth"])
-@pytest.mark.parametrize("n,nsteps,alignment", [(10, 5, None), (256, 6, 64)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4], ids=["fused", "seven-kernels", "seven-kernels+time_smooth", "fused+time_smooth",
+                                                      "two-filtered-steps-per-launch"])
+@pytest.mark.parametrize("n,nsteps,alignment", [(10, 5, None), (256, 6, 64)])      # (5 steps: mode 4 ends with one single step)
 def test_fortran_periodic_shallow_app_on_gpu(exe, n, nsteps, alignment, mode):
     """examples/shallow_app.f90 -- a GOcean-style SW-offset, doubly periodic shallow-water model written
     against the reference's API (grid_type, r2d_field, halo lists) with the PSy layer of this library: the fused

@@ -210,3 +210,103 @@ def test_two_filtered_steps_per_launch(D, nx, ny, alignment, fallback):
                 assert torch.equal(cut(x), cut(y)), (pair, int((cut(x) != cut(y)).sum()))
     finally:
         L.dlesm_set_tuning(b"sw_x2_fused", 1)
+
+
+# ---- the SW-offset, doubly periodic model (the GOcean `shallow` benchmark's configuration) --------------------------------------
+def _grid_sw(D, nx, ny, alignment):
+    import os
+    if alignment is None:
+        os.environ.pop("DL_ESM_ALIGNMENT", None)
+    else:
+        os.environ["DL_ESM_ALIGNMENT"] = str(alignment)
+    g = D.grid_type(D.GO_ARAKAWA_C, (D.GO_BC_PERIODIC, D.GO_BC_PERIODIC, D.GO_BC_NONE), D.GO_OFFSET_SW)
+    g.decompose(nx, ny)
+    D.grid_init(g, 1.0, 1.0)
+    return g
+
+
+def _periodic_fields(D, g, seed):
+    """twelve fields of the periodic model: levels n and n-1 hash data on the internal region with their periodic images; the
+    output arrays start as garbage (-3) everywhere, halos included: whatever is valid afterwards the launch has written"""
+    pts = {"u": D.GO_U_POINTS, "v": D.GO_V_POINTS, "p": D.GO_T_POINTS}
+    F = {n: D.r2d_field(g, pts[n[0]]) for n in NAMES}
+    it = F["p"].internal
+    for k, n in enumerate(NAMES[:6]):
+        D.psy.hash_init(F[n], seed + k, box=it)
+        F[n].data.mul_(0.1)
+        F[n].data.add_(1.0 if n[0] == "p" else -0.05)
+        D.psy.apply_periodic_halos(F[n])
+    for n in NAMES[6:]:
+        D.set_field(F[n], -3.0)
+    return F
+
+
+PERIODIC_CASES = [(2, 2, None), (3, 5, None), (10, 10, None), (10, 10, 8), (9, 7, 2), (64, 48, 8), (63, 49, None), (124, 5, 2), (125, 6, 2),
+                  (257, 129, None), (256, 130, 64), (300, 77, None), (1021, 33, 64), (130, 260, 64)]
+
+
+@pytest.mark.parametrize("fallback", [False, True])
+@pytest.mark.parametrize("nx,ny,alignment", PERIODIC_CASES)
+def test_two_periodic_steps_per_launch_match_the_oracle_model(D, nx, ny, alignment, fallback):
+    """dlesm_shallow_step_sw_x2_periodic_f64 against the ORACLE running the periodic model for two steps (orc_sw_step_sw + the
+    reference's periodic copies, field_mod.f90:1394-1464): both levels, internal region AND halos, bit for bit; even and odd N
+    (the image of a column two cells outside the box lands on either 16-byte phase)"""
+    import torch
+    L = D._cabi.lib()
+    g = _grid_sw(D, nx, ny, alignment)
+    F = _periodic_fields(D, g, SEED + 60)
+    it = F["p"].internal
+    prm = D.psy.shallow_params(1.0e5, 0.9e5, 40.0)
+    H = {n: F[n].get_data() for n in NAMES}
+    n1 = [H[n].copy() for n in NAMES[6:9]]
+    n2 = [H[n].copy() for n in NAMES[9:]]
+    O.sw_step_sw(prm, g.nx, it.box(), H["u"], H["v"], H["p"], H["uold"], H["vold"], H["pold"], *n1)
+    for f in n1:
+        O.apply_periodic_halos(f, g.nx, it.box(), 0, 0)
+    O.sw_step_sw(prm, g.nx, it.box(), *n1, H["u"], H["v"], H["p"], *n2)
+    for f in n2:
+        O.apply_periodic_halos(f, g.nx, it.box(), 0, 0)
+    L.dlesm_set_tuning(b"sw_x2_fused", 0 if fallback else 1)
+    try:
+        D.psy.invoke_shallow_step_sw_x2_periodic(prm, *[F[n] for n in NAMES])
+        torch.cuda.synchronize()
+    finally:
+        L.dlesm_set_tuning(b"sw_x2_fused", 1)
+    for name, want in zip(NAMES[6:], n1 + n2):
+        got = F[name].get_data()
+        a, b = got[:it.ystop + 1, :it.xstop + 1], want[:it.ystop + 1, :it.xstop + 1]      # internal region + the halo ring
+        assert np.array_equal(a, b), (name, int(np.count_nonzero(a != b)), np.argwhere(a != b)[:6].tolist())
+    for n in NAMES[:6]:
+        assert np.array_equal(F[n].get_data(), H[n]), n
+
+
+@pytest.mark.parametrize("fallback", [False, True])
+@pytest.mark.parametrize("nx,ny,alignment", [(2, 2, None), (10, 10, None), (9, 7, 2), (64, 48, 8), (63, 49, None), (257, 129, None), (300, 77, None),
+                                             (1021, 33, 64), (130, 260, 64)])
+def test_two_filtered_periodic_steps_per_launch(D, nx, ny, alignment, fallback):
+    """dlesm_shallow_step_sw_smooth_x2_periodic_f64 -- two whole time steps of the GOcean `shallow` loop per launch -- against the
+    one-launch filtered periodic step applied twice with the loop's rotation (itself checked against the oracle's loop nests,
+    tests/test_gpu_shallow_kernels.py), three double steps in a row: internal region and halos of both levels"""
+    import torch
+    L = D._cabi.lib()
+    g = _grid_sw(D, nx, ny, alignment)
+    alpha = 0.001
+    prm = D.psy.shallow_params(1.0e5, 0.9e5, 40.0)
+    A, B = _periodic_fields(D, g, SEED + 80), _periodic_fields(D, g, SEED + 80)
+    it = A["p"].internal
+    a_cur, a_old, a_n2, a_o2 = ([A[n] for n in NAMES[k:k + 3]] for k in (0, 3, 6, 9))
+    b_cur, b_old, b_new = ([B[n] for n in NAMES[k:k + 3]] for k in (0, 3, 6))
+    cut = lambda f: f.data[:it.ystop + 1, :it.xstop + 1]      # noqa: E731
+    L.dlesm_set_tuning(b"sw_x2_fused", 0 if fallback else 1)
+    try:
+        for pair in range(3):
+            D.psy.invoke_shallow_step_sw_smooth_x2_periodic(prm, alpha, *a_cur, *a_old, *a_n2, *a_o2)
+            a_cur, a_old, a_n2, a_o2 = a_n2, a_o2, a_cur, a_old
+            for _ in range(2):
+                D.psy.invoke_shallow_step_sw_smooth_periodic(prm, alpha, *b_cur, *b_old, *b_new)
+                b_cur, b_old, b_new = b_new, b_old, b_cur
+            torch.cuda.synchronize()
+            for x, y in zip(a_cur + a_old, b_cur + b_old):
+                assert torch.equal(cut(x), cut(y)), (pair, int((cut(x) != cut(y)).sum()), (cut(x) != cut(y)).nonzero()[:6].tolist())
+    finally:
+        L.dlesm_set_tuning(b"sw_x2_fused", 1)
