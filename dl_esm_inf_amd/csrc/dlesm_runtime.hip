@@ -75,7 +75,7 @@ static const struct { const char *key; int cls; } kKeys[] = {
     {"j5xt_march", KEY_LAB}, {"j5xt_march_slots", KEY_LAB}, {"j5xt_march_ring", KEY_LAB}, {"j5xt_march_perm", KEY_LAB},
     {"sw_tile_rows", KEY_LAB}, {"sw_dpp", KEY_LAB}, {"sw_stack", KEY_LAB}, {"sw_dm_diag", KEY_LAB},
     {"dm_event_system_fence", KEY_LAB}, {"util_segp", KEY_LAB},
-    {"sw_x2_rows", KEY_LAB}, {"sw_x2_nt", KEY_LAB}, {"sw_x2_stack", KEY_LAB}, {"sw_x2_pad", KEY_LAB},
+    {"sw_x2_rows", KEY_LAB}, {"sw_x2_nt", KEY_LAB}, {"sw_x2_stack", KEY_LAB}, {"sw_x2_pad", KEY_LAB}, {"sw_x2_sw_form", KEY_LAB},
 };
 static int key_class(const char *key)
 {

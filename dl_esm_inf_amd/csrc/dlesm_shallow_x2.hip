@@ -165,8 +165,9 @@ struct X2Arrays {
 // FILTERED level n+1 (into u1, v1, p1) -- the unfiltered one never leaves the registers.  The filter is cell-local, so it
 // costs no halo.  The ring of level n+1 is then taken from level n (u, v, p): a non-periodic model keeps the same fixed
 // boundary values at every time level, and no array holds an unfiltered level n+1 to read it from.
-template <int R, int NTM, bool SM = false>
-__global__ __launch_bounds__(256) void shallow_tile_x2(dlesm_sw_params q, int ld, int ny, int x0, int x1, int y0, int y1, int cb, int nxw,
+// WPE: the occupancy (waves per SIMD) the register allocator is held to -- __launch_bounds__(256) alone only promises one.
+template <int R, int NTM, bool SM = false, int WPE = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void shallow_tile_x2(dlesm_sw_params q, int ld, int ny, int x0, int x1, int y0, int y1, int cb, int nxw,
                                                        int stack, X2Arrays a, double alpha)
 {
     const int lane = threadIdx.x & 63;
@@ -280,8 +281,8 @@ __global__ __launch_bounds__(256) void shallow_tile_x2(dlesm_sw_params q, int ld
 // that come out are stored with their periodic images (shallow_tile_sw's rule: x pair first, then the y pair over the widened
 // columns, field_mod.f90:1394-1464).  Precondition beyond the single step's: level n-1 carries valid halos too (the first stage
 // needs it one cell around the tile); every step entry of this library that writes a level writes its images.
-template <int R, int NTM, bool SM>
-__global__ __launch_bounds__(256) void shallow_tile_sw_x2(dlesm_sw_params q, int ld, int ny, int x0, int x1, int y0, int y1, int cb, int nxw,
+template <int R, int NTM, bool SM, int WPE = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void shallow_tile_sw_x2(dlesm_sw_params q, int ld, int ny, int x0, int x1, int y0, int y1, int cb, int nxw,
                                                           X2Arrays a, double alpha)
 {
     const int lane = threadIdx.x & 63;
@@ -442,16 +443,37 @@ static void launch_sw_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, i
     const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
     const int cb = (x0 / 2) & ~7;
     const int nxw = (x1 / 2 - cb + 62) / 62, tpb = 4;
-    const int R = alpha ? 2 : 4;
+    // plain form: two-row tiles held to two waves per SIMD.  Left to itself (a 256-thread launch bound only promises one wave per
+    // SIMD) the allocator takes 260 registers for two-row and 346 for four-row tiles -- one wave per SIMD, 1.555 ms per launch at
+    // 8192^2; capped at 256: 1.357 ms (four-row tiles capped: 320 B of scratch, 2.06 ms).  sw_x2_sw_form = 1 (lab): the uncapped
+    // four-row form.
+    const int form = kLab && !alpha ? tuning("sw_x2_sw_form", 0) : 0;
+    const int R = form == 1 ? 4 : 2;
     const int strips = (y1 - y0 + R) / R;
     const unsigned grid = (unsigned)((long)nxw * ((strips + tpb - 1) / tpb));
     if (alpha) hipLaunchKernelGGL((shallow_tile_sw_x2<2, 6, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, a, *alpha);
-    else hipLaunchKernelGGL((shallow_tile_sw_x2<4, 2, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, a, 0.0);
+#ifdef DLESM_LAB
+    else if (form == 1) hipLaunchKernelGGL((shallow_tile_sw_x2<4, 2, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, a, 0.0);
+#endif
+    else hipLaunchKernelGGL((shallow_tile_sw_x2<2, 2, false, 2>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, a, 0.0);
 }
 } // namespace
 } // namespace dlesm
 
 using namespace dlesm;
+
+// the twelve arrays of a two-step call are ld x ny doubles each and must not overlap (a shifted alias would be read and written
+// by different tiles of one launch)
+static int x2_disjoint(const char *who, const double *const (&all)[12], int ld, int ny)
+{
+    const uintptr_t bytes = (uintptr_t)ld * (uintptr_t)ny * sizeof(double);
+    for (int i = 0; i < 12; i++)
+        for (int j = i + 1; j < 12; j++) {
+            const uintptr_t a = (uintptr_t)all[i], b = (uintptr_t)all[j];
+            DLESM_REQUIRE((a < b ? b - a : a - b) >= bytes, "%s: the twelve arrays must not overlap (arguments %d and %d do)", who, i, j);
+        }
+    return DLESM_OK;
+}
 
 // Two leapfrog steps, one launch (NE offset, fixed boundary ring): level n+1 into (unew, vnew, pnew), level n+2 into
 // (unew2, vnew2, pnew2) -- bit for bit what
@@ -471,9 +493,7 @@ extern "C" int dlesm_shallow_step_x2_f64(const dlesm_sw_params *q, int ld, int n
     if (xstop < xstart || ystop < ystart) return DLESM_OK;
     if (int rc = check_box("dlesm_shallow_step_x2_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     const double *all[12] = {u, v, p, uold, vold, pold, unew, vnew, pnew, unew2, vnew2, pnew2};
-    for (int i = 0; i < 12; i++)
-        for (int j = i + 1; j < 12; j++)
-            DLESM_REQUIRE(all[i] != all[j], "dlesm_shallow_step_x2_f64: the twelve arrays must be distinct (arguments %d and %d are not)", i, j);
+    if (int rc = x2_disjoint("dlesm_shallow_step_x2_f64", all, ld, ny)) return rc;
     bool aligned = ld % 2 == 0 || (xstop - 1) + 1 <= 2 * (ld / 2) - 1;
     for (const double *f : all) aligned = aligned && ((uintptr_t)f % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
@@ -505,9 +525,7 @@ extern "C" int dlesm_shallow_step_smooth_x2_f64(const dlesm_sw_params *q, double
     if (xstop < xstart || ystop < ystart) return DLESM_OK;
     if (int rc = check_box("dlesm_shallow_step_smooth_x2_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     const double *all[12] = {u, v, p, uold, vold, pold, unew2, vnew2, pnew2, uold2, vold2, pold2};
-    for (int i = 0; i < 12; i++)
-        for (int j = i + 1; j < 12; j++)
-            DLESM_REQUIRE(all[i] != all[j], "dlesm_shallow_step_smooth_x2_f64: the twelve arrays must be distinct (arguments %d and %d are not)", i, j);
+    if (int rc = x2_disjoint("dlesm_shallow_step_smooth_x2_f64", all, ld, ny)) return rc;
     bool aligned = ld % 2 == 0 || (xstop - 1) + 1 <= 2 * (ld / 2) - 1;
     for (const double *f : all) aligned = aligned && ((uintptr_t)f % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
@@ -543,9 +561,7 @@ static int sw_x2_common(const char *who, const dlesm_region *internal, int ld, i
     DLESM_REQUIRE(internal != nullptr, "null pointer");
     for (const double *f : all) DLESM_REQUIRE(f != nullptr, "null pointer");
     if (int rc = check_box(who, ld, ny, internal->xstart, internal->xstop, internal->ystart, internal->ystop, 1)) return rc;
-    for (int i = 0; i < 12; i++)
-        for (int j = i + 1; j < 12; j++)
-            DLESM_REQUIRE(all[i] != all[j], "%s: the twelve arrays must be distinct (arguments %d and %d are not)", who, i, j);
+    if (int rc = x2_disjoint(who, all, ld, ny)) return rc;
     *aligned = ld % 2 == 0 || (internal->xstop - 1) + 1 <= 2 * (ld / 2) - 1;
     for (const double *f : all) *aligned = *aligned && ((uintptr_t)f % 16 == 0);
     return DLESM_OK;

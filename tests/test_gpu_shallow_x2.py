@@ -133,7 +133,10 @@ def test_refusals(D):
     assert call(ptrs, it.box()) == 0
     aliased = list(ptrs)
     aliased[9] = aliased[3]                           # level n+2 into the arrays of level n-1: refused (not in place)
-    assert call(aliased, it.box()) == D._cabi.EINVAL and b"distinct" in L.dlesm_last_error()
+    assert call(aliased, it.box()) == D._cabi.EINVAL and b"overlap" in L.dlesm_last_error()
+    shifted = list(ptrs)
+    shifted[10] = C.c_void_p(ptrs[4].value + 16 * g.nx)     # vnew2 two rows into vold: a shifted alias
+    assert call(shifted, it.box()) == D._cabi.EINVAL and b"overlap" in L.dlesm_last_error()
     assert call(ptrs, (1, it.xstop, it.ystart, it.ystop)) == D._cabi.EINVAL          # no room for the stencil ring
     assert call(ptrs, (5, 4, it.ystart, it.ystop)) == 0                              # an empty box: a zero-trip loop nest
 
@@ -278,6 +281,26 @@ def test_two_periodic_steps_per_launch_match_the_oracle_model(D, nx, ny, alignme
         assert np.array_equal(a, b), (name, int(np.count_nonzero(a != b)), np.argwhere(a != b)[:6].tolist())
     for n in NAMES[:6]:
         assert np.array_equal(F[n].get_data(), H[n]), n
+
+
+@pytest.mark.lab
+@pytest.mark.parametrize("nx,ny,alignment", [(10, 10, None), (63, 49, None), (257, 129, None), (1021, 33, 64), (130, 260, 64)])
+def test_two_periodic_steps_four_row_tiles(D, nx, ny, alignment):
+    """the comparison form of the plain periodic kernel (four-row tiles, registers uncapped: lab build) == the product's form"""
+    import torch
+    L = D._cabi.lib()
+    g = _grid_sw(D, nx, ny, alignment)
+    A, B = _periodic_fields(D, g, SEED + 70), _periodic_fields(D, g, SEED + 70)
+    prm = D.psy.shallow_params(1.0e5, 0.9e5, 40.0)
+    D.psy.invoke_shallow_step_sw_x2_periodic(prm, *[A[n] for n in NAMES])
+    L.dlesm_set_tuning(b"sw_x2_sw_form", 1)
+    try:
+        D.psy.invoke_shallow_step_sw_x2_periodic(prm, *[B[n] for n in NAMES])
+        torch.cuda.synchronize()
+    finally:
+        L.dlesm_set_tuning(b"sw_x2_sw_form", 0)
+    for n in NAMES:
+        assert torch.equal(A[n].data, B[n].data), n
 
 
 @pytest.mark.parametrize("fallback", [False, True])
