@@ -744,6 +744,39 @@ def shallow_water_periodic(D, torch, stream, alignment, tile, steps):
            "one_launch_equals_step_plus_halo_copies": same,
            # pnew - pold is a discrete divergence: on the torus SUM(p) is conserved up to rounding
            "mass_drift_relative": abs(p1 - p0[(5 + steps) % 2]) / abs(p0[(5 + steps) % 2])}
+    # round 4: two plain steps per launch (dlesm_shallow_step_sw_x2_periodic_f64, 48 B/cell/step), checked against two one-launch steps
+    try:
+        ex = [D.r2d_field(g, f.defined_on) for f in cur + cur]          # levels n+1 and n+2 of the two-step call
+        ref = [D.r2d_field(g, f.defined_on) for f in cur + cur]
+        with torch.cuda.stream(stream):
+            D.psy.invoke_shallow_step_sw_x2_periodic(prm, *cur, *old, *ex, stream=stream)
+            D.psy.invoke_shallow_step_sw_periodic(prm, *cur, *old, *ref[:3], stream=stream)
+            D.psy.invoke_shallow_step_sw_periodic(prm, *ref[:3], *cur, *ref[3:], stream=stream)
+        stream.synchronize()
+        same2 = all(bool(torch.equal(a.data[:tile + 2, :tile + 2], b.data[:tile + 2, :tile + 2])) for a, b in zip(ex, ref))
+        del ref
+        torch.cuda.empty_cache()
+        launches = max(MIN_SECONDARY_LAUNCHES, steps // 2)
+        with torch.cuda.stream(stream):
+            c2, o2, n1, n2 = cur, old, ex[:3], ex[3:]
+            for k in range(launches + 3):
+                if k == 3:
+                    e0.record(stream)
+                D.psy.invoke_shallow_step_sw_x2_periodic(prm, *c2, *o2, *n1, *n2, stream=stream)
+                c2, o2, n1, n2 = n2, n1, o2, c2
+            e1.record(stream)
+        stream.synchronize()
+        ms2 = e0.elapsed_time(e1) / launches
+        out["two_steps_per_launch"] = {"ms_per_launch": round(ms2, 5), "ms_per_step": round(ms2 / 2, 5),
+                                       "value": round(2 * cells / (ms2 * 1e-3) / 1e6, 1), "unit": "Mcells/s",
+                                       "algorithmic_bytes_per_cell_per_step": 48,
+                                       "frac": round(96 * cells / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "kernel": "shallow_tile_sw_x2<2,2,plain> held to two waves per SIMD",
+                                       "bit_identical_to_two_one_launch_steps_fields_and_halos": bool(same2),
+                                       "speedup_per_step": round(2 * ms / ms2, 3)}
+        del ex
+    except Exception as e:                                   # noqa: BLE001
+        out["two_steps_per_launch"] = {"error": f"{type(e).__name__}: {e}"}
     # round 4: the benchmark's WHOLE time loop -- update, Asselin filter of the old level, periodic images -- one launch per step
     # (dlesm_shallow_step_sw_smooth_periodic_f64, 96 B/cell/step) and TWO steps per launch (..._smooth_x2_periodic_f64, 48): the
     # two-step form is checked against two one-launch steps from the same state (fields and halos), then both are timed

@@ -54,6 +54,8 @@ def test_bench_line_and_secondary_legs():
     assert "error" not in x2 and x2["bit_identical_to_two_single_steps"] is True and x2["value"] > 0, x2
     assert x2["roofline"]["algorithmic_bytes_per_cell_per_step"] == 48 and x2["copy_ceiling"]["best_gbs"] > 0, x2
     assert sw["sw_offset_periodic"]["one_launch_equals_step_plus_halo_copies"] is True, sw["sw_offset_periodic"]
+    pp = sw["sw_offset_periodic"]["two_steps_per_launch"]
+    assert "error" not in pp and pp["bit_identical_to_two_one_launch_steps_fields_and_halos"] is True and pp["value"] > 0, pp
     pts = sw["sw_offset_periodic"]["with_time_smooth"]       # round 4: the benchmark's filtered loop, one and two steps per launch
     assert "error" not in pts and pts["two_steps_per_launch"]["bit_identical_to_two_one_launch_steps_fields_and_halos"] is True, pts
     assert pts["two_steps_per_launch"]["value"] > 0 and pts["one_launch_per_step"]["value"] > 0, pts
