@@ -71,9 +71,25 @@ def _tune(D, kw):
         D._cabi.lib().dlesm_set_tuning(k.encode(), v)
 
 
-@pytest.mark.parametrize("nx,ny,alignment", CASES)
-@pytest.mark.parametrize("nsteps", STEPS)
-@pytest.mark.parametrize("tune", TUNES, ids=lambda t: "-".join(f"{k}{v}" for k, v in t.items()) or "default")
+# the forms the product library holds run the whole matrix; the comparison forms of the lab build (tile heights, shuffles instead
+# of DPP, the pipeline form) a representative part of it -- they are measurements' counterparts, not what ships
+LAB_CASES = [(1, 1, None), (10, 4, 8), (61, 67, None), (124, 9, 2), (249, 31, 64), (1021, 33, 64), (1100, 90, None), (2047, 150, 2), (5000, 64, 64)]
+LAB_STEPS = [2, 5, 8]
+
+
+def _matrix():
+    from conftest import needs_lab
+    out = []
+    for tune in TUNES:
+        lab = needs_lab({**DEFAULTS, **tune})
+        for case in (LAB_CASES if lab else CASES):
+            for nsteps in (LAB_STEPS if lab else STEPS):
+                tid = "-".join(f"{k}{v}" for k, v in tune.items()) or "default"
+                out.append(pytest.param(*case, nsteps, tune, id=f"{tid}-{nsteps}-{case[0]}-{case[1]}-{case[2]}"))
+    return out
+
+
+@pytest.mark.parametrize("nx,ny,alignment,nsteps,tune", _matrix())
 def test_fused_steps_bit_exact(D, nx, ny, alignment, nsteps, tune):
     _tune(D, {**DEFAULTS, **tune})
     try:
