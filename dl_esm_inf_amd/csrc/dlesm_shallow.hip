@@ -3,11 +3,18 @@
 // 72 B/cell of algorithmic traffic: u, v, p (3x3 footprint), uold, vold, pold read once,
 // unew, vnew, pnew written once; cu, cv, z, h never touch memory.
 //
-// Work unit: a wave tile of 62 output lanes x 2 doubles x R rows.  A wave loads 64 lanes
-// (one 16-byte-aligned, 1 KiB-contiguous access per row): lanes 0 and 63 are halo lanes whose
+// Work unit: a wave tile of 56 output lanes x 2 doubles x R rows.  A wave loads 64 lanes
+// (one 16-byte-aligned, 1 KiB-contiguous access per row): the outer lanes are halo lanes whose
 // values only feed their neighbours through wave64 shuffles, so there are no scattered edge
 // loads and every cross-lane value -- raw (p, v east; u west) or derived (cu, z west; cv, h
-// east) -- is one shuffle away.  Tiles are numbered row-major and workgroups sweep memory
+// east) -- is one shuffle away.  ONE halo lane per side is all the arithmetic needs; FOUR are
+// given up (SW_HALO_LANES) so that a tile's 112 output columns are seven WHOLE 128-byte lines
+// of every array written: with 62 output lanes the tile edges fell inside a line (at 992-byte
+// steps) and two of every 8.75 lines stored per row were partial.  Measured at 8192^2, same
+// box, planned shapes (round 4): step 0.823 -> 0.808 ms, filtered step 1.18 -> 1.12 ms, the
+// periodic forms alike, against 12.5 % more lanes loaded (L2 hits: the neighbouring tile's
+// lines); eight halo lanes (loads on whole lines as well) 0.814 / 1.13.
+// Tiles are numbered row-major and workgroups sweep memory
 // linearly in dispatch order, exactly as jacobi5_tile does (see the notes there); the
 // (R+2)-row overlap between vertically adjacent tiles is served by L2 / Infinity Cache.
 //
@@ -27,6 +34,9 @@ namespace dlesm {
 namespace {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int SW_HALO_LANES = 4;                         // lanes per side that only feed their neighbours
+constexpr int SW_OUT_LANES = 64 - 2 * SW_HALO_LANES;     // 56 chunks = 112 columns = 7 lines of 128 bytes
 
 struct V2 {
     double x, y;
@@ -98,11 +108,11 @@ __device__ __forceinline__ void shallow_tile_body(
     if (jb > y1) return;
     int je = jb + R - 1;
     if (je > y1) je = y1;
-    const int c = cb + xw * 62 - 1 + lane;             // this lane's chunk (2 columns)
-    if (c - lane + 1 > x1 / 2) return;                 // idle padding tile
+    const int c = cb + xw * SW_OUT_LANES - SW_HALO_LANES + lane;             // this lane's chunk (2 columns)
+    if (c - lane + SW_HALO_LANES > x1 / 2) return;                 // idle padding tile
     const int c_ld = ld / 2 - 1;
     const int cl = c < 0 ? 0 : (c > c_ld ? c_ld : c);  // halo / trailing lanes: any valid chunk
-    const bool out_lane = lane >= 1 && lane <= 62 && c <= c_ld;
+    const bool out_lane = lane >= SW_HALO_LANES && lane < 64 - SW_HALO_LANES && c <= c_ld;
     const bool m0 = out_lane && 2 * c >= x0 && 2 * c <= x1;
     const bool m1 = out_lane && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
 
@@ -410,11 +420,11 @@ __global__ __launch_bounds__(512) void shallow_tile_sw(
     if (jb > y1) return;
     int je = jb + R - 1;
     if (je > y1) je = y1;
-    const int c = cb + xw * 62 - 1 + lane;             // this lane's chunk (2 columns)
-    if (c - lane + 1 > x1 / 2) return;                 // idle padding tile
+    const int c = cb + xw * SW_OUT_LANES - SW_HALO_LANES + lane;             // this lane's chunk (2 columns)
+    if (c - lane + SW_HALO_LANES > x1 / 2) return;                 // idle padding tile
     const int c_ld = ld / 2 - 1;
     const int cl = c < 0 ? 0 : (c > c_ld ? c_ld : c);  // halo / trailing lanes: any valid chunk
-    const bool out_lane = lane >= 1 && lane <= 62 && c <= c_ld;
+    const bool out_lane = lane >= SW_HALO_LANES && lane < 64 - SW_HALO_LANES && c <= c_ld;
     const bool m0 = out_lane && 2 * c >= x0 && 2 * c <= x1;
     const bool m1 = out_lane && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
 
@@ -567,28 +577,20 @@ static inline int sw_first_chunk(int x0) { return (x0 / 2) & ~7; }
 static void sw_rule_shape(int ld, int x0, int x1, int *nxw_out, int *tpb_out)
 {
     const int cb = sw_first_chunk(x0), c_last = x1 / 2;
-    int nxw = (c_last - cb + 62) / 62, tpb = 4;          // 62 output chunks per wave tile
-    // This kernel's landscape differs from the Jacobi one (nine arrays in flight): an exhaustive search at
-    // 8192^2 (scripts/shallow_probe.py 8192 search; 67 tiles per row) finds 8 waves per group JUST ABOVE a
-    // multiple of 8 groups best (67 tiles 0.844 ms, 68 0.846, 69 0.852), 4 waves at 23.75 groups equal
-    // (0.846), and the region the Jacobi rule would pick -- 15.75 groups per row -- 25 % slower.  So: the
-    // group size whose 8-group multiple lies closest below the row, no padding when the row is within
-    // 3/8 group past it, else padding up to the next multiple (+1 tile when that lands on it exactly).
+    int nxw = (c_last - cb + SW_OUT_LANES) / SW_OUT_LANES, tpb = 4;          // output chunks per wave tile
+    // Exhaustive (waves per group, tiles per row) searches with the 56-lane tile at 2048^2 .. 12288^2 (round 4,
+    // scripts/shallow_shape_search.py, profiles/r04_shallow_shape_search.txt) show one pattern, the Jacobi sweep's: FOUR waves
+    // per group and a row of a QUARTER GROUP SHORT OF OR PAST a multiple of 8 groups -- 31 / 33, 63 / 65, 95 / 97 tiles --
+    // first or within 1 % of first at every size, idle padding tiles included (8192^2: 74 tiles padded to 95 = 23.75 groups
+    // 0.808 ms, unpadded 0.89; 4096^2: 37 -> 63 tiles; exactly 8k groups per row is the worst shape: 1.11 ms).  So: the
+    // smallest such row length that holds the box.  (The 62-lane tile of rounds 1-3 liked eight waves just above 8k groups.)
     if (!tuning("j5_autoshape", 1) || tuning("j5_tpb", 0) || nxw < 16) {
         choose_block_shape(&nxw, &tpb);                  // experiments and thin boxes: the shared path
     } else {
-        double best = 1e9;
-        int pad = 0;
-        for (int cand : {8, 4, 2}) {
-            const int period = 8 * cand, slack = 3 * cand / 8;
-            if (nxw < period) continue;
-            const int r = nxw % period, p = r <= slack ? 0 : period - r;
-            const double cost = (double)p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : 0.03);
-            if (cost < best) { best = cost; tpb = cand; pad = p; }
-        }
-        if (best > 0.25) { tpb = 4; pad = 0; }
-        nxw += pad;
-        if (nxw >= 128 && nxw % (8 * tpb) == 0) nxw += 1;
+        tpb = 4;
+        const int below = (nxw + 1 + 31) / 32 * 32 - 1;  // smallest 32k - 1 >= nxw
+        const int above = (nxw - 1 + 31) / 32 * 32 + 1;  // smallest 32k + 1 >= nxw
+        nxw = below < above ? below : above;
     }
     *nxw_out = nxw;
     *tpb_out = tpb;
@@ -1019,7 +1021,7 @@ static int shallow_autotune(bool sw_offset, const dlesm_sw_params *q, int ld, in
     }
     if (xstop < xstart || ystop < ystart || tuning("sw_kernel", 0) != 0) return DLESM_OK;
     const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
-    const int nxw0 = (x1 / 2 - sw_first_chunk(x0) + 62) / 62;
+    const int nxw0 = (x1 / 2 - sw_first_chunk(x0) + SW_OUT_LANES) / SW_OUT_LANES;
     if (nxw0 < 16 || tuning("sw_tile_rows", 2) != 2) return DLESM_OK;      // thin boxes: nothing to choose
     hipStream_t s = (hipStream_t)stream;
     std::vector<SwShape> cand;

@@ -11,9 +11,9 @@
 // tree of the single step, operand for operand (the first stage evaluated redundantly on the one-cell rim of the tile, as
 // temporal blocking always does), so the two levels are bit-identical to two calls of dlesm_shallow_step_f64.
 //
-// Wave tile: 62 output lanes x 2 doubles x R rows, as shallow_tile.  A lane holds two columns, so the ONE halo lane per side
-// the single step needs already covers the two columns two steps need: stage 1 is valid on columns 1 .. 126 of the wave's
-// 128, stage 2 on the 124 columns of lanes 1 .. 62.  Vertically the tile loads rows jb-2 .. jb+R+1 of level n and rows
+// Wave tile: 62 (or 56, template parameter HL) output lanes x 2 doubles x R rows.  A lane holds two columns, so the ONE halo lane
+// per side the single step needs already covers the two columns two steps need: stage 1 is valid on columns 1 .. 126 of the
+// wave's 128, stage 2 on the 124 columns of lanes 1 .. 62.  Vertically the tile loads rows jb-2 .. jb+R+1 of level n and rows
 // jb-1 .. jb+R of level n-1.  Cells of level n+1 that lie OUTSIDE the box (the fixed boundary ring of a non-periodic model)
 // are not computed: they are what the level-n+1 arrays hold there, loaded by the tiles that touch the edge of the box only.
 //
@@ -166,10 +166,14 @@ struct X2Arrays {
 // costs no halo.  The ring of level n+1 is then taken from level n (u, v, p): a non-periodic model keeps the same fixed
 // boundary values at every time level, and no array holds an unfiltered level n+1 to read it from.
 // WPE: the occupancy (waves per SIMD) the register allocator is held to -- __launch_bounds__(256) alone only promises one.
-template <int R, int NTM, bool SM = false, int WPE = 1>
+// HL: lanes per side that only feed their neighbours.  One is all two steps need; with four the 112 output columns of a tile are
+// seven whole 128-byte lines of the six arrays written (dlesm_shallow.hip) -- that pays for the four-row plain form (1.253 ->
+// 1.208 ms at 8192^2) and costs the two-row forms 3-4 % (twice the tiles, twice the extra lanes loaded), which keep one.
+template <int R, int NTM, bool SM = false, int WPE = 1, int HL = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void shallow_tile_x2(dlesm_sw_params q, int ld, int ny, int x0, int x1, int y0, int y1, int cb, int nxw,
                                                        int stack, X2Arrays a, double alpha)
 {
+    constexpr int X2_HALO_LANES = HL, X2_OUT_LANES = 64 - 2 * HL;
     const int lane = threadIdx.x & 63;
     int xw, strip;
     if (stack) {      // the waves of a workgroup are VERTICALLY adjacent tiles: the rows two of them share are requested by one CU
@@ -182,11 +186,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
     const int jb = y0 + strip * R;
     if (jb > y1) return;
     const int je = jb + R - 1 < y1 ? jb + R - 1 : y1;
-    const int c = cb + xw * 62 - 1 + lane;             // this lane's chunk (2 columns)
-    if (c - lane + 1 > x1 / 2) return;                 // idle padding tile
+    const int c = cb + xw * X2_OUT_LANES - X2_HALO_LANES + lane;             // this lane's chunk (2 columns)
+    if (c - lane + X2_HALO_LANES > x1 / 2) return;                 // idle padding tile
     const int c_ld = ld / 2 - 1;
     const int cl = c < 0 ? 0 : (c > c_ld ? c_ld : c);  // halo / trailing lanes: any valid chunk
-    const bool out_lane = lane >= 1 && lane <= 62 && c <= c_ld;
+    const bool out_lane = lane >= X2_HALO_LANES && lane < 64 - X2_HALO_LANES && c <= c_ld;
     const bool m0 = out_lane && 2 * c >= x0 && 2 * c <= x1;
     const bool m1 = out_lane && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
     const size_t col = (size_t)cl * 2;
@@ -285,16 +289,17 @@ template <int R, int NTM, bool SM, int WPE = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void shallow_tile_sw_x2(dlesm_sw_params q, int ld, int ny, int x0, int x1, int y0, int y1, int cb, int nxw,
                                                           X2Arrays a, double alpha)
 {
+    constexpr int X2_HALO_LANES = 1, X2_OUT_LANES = 62;
     const int lane = threadIdx.x & 63;
     const int xw = blockIdx.x % nxw;                     // (four vertically adjacent tiles per workgroup, as shallow_tile_x2)
     const int strip = (blockIdx.x / nxw) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int jb = y0 + strip * R;
     if (jb > y1) return;
     const int je = jb + R - 1 < y1 ? jb + R - 1 : y1;
-    const int c = cb + xw * 62 - 1 + lane;
-    if (c - lane + 1 > x1 / 2) return;
+    const int c = cb + xw * X2_OUT_LANES - X2_HALO_LANES + lane;
+    if (c - lane + X2_HALO_LANES > x1 / 2) return;
     const int Lx = x1 - x0 + 1, Ly = y1 - y0 + 1;
-    const bool out_lane = lane >= 1 && lane <= 62;
+    const bool out_lane = lane >= X2_HALO_LANES && lane < 64 - X2_HALO_LANES;
     const bool m0 = out_lane && 2 * c >= x0 && 2 * c <= x1;
     const bool m1 = out_lane && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
     // this lane's two columns, from where they are the periodic image of when they lie wholly beyond the halo
@@ -404,7 +409,8 @@ static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int 
         stack = tuning("sw_x2_stack", 4);
         pad = tuning("sw_x2_pad", 0);
     }
-    int nxw = (x1 / 2 - cb + 62) / 62, tpb = 4;
+    const int out_lanes = (!alpha && R == 4) ? 56 : 62;      // (the four-row plain form: whole-line tiles, HL = 4)
+    int nxw = (x1 / 2 - cb + out_lanes) / out_lanes, tpb = 4;
     if (stack) {
         nxw += pad;
         tpb = stack == 2 ? 2 : 4;
@@ -418,7 +424,7 @@ static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int 
 #define DLESM_X2(RR, NN)                                                                                                                                  \
     do {                                                                                                                                                  \
         if (alpha) hipLaunchKernelGGL((shallow_tile_x2<RR, NN, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al); \
-        else hipLaunchKernelGGL((shallow_tile_x2<RR, NN, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);    \
+        else hipLaunchKernelGGL((shallow_tile_x2<RR, NN, false, 1, (RR == 4 ? 4 : 1)>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al); \
     } while (0)
 #ifdef DLESM_LAB
 #define DLESM_X2R(RR)                                                                                                  \
@@ -431,7 +437,7 @@ static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int 
 #else
     (void)nt;
     if (alpha) hipLaunchKernelGGL((shallow_tile_x2<2, 6, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
-    else hipLaunchKernelGGL((shallow_tile_x2<4, 2, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
+    else hipLaunchKernelGGL((shallow_tile_x2<4, 2, false, 1, 4>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
 #endif
 #undef DLESM_X2
 }
