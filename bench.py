@@ -650,7 +650,7 @@ def shallow_water_smooth(D, torch, stream, g, F, prm, tile, steps, alpha=0.001):
               "ms_per_launch": round(ms2, 5), "ms_per_step": round(ms2 / 2, 5),
               "roofline": {"bound": "hbm", "achieved": round(g2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g2 / HBM_PEAK_GBS, 4),
                            "algorithmic_bytes_per_cell_per_launch": 96, "algorithmic_bytes_per_cell_per_step": 48,
-                           "kernel": "shallow_tile_x2<2,6,smooth> (two-row tiles, every load issued first, four vertically adjacent tiles per workgroup)"},
+                           "kernel": "shallow_tile_x2<3,2,smooth> (three-row tiles held to two waves per SIMD, four vertically adjacent tiles per workgroup)"},
               "bit_identical_to_two_one_launch_filtered_steps": bool(same2),
               "speedup_per_step_vs_one_launch_filtered_step": round(2 * res["one_launch"] / ms2, 3),
               "speedup_per_step_vs_step_plus_three_time_smooth": round(2 * res["step_plus_three_time_smooth"] / ms2, 3)}
@@ -827,7 +827,7 @@ def shallow_water_periodic(D, torch, stream, alignment, tile, steps):
                                      "value": round(2 * cells / (res["two"] * 1e-3) / 1e6, 1), "unit": "Mcells/s",
                                      "algorithmic_bytes_per_cell_per_step": 48,
                                      "frac": round(96 * cells / (res["two"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     "kernel": "shallow_tile_sw_x2<2,6,smooth>",
+                                     "kernel": "shallow_tile_sw_x2<3,2,smooth> (three-row tiles held to two waves per SIMD)",
                                      "bit_identical_to_two_one_launch_steps_fields_and_halos": bool(same2),
                                      "speedup_per_step": round(2 * res["one"] / res["two"], 3)}}
         del ex

@@ -398,14 +398,15 @@ static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int 
     // 2048^2 .. 6144^2 and 12288^2, profiles/r04_shallow_x2.txt); new levels stored
     // non-temporally, level n-1 loaded with the default policy (its halo rows ARE re-read; non-temporal: 1.47 ms).
     // sw_x2_rows / _nt / _stack / _pad select the comparison forms (lab build).
-    // The filtered form keeps level n-1 live through the first stage (the filter needs it again) and does not fit four-row
-    // tiles into 256 VGPRs (spills to AGPRs at one wave per SIMD: 2.34 ms); two-row tiles with every load issued first:
-    // 1.33 ms per two filtered steps against 2 x 1.19 ms for two one-launch filtered steps (same box).
-    int R = alpha ? 2 : 4, nt = alpha ? 6 : 2, stack = 4, pad = 0;
+    // The filtered form, THREE-row tiles held to two waves per SIMD (256 registers, no scratch): 1.26-1.27 ms against 1.31-1.33
+    // for two-row tiles with every load issued first (210 registers) on the same box -- fewer rows of level n requested per row
+    // written ((R+4)/R: 2.33 against 3).  Four-row tiles do not fit: capped 164-336 B of scratch, uncapped one wave per SIMD,
+    // also with the rows of level n-1 the filter needs loaded a second time instead of kept live.
+    int R = alpha ? 3 : 4, nt = 2, stack = 4, pad = 0;
     if (kLab) {
-        R = tuning("sw_x2_rows", R);
-        if (R != 2 && R != 6) R = 4;
-        nt = tuning("sw_x2_nt", nt) & 7;
+        const int rows = tuning("sw_x2_rows", 0);        // (0: the product's height for the form)
+        if (rows == 2 || rows == 4 || rows == 6 || (rows == 3 && alpha)) R = rows;
+        nt = tuning("sw_x2_nt", R == 2 && alpha ? 6 : nt) & 7;
         stack = tuning("sw_x2_stack", 4);
         pad = tuning("sw_x2_pad", 0);
     }
@@ -432,11 +433,12 @@ static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int 
     case 0: DLESM_X2(RR, 0); break; case 3: DLESM_X2(RR, 3); break; case 4: DLESM_X2(RR, 4); break;                   \
     case 6: DLESM_X2(RR, 6); break; case 7: DLESM_X2(RR, 7); break; default: DLESM_X2(RR, 2); break;                  \
     }
-    if (R == 2) { DLESM_X2R(2) } else if (R == 6) { DLESM_X2R(6) } else { DLESM_X2R(4) }
+    if (R == 3) hipLaunchKernelGGL((shallow_tile_x2<3, 2, true, 2>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
+    else if (R == 2) { DLESM_X2R(2) } else if (R == 6) { DLESM_X2R(6) } else { DLESM_X2R(4) }
 #undef DLESM_X2R
 #else
     (void)nt;
-    if (alpha) hipLaunchKernelGGL((shallow_tile_x2<2, 6, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
+    if (alpha) hipLaunchKernelGGL((shallow_tile_x2<3, 2, true, 2>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
     else hipLaunchKernelGGL((shallow_tile_x2<4, 2, false, 1, 4>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
 #endif
 #undef DLESM_X2
@@ -453,11 +455,17 @@ static void launch_sw_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, i
     // SIMD) the allocator takes 260 registers for two-row and 346 for four-row tiles -- one wave per SIMD, 1.555 ms per launch at
     // 8192^2; capped at 256: 1.357 ms (four-row tiles capped: 320 B of scratch, 2.06 ms).  sw_x2_sw_form = 1 (lab): the uncapped
     // four-row form.
-    const int form = kLab && !alpha ? tuning("sw_x2_sw_form", 0) : 0;
-    const int R = form == 1 ? 4 : 2;
+    // filtered form: three-row tiles at two waves per SIMD (248 registers), 1.30-1.33 ms against 1.38-1.39 for two-row tiles
+    // (sw_x2_sw_form = 1 in the lab build: the two-row form)
+    const int form = kLab ? tuning("sw_x2_sw_form", 0) : 0;
+    const int R = alpha ? (form == 1 ? 2 : 3) : (form == 1 ? 4 : 2);
     const int strips = (y1 - y0 + R) / R;
     const unsigned grid = (unsigned)((long)nxw * ((strips + tpb - 1) / tpb));
-    if (alpha) hipLaunchKernelGGL((shallow_tile_sw_x2<2, 6, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, a, *alpha);
+#ifdef DLESM_LAB
+    if (alpha && form == 1) hipLaunchKernelGGL((shallow_tile_sw_x2<2, 6, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, a, *alpha);
+    else
+#endif
+    if (alpha) hipLaunchKernelGGL((shallow_tile_sw_x2<3, 2, true, 2>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, a, *alpha);
 #ifdef DLESM_LAB
     else if (form == 1) hipLaunchKernelGGL((shallow_tile_sw_x2<4, 2, false>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, a, 0.0);
 #endif

@@ -26,9 +26,9 @@ def pytest_configure(config):
 LAB_RUN = os.path.basename(os.environ.get("DLESM_HIP_LIB", "")) == "libdlesm_hip_lab.so"
 _LAB_DEFAULTS = {"j5_kernel": 0, "j5_rows": 0, "j5_unroll": 4, "j5xt_rows": 0, "j5xt_dpp": 1, "j5xt_march": 0,
                  "j5xt_march_ring": 9, "j5xt_march_slots": 3072, "j5xt_march_perm": 1, "sw_tile_rows": 2, "sw_dpp": 1,
-                 "sw_stack": 1, "sw_dm_diag": 0, "dm_event_system_fence": 0, "sw_x2_rows": 4, "sw_x2_nt": 2, "sw_x2_stack": 4,
+                 "sw_stack": 1, "sw_dm_diag": 0, "dm_event_system_fence": 0, "sw_x2_rows": 0, "sw_x2_nt": 2, "sw_x2_stack": 4,
                  "sw_x2_pad": 0, "sw_x2_sw_form": 0}
-_PARAM_KEYS = {"sw_rows": "sw_tile_rows", "sw_dpp": "sw_dpp", "sw_nt": "sw_nt", "march": "j5xt_march", "stack": "sw_stack"}
+_PARAM_KEYS = {"sw_rows": "sw_tile_rows", "sw_dpp": "sw_dpp", "sw_nt": "sw_nt", "march": "j5xt_march", "stack": "sw_stack", "x2_rows": "sw_x2_rows"}
 
 
 def needs_lab(tune):

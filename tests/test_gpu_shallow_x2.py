@@ -71,7 +71,7 @@ CASES = [(5, 4, None), (5, 4, 2), (1, 1, 2), (2, 1, 2), (1, 3, 2), (64, 48, 8), 
 
 TUNES = [dict(), dict(sw_x2_stack=0), dict(sw_x2_rows=2, sw_x2_nt=7), dict(sw_x2_rows=6, sw_x2_nt=6, sw_x2_stack=8), dict(sw_x2_nt=3, sw_x2_stack=2, sw_x2_pad=3),
          dict(sw_x2_rows=2, sw_x2_nt=0, sw_x2_stack=0)]      # (all but the first: comparison forms, libdlesm_hip_lab.so)
-X2_DEFAULTS = dict(sw_x2_rows=4, sw_x2_nt=2, sw_x2_stack=4, sw_x2_pad=0)
+X2_DEFAULTS = dict(sw_x2_rows=0, sw_x2_nt=2, sw_x2_stack=4, sw_x2_pad=0)
 
 
 @pytest.mark.parametrize("tune", TUNES, ids=lambda t: "-".join(f"{k[6:]}{v}" for k, v in t.items()) or "default")
@@ -181,8 +181,8 @@ def test_full_size_equals_two_single_steps(D):
 
 # ---- with the Asselin filter after each step: two whole time steps of the GOcean loop per launch --------------------------------
 @pytest.mark.parametrize("nx,ny,alignment", [(5, 4, None), (64, 48, 8), (127, 9, None), (257, 129, None), (300, 70, 64), (1000, 37, 64), (2100, 33, 64)])
-@pytest.mark.parametrize("fallback", [False, True])
-def test_two_filtered_steps_per_launch(D, nx, ny, alignment, fallback):
+@pytest.mark.parametrize("fallback,x2_rows", [(False, 0), (True, 0), (False, 2), (False, 4)])   # (rows 2 / 4: the lab build's tile heights)
+def test_two_filtered_steps_per_launch(D, nx, ny, alignment, fallback, x2_rows):
     """dlesm_shallow_step_smooth_x2_f64 against the one-launch filtered step applied twice with the loop's rotation (itself checked
     against the oracle's loop nests in tests/test_gpu_shallow_kernels.py), and a longer ping-pong loop against that loop"""
     import torch
@@ -196,6 +196,8 @@ def test_two_filtered_steps_per_launch(D, nx, ny, alignment, fallback):
         D.copy_field(src, dst)
     b_cur, b_old, b_new = ([B[n] for n in NAMES[k:k + 3]] for k in (0, 3, 6))
     L.dlesm_set_tuning(b"sw_x2_fused", 0 if fallback else 1)
+    if x2_rows:
+        L.dlesm_set_tuning(b"sw_x2_rows", x2_rows)
     try:
         for pair in range(3):
             keep = [f.data.clone() for f in a_cur + a_old]
@@ -213,6 +215,8 @@ def test_two_filtered_steps_per_launch(D, nx, ny, alignment, fallback):
                 assert torch.equal(cut(x), cut(y)), (pair, int((cut(x) != cut(y)).sum()))
     finally:
         L.dlesm_set_tuning(b"sw_x2_fused", 1)
+        if x2_rows:
+            L.dlesm_set_tuning(b"sw_x2_rows", 0)
 
 
 # ---- the SW-offset, doubly periodic model (the GOcean `shallow` benchmark's configuration) --------------------------------------
@@ -307,6 +311,17 @@ def test_two_periodic_steps_four_row_tiles(D, nx, ny, alignment):
 @pytest.mark.parametrize("nx,ny,alignment", [(2, 2, None), (10, 10, None), (9, 7, 2), (64, 48, 8), (63, 49, None), (257, 129, None), (300, 77, None),
                                              (1021, 33, 64), (130, 260, 64)])
 def test_two_filtered_periodic_steps_per_launch(D, nx, ny, alignment, fallback):
+    _filtered_periodic(D, nx, ny, alignment, fallback, 0)
+
+
+@pytest.mark.lab
+@pytest.mark.parametrize("nx,ny,alignment", [(10, 10, None), (63, 49, None), (257, 129, None), (1021, 33, 64), (130, 260, 64)])
+def test_two_filtered_periodic_steps_two_row_tiles(D, nx, ny, alignment):
+    """the comparison form of the filtered periodic kernel (two-row tiles, every load issued first: lab build)"""
+    _filtered_periodic(D, nx, ny, alignment, False, 1)
+
+
+def _filtered_periodic(D, nx, ny, alignment, fallback, sw_form):
     """dlesm_shallow_step_sw_smooth_x2_periodic_f64 -- two whole time steps of the GOcean `shallow` loop per launch -- against the
     one-launch filtered periodic step applied twice with the loop's rotation (itself checked against the oracle's loop nests,
     tests/test_gpu_shallow_kernels.py), three double steps in a row: internal region and halos of both levels"""
@@ -321,6 +336,8 @@ def test_two_filtered_periodic_steps_per_launch(D, nx, ny, alignment, fallback):
     b_cur, b_old, b_new = ([B[n] for n in NAMES[k:k + 3]] for k in (0, 3, 6))
     cut = lambda f: f.data[:it.ystop + 1, :it.xstop + 1]      # noqa: E731
     L.dlesm_set_tuning(b"sw_x2_fused", 0 if fallback else 1)
+    if sw_form:
+        L.dlesm_set_tuning(b"sw_x2_sw_form", sw_form)
     try:
         for pair in range(3):
             D.psy.invoke_shallow_step_sw_smooth_x2_periodic(prm, alpha, *a_cur, *a_old, *a_n2, *a_o2)
@@ -333,3 +350,5 @@ def test_two_filtered_periodic_steps_per_launch(D, nx, ny, alignment, fallback):
                 assert torch.equal(cut(x), cut(y)), (pair, int((cut(x) != cut(y)).sum()), (cut(x) != cut(y)).nonzero()[:6].tolist())
     finally:
         L.dlesm_set_tuning(b"sw_x2_fused", 1)
+        if sw_form:
+            L.dlesm_set_tuning(b"sw_x2_sw_form", 0)
