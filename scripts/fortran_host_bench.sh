@@ -17,8 +17,8 @@ for cfg in "4096 2000" "8192 800" "16384 400"; do
         done
     done
 done
-echo "# shallow_app.exe N NSTEPS MODE : 0 = fused one-launch periodic step, 1 = the seven GOcean kernels one by one (+ periodic copies), 2 = 1 + time_smooth, 3 = one launch per step incl. time_smooth"
-for mode in 0 1 2 3; do
+echo "# shallow_app.exe N NSTEPS MODE : 0 = fused one-launch periodic step, 1 = the seven GOcean kernels one by one (+ periodic copies), 2 = 1 + time_smooth, 3 = one launch per step incl. time_smooth, 4 = one launch per TWO steps incl. time_smooth"
+for mode in 0 1 2 3 4; do
     for rep in 1 2; do
         echo -n "shallow_app 8192^2 steps=200 mode=$mode run=$rep : "
         timeout -k 10 200 $B/shallow_app.exe 8192 200 $mode 2>&1 | grep -E "Mcells" | tr -s ' '
