@@ -77,6 +77,13 @@ struct SwSmooth {
 [[maybe_unused]] __device__ __forceinline__ V2 pin_here(const V2 &a) { return V2{::dlesm::pin_here(a.x), ::dlesm::pin_here(a.y)}; }   // dlesm_internal.h
 // new time level stored non-temporally by default: +1.2 % at 8192^2 (profiles/r02_shallow_variants.txt)
 #define SW_NT_DEFAULT 2
+// ... unless the nine arrays of the step fit the 256 MB Infinity Cache together: a store that bypasses it takes the next step's
+// input away (the Jacobi sweep's finding at 4096^2, nt_stores_for).  Measured with the round-4 tile, rule shapes, time-loop
+// rotation: 1024^2 (80 MB) 0.0153 ms cached against 0.0165; 1536^2 (177 MB) 0.0296 / 0.0301; 2048^2 (312 MB) 0.0537 / 0.0510.
+static inline int sw_nt_default(int ld, int y0, int y1)
+{
+    return 9.0 * 8.0 * (double)ld * (double)(y1 - y0 + 3) <= 200.0e6 ? 0 : SW_NT_DEFAULT;
+}
 
 // NTM bit 0: the old time level (read exactly once, by one lane) is loaded non-temporally;
 // bit 1: the new time level is stored non-temporally.  u, v, p keep the default policy: their
@@ -602,7 +609,7 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
                          double *pnew, hipStream_t s, bool sw_offset, SwFrameJob *fj, int wrap, const double *smooth_alpha)
 {
     const int cb = sw_first_chunk(x0);
-    int nxw, tpb, ntm = tuning("sw_nt", SW_NT_DEFAULT) & (kLab ? 15 : 3);      // (bits 4, 8: experiments, lab build only)
+    int nxw, tpb, ntm = tuning("sw_nt", sw_nt_default(ld, y0, y1)) & (kLab ? 15 : 3);      // (bits 4, 8: experiments, lab build only)
     SwSmooth sm{0.0, nullptr, nullptr, nullptr};
     if (smooth_alpha) sm = SwSmooth{*smooth_alpha, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold)};
     {
@@ -1033,7 +1040,7 @@ static int shallow_autotune(bool sw_offset, const dlesm_sw_params *q, int ld, in
     int rn, rt;
     sw_rule_shape(ld, x0, x1, &rn, &rt);
     if (rt > 8) rt = 8;
-    const int nt0 = tuning("sw_nt", SW_NT_DEFAULT) & 3;
+    const int nt0 = tuning("sw_nt", sw_nt_default(ld, y0, y1)) & 3;
     add(rt, rn, nt0);                                                      // the rule's own choice first
     for (int tpb : {8, 4}) {
         add(tpb, nxw0, nt0);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """experiment: exhaustive search over (waves per workgroup, idle padding tiles per row) for the
-Jacobi-5 tile sweep at one size, to refit choose_block_shape():  scripts/shape_search.py N [A [T]]
-(T > 1: the fused T-step kernel instead of the single-step one)"""
+Jacobi-5 tile sweep at one size, to refit choose_block_shape():  scripts/shape_search.py N [A [T [ROWS]]]
+(T > 1: the fused T-step kernel instead of the single-step one; ROWS: rows per wave tile of the single-step sweep, 2 or 3)"""
 import ctypes as C
 import os
 import sys
@@ -27,6 +27,8 @@ sp = C.c_void_p(s.cuda_stream)
 D.psy.hash_init(a, 1, stream=s)
 D.copy_field(a, b, stream=s)
 FUSED = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+if len(sys.argv) > 4:
+    L.dlesm_set_tuning(b"j5_tile_rows", int(sys.argv[4]))
 OL = 64 - 2 * ((FUSED + 1) // 2) if FUSED > 1 else 64
 base = (box[1] // 2 - 0 + OL) // OL          # wave tiles per row, tile origin at chunk 0 (x0 = 1)
 
