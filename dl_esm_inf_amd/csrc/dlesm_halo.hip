@@ -1419,7 +1419,7 @@ extern "C" int dlesm_jacobi5_multi_step_dm(dlesm_halo_plan *p, const double *in,
     // From 7 steps per launch the T-deep frame costs more as four thin launches than the exchange it would hide:
     // measured in loop-back at 8 steps, whole box then exchange 0.3024 / 1.0175 ms (8192^2 / 16384^2) against
     // 0.3116 / 1.0188 overlapped; at 4 steps the overlapped form wins (0.2340 / 0.8013 against 0.2468 / 0.8338).
-    const bool serial = T >= tuning("j5xt_dm_serial_from", 7);
+    const bool serial = T >= 7;
     if (serial || ix1 < ix0 || iy1 < iy0) { // ... or the tile is all frame: no interior to hide the exchange behind
         if (int rc = box(xstart, xstop, ystart, ystop)) return rc;
         return exchange_on(p, out, DLESM_DIRS_ALL, s);

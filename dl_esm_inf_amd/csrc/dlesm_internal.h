@@ -40,6 +40,9 @@ constexpr bool kLab = true;
 #else
 constexpr bool kLab = false;
 #endif
+// boxes of the shallow-water sweeps this many columns wide or narrower (the west / east frame columns of a distributed step)
+// take the one-cell-per-thread form: a wave tile would load 128 columns for them
+constexpr int SW_THIN_BOX = 8;
 // the process-wide pinned word a device-side wait raises when it gives up (checked by every device entry point)
 int *wait_timed_out_word();
 // forget what streams_run_concurrently has measured (a time-out was acknowledged, the runtime was finalised)

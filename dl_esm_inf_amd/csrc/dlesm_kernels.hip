@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void jacobi5_frame(const double *__restrict__ 
 // sweeps at 16384^2, nothing lost elsewhere (scripts/shape_share_probe.py); without a plan, the rule.
 void shape_for_tile_sweep(int ld, int x0, int x1, int y0, int y1, int *nxw_io, int *tpb_out)
 {
-    if (tuning("j5_autoshape", 1) && tuning("j5_use_tuned", 1) && tuning("j5_share_plan", 1) && !tuning("j5_tpb", 0)) {
+    if (tuning("j5_autoshape", 1) && tuning("j5_use_tuned", 1) && !tuning("j5_tpb", 0)) {
         std::lock_guard<std::mutex> lk(g_shape_mu);
         auto it = g_shape_cache.find(ShapeKey{ld, x0, x1, y0, y1, 2});
         if (it != g_shape_cache.end() && it->second.nxw >= *nxw_io) {
@@ -1707,7 +1707,7 @@ extern "C" int dlesm_stencil5_autotune_f64(const double *in, double *out, int ld
     }
     // tile heights: 2 rows (the default) and 3 -- at 4096^2 with a 33280-byte row pitch 3 rows measured 3-4 %
     // faster, at 16384^2 2 rows; only the 16-byte-lane form, and only when the caller has not fixed it
-    const bool try_rows = vec2 && tuning("j5_tile_rows", 0) < 1 && tuning("j5_tune_rows", 1);
+    const bool try_rows = vec2 && tuning("j5_tile_rows", 0) < 1;
     for (int rows : {0, 3}) {
         if (rows && !try_rows) continue;
         for (int tpb : {8, 4}) {
@@ -1799,7 +1799,7 @@ extern "C" int dlesm_shallow_step_f64(const dlesm_sw_params *q, int ld, int ny, 
     // 8192^2; 1 = direct form, 62 % (scripts/shallow_probe.py, profiles/r01_shallow_*.txt)
     // boxes a few columns wide (the west/east frame columns of the distributed step): a wave tile would load
     // 128 columns x 4 rows of three arrays for two useful cells -- one cell per thread moves 6 x less
-    const bool thin = nx <= tuning("sw_thin_box", 8) && nyb > 8;
+    const bool thin = nx <= SW_THIN_BOX && nyb > 8;
     if (aligned && tuning("sw_kernel", 0) == 0 && !thin) {
         launch_shallow_tile(*q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold,
                             unew, vnew, pnew, (hipStream_t)stream);

@@ -53,20 +53,18 @@ static const struct { const char *key; int cls; } kKeys[] = {
     {"dm_safe", KEY_USER}, {"dm_wait_seconds", KEY_USER}, {"dm_peer", KEY_USER}, {"dm_peer_exchange", KEY_USER},
     {"mailbox_fences", KEY_USER}, {"mailbox_fields", KEY_USER}, {"mailbox_gather_host", KEY_USER}, {"dm_acquire", KEY_USER},
     {"j5_dm_corners", KEY_USER}, {"j5_nt_stores", KEY_USER}, {"j5_use_tuned", KEY_USER}, {"side_stream_priority", KEY_USER},
-    {"dm_graph_force", KEY_USER},
+    {"dm_graph_force", KEY_USER}, {"mailbox_finegrained", KEY_USER},
     // ---- HOOK: launch shapes the planning calls choose from
-    {"j5_tpb", KEY_HOOK}, {"j5_pad_tiles", KEY_HOOK}, {"j5_autoshape", KEY_HOOK}, {"j5_skew", KEY_HOOK}, {"j5_tile_rows", KEY_HOOK},
-    {"j5_tune_rows", KEY_HOOK}, {"j5_share_plan", KEY_HOOK}, {"sw_nt", KEY_HOOK}, {"swk_nt", KEY_HOOK}, {"swk_ntl", KEY_HOOK},
+    {"j5_tpb", KEY_HOOK}, {"j5_pad_tiles", KEY_HOOK}, {"j5_autoshape", KEY_HOOK}, {"j5_skew", KEY_HOOK}, {"j5_tile_rows", KEY_HOOK}, {"sw_nt", KEY_HOOK}, {"swk_nt", KEY_HOOK}, {"swk_ntl", KEY_HOOK},
     {"cont_nt", KEY_HOOK}, {"sw_smooth_ntl", KEY_HOOK},
     // ---- HOOK: fall-back kernels (unaligned bases, odd pitches, thin boxes) and the forms DLESM_DM_SAFE / a capture select
     {"j5_variant", KEY_HOOK}, {"sw_kernel", KEY_HOOK}, {"swk_kernel", KEY_HOOK}, {"s9_kernel", KEY_HOOK}, {"j5m_kernel", KEY_HOOK},
-    {"cont_kernel", KEY_HOOK}, {"sw_thin_box", KEY_HOOK}, {"sw_wrap_fused", KEY_HOOK}, {"sw_smooth_fused", KEY_HOOK},
+    {"cont_kernel", KEY_HOOK}, {"sw_wrap_fused", KEY_HOOK}, {"sw_smooth_fused", KEY_HOOK},
     {"sw_x2_fused", KEY_HOOK},
     {"util_rowseg", KEY_HOOK}, {"util_rowlinear", KEY_HOOK}, {"util_gather_linear", KEY_HOOK},
     {"j5_dm_fused", KEY_HOOK}, {"sw_dm_fused", KEY_HOOK}, {"s9_dm_fused", KEY_HOOK}, {"j5_dm_chain", KEY_HOOK}, {"sw_dm_chain", KEY_HOOK},
     {"j5_dm_lazy_unpack", KEY_HOOK}, {"j5_dm_frame_pack", KEY_HOOK}, {"dm_flag_join", KEY_HOOK}, {"dm_aggregate", KEY_HOOK},
-    {"dm_aggregate_single", KEY_HOOK}, {"dm_peer_one_launch", KEY_HOOK}, {"dm_peer_join_fused", KEY_HOOK},
-    {"mailbox_finegrained", KEY_HOOK}, {"j5xt_dm_serial_from", KEY_HOOK}, {"dm_inject_timeout", KEY_HOOK},
+    {"dm_aggregate_single", KEY_HOOK}, {"dm_peer_one_launch", KEY_HOOK}, {"dm_peer_join_fused", KEY_HOOK}, {"dm_inject_timeout", KEY_HOOK},
     // (tests only: sw_dm_frame = 0 is the ring as four thin boxes of the plain step, no kernel of its own; dm_skip_parts
     //  switches parts of an RCCL exchange OFF -- results then come from the mailboxes or are wrong by design)
     {"sw_dm_frame", KEY_HOOK}, {"dm_skip_parts", KEY_HOOK},

@@ -904,7 +904,7 @@ extern "C" int dlesm_shallow_step_smooth_f64(const dlesm_sw_params *q, double al
     if (int rc = check_box("dlesm_shallow_step_smooth_f64", ld, ny, xstart, xstop, ystart, ystop, 1)) return rc;
     if (int rc = nine_distinct("dlesm_shallow_step_smooth_f64", u, v, p, uold, vold, pold, unew, vnew, pnew)) return rc;
     const int nx = xstop - xstart + 1, nyb = ystop - ystart + 1;
-    const bool thin = nx <= tuning("sw_thin_box", 8) && nyb > 8;
+    const bool thin = nx <= SW_THIN_BOX && nyb > 8;
     if (nine_aligned(ld, xstop, u, v, p, uold, vold, pold, unew, vnew, pnew) && tuning("sw_kernel", 0) == 0 && !thin &&
         tuning("sw_smooth_fused", 1)) {
         launch_shallow_tile(*q, ld, xstart - 1, xstop - 1, ystart - 1, ystop - 1, u, v, p, uold, vold, pold, unew, vnew, pnew,

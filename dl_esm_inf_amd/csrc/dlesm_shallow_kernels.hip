@@ -326,7 +326,7 @@ int launch_kernel(const char *who, const KArgs &a, int ld, int ny, int xstart, i
     aligned = aligned && (uintptr_t)a.out % 16 == 0;
     for (int n = 0; n < K::NIN; n++) aligned = aligned && (uintptr_t)a.in[n] % 16 == 0;
     const int nx = x1 - x0 + 1, h = y1 - y0 + 1;
-    const bool thin = nx <= tuning("sw_thin_box", 8) && h > 8;
+    const bool thin = nx <= SW_THIN_BOX && h > 8;
     if (aligned && !thin && tuning("swk_kernel", 0) == 0) {
         constexpr int R = 2;
         const int cb = (x0 / 2) & ~7, c_last = x1 / 2;        // tiles anchored on 128-byte lines of the row

@@ -334,7 +334,9 @@ def test_shallow_model_with_time_smoothing_against_the_oracle(D, nx, ny, alignme
     assert np.all(np.isfinite(H[cur[2]][ys - 1:ye, xs - 1:xe]))
 
 
-@pytest.mark.parametrize("sw_kernel,sw_nt", [(0, 2), (0, 10), (0, 0), (1, 2)], ids=["tile", "tile-straight", "tile-cached", "direct"])
+# (sw_kernel -1: the one-launch ENTRIES taking their definition -- step, filter launches, periodic copies -- as they do by themselves
+#  for arrays that miss the wave-tile conditions: sw_smooth_fused = sw_wrap_fused = 0)
+@pytest.mark.parametrize("sw_kernel,sw_nt", [(0, 2), (0, 10), (0, 0), (1, 2), (-1, 2)], ids=["tile", "tile-straight", "tile-cached", "direct", "definition"])
 @pytest.mark.parametrize("nx,ny,alignment", [(10, 10, None), (37, 5, 2), (64, 48, 8), (300, 77, None), (1021, 33, 64), (130, 260, 64)])
 @pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW-periodic"])
 def test_step_with_the_filter_folded_in_equals_step_plus_time_smooth(D, nx, ny, alignment, sw_offset, sw_kernel, sw_nt):
@@ -344,8 +346,10 @@ def test_step_with_the_filter_folded_in_equals_step_plus_time_smooth(D, nx, ny, 
     and == the oracle's loop nests.  Three steps with the benchmark's rotation (u <- unew, uold keeps the filtered u)."""
     import torch
     L = D._cabi.lib()
-    L.dlesm_set_tuning(b"sw_kernel", sw_kernel)
+    L.dlesm_set_tuning(b"sw_kernel", max(sw_kernel, 0))
     L.dlesm_set_tuning(b"sw_nt", sw_nt)
+    L.dlesm_set_tuning(b"sw_smooth_fused", 0 if sw_kernel < 0 else 1)
+    L.dlesm_set_tuning(b"sw_wrap_fused", 0 if sw_kernel < 0 else 1)
     try:
         g = _grid(D, nx, ny, alignment, sw_offset)
         names, A = _state(D, g)
@@ -387,6 +391,8 @@ def test_step_with_the_filter_folded_in_equals_step_plus_time_smooth(D, nx, ny, 
     finally:
         L.dlesm_set_tuning(b"sw_kernel", 0)
         L.dlesm_set_tuning(b"sw_nt", 2)
+        L.dlesm_set_tuning(b"sw_smooth_fused", 1)
+        L.dlesm_set_tuning(b"sw_wrap_fused", 1)
 
 
 @pytest.mark.parametrize("sw_offset", [False, True], ids=["NE", "SW-periodic"])
