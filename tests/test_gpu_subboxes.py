@@ -49,6 +49,12 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _inbox(ny, ld, xs, xe, ys, ye):
+    m = np.zeros((ny, ld), dtype=bool)
+    m[ys - 1:ye, xs - 1:xe] = True
+    return m
+
+
 @pytest.mark.parametrize("case", _cases(40, 1), ids=lambda c: "x".join(map(str, c)))
 def test_two_and_three_stream_sweeps_on_subboxes(T, case):
     torch, D, L = T
@@ -102,3 +108,55 @@ def test_shallow_and_continuity_on_subboxes(T, case, sw_offset):
     O.continuity(0.37, ld, (xs, xe, ys, ye), *H, h6, h7, hs)
     torch.cuda.synchronize()
     assert np.array_equal(ds.cpu().numpy(), hs)
+
+
+@pytest.mark.parametrize("case", _cases(36, 3), ids=lambda c: "x".join(map(str, c)))
+def test_two_steps_per_launch_on_subboxes(T, case):
+    """dlesm_shallow_step_x2_f64 on an arbitrary box of arbitrary arrays == the oracle's step twice on that box (the second step
+    reads level n+1 one cell outside the box from where the level-n+1 arrays hold it); cells outside the box untouched"""
+    torch, D, L = T
+    ld, ny, xs, xe, ys, ye = case
+    if xs < 2 or ys < 2 or xe > ld - 1 or ye > ny - 1:
+        pytest.skip("no room for the stencil ring")
+    rng = np.random.default_rng(ld * 131 + ny)
+    H, Dv = zip(*[_rand(torch, rng, ny, ld, lo=(1.0 if k % 3 == 2 else -0.5)) for k in range(12)])
+    H = [h.copy() for h in H]
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 40.0)
+    D._cabi.check(L.dlesm_shallow_step_x2_f64(C.byref(prm), ld, ny, xs, xe, ys, ye, *[_ptr(t) for t in Dv], None))
+    box = (xs, xe, ys, ye)
+    O.sw_step(prm, ld, box, *H[:6], *H[6:9])
+    O.sw_step(prm, ld, box, *H[6:9], *H[:3], *H[9:])
+    torch.cuda.synchronize()
+    for k in range(12):
+        assert np.array_equal(Dv[k].cpu().numpy(), H[k]), k
+
+
+@pytest.mark.parametrize("case", _cases(30, 4), ids=lambda c: "x".join(map(str, c)))
+def test_two_filtered_steps_per_launch_on_subboxes(T, case):
+    """dlesm_shallow_step_smooth_x2_f64 on an arbitrary box: the wave-tile kernel against the entry's own definition (the path
+    arrays that miss the tile conditions take: two one-launch filtered steps through scratch copies), every array, every cell"""
+    torch, D, L = T
+    ld, ny, xs, xe, ys, ye = case
+    rng = np.random.default_rng(ld * 17 + ny)
+    H, A = zip(*[_rand(torch, rng, ny, ld, lo=(1.0 if k % 3 == 2 else -0.5)) for k in range(12)])
+    B = [t.clone() for t in A]
+    prm = D.psy.shallow_params(1.0e5, 1.0e5, 40.0)
+    D._cabi.check(L.dlesm_shallow_step_smooth_x2_f64(C.byref(prm), 0.001, ld, ny, xs, xe, ys, ye, *[_ptr(t) for t in A], None))
+    L.dlesm_set_tuning(b"sw_x2_fused", 0)
+    try:
+        D._cabi.check(L.dlesm_shallow_step_smooth_x2_f64(C.byref(prm), 0.001, ld, ny, xs, xe, ys, ye, *[_ptr(t) for t in B], None))
+    finally:
+        L.dlesm_set_tuning(b"sw_x2_fused", 1)
+    torch.cuda.synchronize()
+    for k in range(12):
+        if k < 6:
+            assert np.array_equal(A[k].cpu().numpy(), H[k]), ("input modified", k)
+        if k < 6:
+            continue
+        # the box is what both forms define (outside it the definition leaves a copy of the old level in uold2.., the kernel
+        # what was there: a time loop keeps every array's ring)
+        a, b = A[k][ys - 1:ye, xs - 1:xe], B[k][ys - 1:ye, xs - 1:xe]
+        assert torch.equal(a, b), (k, int((a != b).sum()))
+        if k < 9:      # level n+2 is written on the box only, by both
+            assert np.array_equal(np.where(_inbox(ny, ld, xs, xe, ys, ye), 0.0, A[k].cpu().numpy()),
+                                  np.where(_inbox(ny, ld, xs, xe, ys, ye), 0.0, H[k])), ("cells outside the box written", k)
