@@ -8,7 +8,7 @@
 // values only feed their neighbours through wave64 shuffles, so there are no scattered edge
 // loads and every cross-lane value -- raw (p, v east; u west) or derived (cu, z west; cv, h
 // east) -- is one shuffle away.  ONE halo lane per side is all the arithmetic needs; FOUR are
-// given up (SW_HALO_LANES) so that a tile's 112 output columns are seven WHOLE 128-byte lines
+// given up (sw_halo_lanes) when rows start on lines, so that a tile's 112 output columns are seven WHOLE 128-byte lines
 // of every array written: with 62 output lanes the tile edges fell inside a line (at 992-byte
 // steps) and two of every 8.75 lines stored per row were partial.  Measured at 8192^2, same
 // box, planned shapes (round 4): step 0.823 -> 0.808 ms, filtered step 1.18 -> 1.12 ms, the
@@ -35,8 +35,17 @@ namespace {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-constexpr int SW_HALO_LANES = 4;                         // lanes per side that only feed their neighbours
-constexpr int SW_OUT_LANES = 64 - 2 * SW_HALO_LANES;     // 56 chunks = 112 columns = 7 lines of 128 bytes
+// lanes per side that only feed their neighbours: 4 (56 output chunks = 112 columns = 7 whole lines of 128 bytes) when every
+// row of every array starts on a line -- an even pitch that is a multiple of 16 doubles, line-aligned bases: DL_ESM_ALIGNMENT a
+// multiple of 16 --, else 1 (62 output chunks): on an odd pitch (the reference's default alignment) no tile covers whole lines
+// whatever its width, and the wider halo only costs (8192^2, alignment 1, planned shapes, same box: step 0.836-0.845 ms with
+// 56 lanes against 0.808-0.813 with 62).
+static inline int sw_halo_lanes(int ld, std::initializer_list<const double *> arrays)
+{
+    bool lines = ld % 16 == 0;
+    for (const double *f : arrays) lines = lines && ((uintptr_t)f % 128 == 0);
+    return lines ? 4 : 1;
+}
 
 struct V2 {
     double x, y;
@@ -90,7 +99,7 @@ static inline int sw_nt_default(int ld, int y0, int y1)
 // rows are re-read by the tile below.
 template <int R, bool DPP, int NTM, bool SM = false>
 __device__ __forceinline__ void shallow_tile_body(
-    const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
+    const dlesm_sw_params &q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw, int hl,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
     typename OldLevel<SM>::ptr uold, typename OldLevel<SM>::ptr vold, typename OldLevel<SM>::ptr pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, unsigned block, int stack = 1,
@@ -115,11 +124,11 @@ __device__ __forceinline__ void shallow_tile_body(
     if (jb > y1) return;
     int je = jb + R - 1;
     if (je > y1) je = y1;
-    const int c = cb + xw * SW_OUT_LANES - SW_HALO_LANES + lane;             // this lane's chunk (2 columns)
-    if (c - lane + SW_HALO_LANES > x1 / 2) return;                 // idle padding tile
+    const int c = cb + xw * (64 - 2 * hl) - hl + lane;             // this lane's chunk (2 columns)
+    if (c - lane + hl > x1 / 2) return;                 // idle padding tile
     const int c_ld = ld / 2 - 1;
     const int cl = c < 0 ? 0 : (c > c_ld ? c_ld : c);  // halo / trailing lanes: any valid chunk
-    const bool out_lane = lane >= SW_HALO_LANES && lane < 64 - SW_HALO_LANES && c <= c_ld;
+    const bool out_lane = lane >= hl && lane < 64 - hl && c <= c_ld;
     const bool m0 = out_lane && 2 * c >= x0 && 2 * c <= x1;
     const bool m1 = out_lane && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
 
@@ -255,12 +264,12 @@ __device__ __forceinline__ void shallow_tile_body(
 
 template <int R, bool DPP, int NTM, bool SM = false>
 __global__ __launch_bounds__(512) void shallow_tile(
-    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw, int hl,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
     typename OldLevel<SM>::ptr uold, typename OldLevel<SM>::ptr vold, typename OldLevel<SM>::ptr pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, int stack, SwSmooth sm)
 {
-    shallow_tile_body<R, DPP, NTM, SM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, blockIdx.x, stack, sm);
+    shallow_tile_body<R, DPP, NTM, SM>(q, ld, x0, x1, y0, y1, cb, nxw, hl, u, v, p, uold, vold, pold, unew, vnew, pnew, blockIdx.x, stack, sm);
 }
 
 // The distributed shallow-water step in ONE launch on the caller's stream (as jacobi5_tile_framed): the
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(512) void shallow_tile(
 // tile sweep over the interior.
 template <int R, bool DPP, int NTM, bool SM = false>
 __global__ __launch_bounds__(512) void shallow_tile_framed(
-    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw, int hl,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
     typename OldLevel<SM>::ptr uold, typename OldLevel<SM>::ptr vold, typename OldLevel<SM>::ptr pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, SwFrameJob fj)
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
     if (blockIdx.x >= (unsigned)fj.nblocks) {
         const SwSmooth sm = fj.smooth ? SwSmooth{fj.alpha, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold)}
                                       : SwSmooth{0.0, nullptr, nullptr, nullptr};
-        shallow_tile_body<R, DPP, NTM, SM>(q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew,
+        shallow_tile_body<R, DPP, NTM, SM>(q, ld, x0, x1, y0, y1, cb, nxw, hl, u, v, p, uold, vold, pold, unew, vnew, pnew,
                                            blockIdx.x - fj.nblocks - fj.nunb, 1, sm);
         return;
     }
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(512) void shallow_tile_framed(
 // wrapped cells) without the two extra launches.
 template <int R, bool DPP, int NTM, bool SM = false>
 __global__ __launch_bounds__(512) void shallow_tile_sw(
-    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw,
+    dlesm_sw_params q, int ld, int x0, int x1, int y0, int y1, int cb, int nxw, int hl,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ p,
     typename OldLevel<SM>::ptr uold, typename OldLevel<SM>::ptr vold, typename OldLevel<SM>::ptr pold,
     double *__restrict__ unew, double *__restrict__ vnew, double *__restrict__ pnew, int wrap, SwSmooth sm)
@@ -427,11 +436,11 @@ __global__ __launch_bounds__(512) void shallow_tile_sw(
     if (jb > y1) return;
     int je = jb + R - 1;
     if (je > y1) je = y1;
-    const int c = cb + xw * SW_OUT_LANES - SW_HALO_LANES + lane;             // this lane's chunk (2 columns)
-    if (c - lane + SW_HALO_LANES > x1 / 2) return;                 // idle padding tile
+    const int c = cb + xw * (64 - 2 * hl) - hl + lane;             // this lane's chunk (2 columns)
+    if (c - lane + hl > x1 / 2) return;                 // idle padding tile
     const int c_ld = ld / 2 - 1;
     const int cl = c < 0 ? 0 : (c > c_ld ? c_ld : c);  // halo / trailing lanes: any valid chunk
-    const bool out_lane = lane >= SW_HALO_LANES && lane < 64 - SW_HALO_LANES && c <= c_ld;
+    const bool out_lane = lane >= hl && lane < 64 - hl && c <= c_ld;
     const bool m0 = out_lane && 2 * c >= x0 && 2 * c <= x1;
     const bool m1 = out_lane && 2 * c + 1 >= x0 && 2 * c + 1 <= x1;
 
@@ -581,23 +590,40 @@ static SwShape g_sw_override = {0, 0, 0};
 // Lanes west of x0 are masked.
 static inline int sw_first_chunk(int x0) { return (x0 / 2) & ~7; }
 
-static void sw_rule_shape(int ld, int x0, int x1, int *nxw_out, int *tpb_out)
+static void sw_rule_shape(int ld, int x0, int x1, int hl, int *nxw_out, int *tpb_out)
 {
-    const int cb = sw_first_chunk(x0), c_last = x1 / 2;
-    int nxw = (c_last - cb + SW_OUT_LANES) / SW_OUT_LANES, tpb = 4;          // output chunks per wave tile
-    // Exhaustive (waves per group, tiles per row) searches with the 56-lane tile at 2048^2 .. 12288^2 (round 4,
-    // scripts/shallow_shape_search.py, profiles/r04_shallow_shape_search.txt) show one pattern, the Jacobi sweep's: FOUR waves
-    // per group and a row of a QUARTER GROUP SHORT OF OR PAST a multiple of 8 groups -- 31 / 33, 63 / 65, 95 / 97 tiles --
-    // first or within 1 % of first at every size, idle padding tiles included (8192^2: 74 tiles padded to 95 = 23.75 groups
-    // 0.808 ms, unpadded 0.89; 4096^2: 37 -> 63 tiles; exactly 8k groups per row is the worst shape: 1.11 ms).  So: the
-    // smallest such row length that holds the box.  (The 62-lane tile of rounds 1-3 liked eight waves just above 8k groups.)
+    const int cb = sw_first_chunk(x0), c_last = x1 / 2, out_lanes = 64 - 2 * hl;
+    int nxw = (c_last - cb + out_lanes) / out_lanes, tpb = 4;          // output chunks per wave tile
     if (!tuning("j5_autoshape", 1) || tuning("j5_tpb", 0) || nxw < 16) {
         choose_block_shape(&nxw, &tpb);                  // experiments and thin boxes: the shared path
-    } else {
+    } else if (hl == 4) {
+        // Exhaustive (waves per group, tiles per row) searches with the 56-lane tile at 2048^2 .. 12288^2 (round 4,
+        // scripts/shallow_shape_search.py, profiles/r04_shallow_shape_search.txt) show one pattern, the Jacobi sweep's: FOUR waves
+        // per group and a row of a QUARTER GROUP SHORT OF OR PAST a multiple of 8 groups -- 31 / 33, 63 / 65, 95 / 97 tiles --
+        // first or within 1 % of first at every size, idle padding tiles included (8192^2: 74 tiles padded to 95 = 23.75 groups
+        // 0.808 ms, unpadded 0.89; 4096^2: 37 -> 63 tiles; exactly 8k groups per row is the worst shape: 1.11 ms).  So: the
+        // smallest such row length that holds the box.
         tpb = 4;
         const int below = (nxw + 1 + 31) / 32 * 32 - 1;  // smallest 32k - 1 >= nxw
         const int above = (nxw - 1 + 31) / 32 * 32 + 1;  // smallest 32k + 1 >= nxw
         nxw = below < above ? below : above;
+    } else {
+        // The 62-lane tile (rounds 1-3; still the form of odd pitches): an exhaustive search at 8192^2 (67 tiles per row) found 8
+        // waves per group JUST ABOVE a multiple of 8 groups best (67 tiles 0.844 ms, 68 0.846, 69 0.852), 4 waves at 23.75 groups
+        // equal, 15.75 groups per row 25 % slower.  So: the group size whose 8-group multiple lies closest below the row, no
+        // padding when the row is within 3/8 group past it, else padding up to the next multiple (+1 tile when on it exactly).
+        double best = 1e9;
+        int pad = 0;
+        for (int cand : {8, 4, 2}) {
+            const int period = 8 * cand, slack = 3 * cand / 8;
+            if (nxw < period) continue;
+            const int r = nxw % period, p = r <= slack ? 0 : period - r;
+            const double cost = (double)p / nxw + (cand == 8 ? 0.0 : cand == 4 ? 0.01 : 0.03);
+            if (cost < best) { best = cost; tpb = cand; pad = p; }
+        }
+        if (best > 0.25) { tpb = 4; pad = 0; }
+        nxw += pad;
+        if (nxw >= 128 && nxw % (8 * tpb) == 0) nxw += 1;
     }
     *nxw_out = nxw;
     *tpb_out = tpb;
@@ -609,15 +635,20 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
                          double *pnew, hipStream_t s, bool sw_offset, SwFrameJob *fj, int wrap, const double *smooth_alpha)
 {
     const int cb = sw_first_chunk(x0);
+    const int hl = sw_halo_lanes(ld, {u, v, p, uold, vold, pold, unew, vnew, pnew});
     int nxw, tpb, ntm = tuning("sw_nt", sw_nt_default(ld, y0, y1)) & (kLab ? 15 : 3);      // (bits 4, 8: experiments, lab build only)
     SwSmooth sm{0.0, nullptr, nullptr, nullptr};
     if (smooth_alpha) sm = SwSmooth{*smooth_alpha, const_cast<double *>(uold), const_cast<double *>(vold), const_cast<double *>(pold)};
     {
         std::lock_guard<std::mutex> lk(g_sw_mu);
-        auto it = g_sw_cache.find(SwKey{ld, x0, x1, y0, y1, sw_offset ? 1 : 0});
+        auto it = g_sw_cache.find(SwKey{ld, x0, x1, y0, y1, (sw_offset ? 1 : 0) | (hl << 1)});
         if (g_sw_override.tpb) { tpb = g_sw_override.tpb; nxw = g_sw_override.nxw; ntm = g_sw_override.ntm; }
         else if (it != g_sw_cache.end() && tuning("j5_use_tuned", 1)) { tpb = it->second.tpb; nxw = it->second.nxw; ntm = it->second.ntm; }
-        else sw_rule_shape(ld, x0, x1, &nxw, &tpb);
+        else sw_rule_shape(ld, x0, x1, hl, &nxw, &tpb);
+    }
+    {   // whatever chose the row length: it must hold the box
+        const int need = (x1 / 2 - cb + (64 - 2 * hl)) / (64 - 2 * hl);
+        if (nxw < need) nxw = need;
     }
     if (tpb > 8) tpb = 8;                                // the kernel is bounded to 512 threads
     // the old level updated in place: non-temporal stores want non-temporal loads of it too (the in-place finding of
@@ -645,7 +676,7 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
         fj->nblocks = (int)(nb < 8 ? 8 : nb > 512 ? 512 : nb);
         fj->nunb = fj->nun > 0 ? 16 : 0;                 // join workgroups of the peer transport (a multiple of 8)
         const unsigned g2 = grid + (unsigned)fj->nblocks + (unsigned)fj->nunb;
-#define DLESM_SWF(NN, SS) hipLaunchKernelGGL((shallow_tile_framed<2, true, NN, SS>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj)
+#define DLESM_SWF(NN, SS) hipLaunchKernelGGL((shallow_tile_framed<2, true, NN, SS>), dim3(g2), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, y1, cb, nxw, hl, u, v, p, uold, vold, pold, unew, vnew, pnew, *fj)
         if (sm.uo) {
             switch (ntm & 3) {
             case 1: DLESM_SWF(1, true); break;
@@ -669,10 +700,10 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     do {                                                                                                       \
         if (sw_offset)                                                                                         \
             hipLaunchKernelGGL((shallow_tile_sw<2, true, NN, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
-                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, wrap, sm);            \
+                               y1, cb, nxw, hl, u, v, p, uold, vold, pold, unew, vnew, pnew, wrap, sm);            \
         else                                                                                                   \
             hipLaunchKernelGGL((shallow_tile<2, true, NN, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
-                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, 1, sm);               \
+                               y1, cb, nxw, hl, u, v, p, uold, vold, pold, unew, vnew, pnew, 1, sm);               \
     } while (0)
         switch ((ntm == 10 || ntm == 11) ? ntm : (ntm & 3)) {
         case 1: DLESM_SWS(1); break;
@@ -691,10 +722,10 @@ void launch_shallow_tile(const dlesm_sw_params &q, int ld, int x0, int x1, int y
     do {                                                                                                       \
         if (sw_offset)                                                                                         \
             hipLaunchKernelGGL((shallow_tile_sw<RR, DD, NN>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
-                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, wrap, sm);            \
+                               y1, cb, nxw, hl, u, v, p, uold, vold, pold, unew, vnew, pnew, wrap, sm);            \
         else                                                                                                   \
             hipLaunchKernelGGL((shallow_tile<RR, DD, NN>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, x0, x1, y0, \
-                               y1, cb, nxw, u, v, p, uold, vold, pold, unew, vnew, pnew, stack, sm);           \
+                               y1, cb, nxw, hl, u, v, p, uold, vold, pold, unew, vnew, pnew, stack, sm);           \
     } while (0)
 #define DLESM_SW2(RR, DD)                                                                                      \
     do {                                                                                                       \
@@ -1028,7 +1059,8 @@ static int shallow_autotune(bool sw_offset, const dlesm_sw_params *q, int ld, in
     }
     if (xstop < xstart || ystop < ystart || tuning("sw_kernel", 0) != 0) return DLESM_OK;
     const int x0 = xstart - 1, x1 = xstop - 1, y0 = ystart - 1, y1 = ystop - 1;
-    const int nxw0 = (x1 / 2 - sw_first_chunk(x0) + SW_OUT_LANES) / SW_OUT_LANES;
+    const int hl = sw_halo_lanes(ld, {u, v, p, uold, vold, pold, (const double *)unew, (const double *)vnew, (const double *)pnew});
+    const int nxw0 = (x1 / 2 - sw_first_chunk(x0) + (64 - 2 * hl)) / (64 - 2 * hl);
     if (nxw0 < 16 || tuning("sw_tile_rows", 2) != 2) return DLESM_OK;      // thin boxes: nothing to choose
     hipStream_t s = (hipStream_t)stream;
     std::vector<SwShape> cand;
@@ -1038,7 +1070,7 @@ static int shallow_autotune(bool sw_offset, const dlesm_sw_params *q, int ld, in
         cand.push_back(SwShape{tpb, t, ntm});
     };
     int rn, rt;
-    sw_rule_shape(ld, x0, x1, &rn, &rt);
+    sw_rule_shape(ld, x0, x1, hl, &rn, &rt);
     if (rt > 8) rt = 8;
     const int nt0 = tuning("sw_nt", sw_nt_default(ld, y0, y1)) & 3;
     add(rt, rn, nt0);                                                      // the rule's own choice first
@@ -1097,7 +1129,7 @@ static int shallow_autotune(bool sw_offset, const dlesm_sw_params *q, int ld, in
     (void)hipEventDestroy(e1);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_sw_mu);
-    g_sw_cache[SwKey{ld, x0, x1, y0, y1, sw_offset ? 1 : 0}] = best;
+    g_sw_cache[SwKey{ld, x0, x1, y0, y1, (sw_offset ? 1 : 0) | (hl << 1)}] = best;
     return DLESM_OK;
 }
 

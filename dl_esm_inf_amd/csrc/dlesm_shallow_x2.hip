@@ -410,7 +410,12 @@ static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int 
         stack = tuning("sw_x2_stack", 4);
         pad = tuning("sw_x2_pad", 0);
     }
-    const int out_lanes = (!alpha && R == 4) ? 56 : 62;      // (the four-row plain form: whole-line tiles, HL = 4)
+    // the four-row plain form on whole-line tiles (HL = 4) when every row of every array starts on a 128-byte line
+    bool lines = ld % 16 == 0;
+    for (const double *f : {a.u, a.v, a.p, a.uo, a.vo, a.po, (const double *)a.u1, (const double *)a.v1, (const double *)a.p1,
+                            (const double *)a.u2, (const double *)a.v2, (const double *)a.p2})
+        lines = lines && ((uintptr_t)f % 128 == 0);
+    const int out_lanes = (!alpha && R == 4 && lines) ? 56 : 62;
     int nxw = (x1 / 2 - cb + out_lanes) / out_lanes, tpb = 4;
     if (stack) {
         nxw += pad;
@@ -425,7 +430,8 @@ static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int 
 #define DLESM_X2(RR, NN)                                                                                                                                  \
     do {                                                                                                                                                  \
         if (alpha) hipLaunchKernelGGL((shallow_tile_x2<RR, NN, true>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al); \
-        else hipLaunchKernelGGL((shallow_tile_x2<RR, NN, false, 1, (RR == 4 ? 4 : 1)>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al); \
+        else if (RR == 4 && lines) hipLaunchKernelGGL((shallow_tile_x2<RR, NN, false, 1, (RR == 4 ? 4 : 1)>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al); \
+        else hipLaunchKernelGGL((shallow_tile_x2<RR, NN, false, 1, 1>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al); \
     } while (0)
 #ifdef DLESM_LAB
 #define DLESM_X2R(RR)                                                                                                  \
@@ -439,7 +445,8 @@ static void launch_x2(const dlesm_sw_params &q, int ld, int ny, int xstart, int 
 #else
     (void)nt;
     if (alpha) hipLaunchKernelGGL((shallow_tile_x2<3, 2, true, 2>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
-    else hipLaunchKernelGGL((shallow_tile_x2<4, 2, false, 1, 4>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
+    else if (lines) hipLaunchKernelGGL((shallow_tile_x2<4, 2, false, 1, 4>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
+    else hipLaunchKernelGGL((shallow_tile_x2<4, 2, false, 1, 1>), dim3(grid), dim3(64 * tpb), 0, s, q, ld, ny, x0, x1, y0, y1, cb, nxw, stack, a, al);
 #endif
 #undef DLESM_X2
 }
