@@ -352,3 +352,131 @@ def _filtered_periodic(D, nx, ny, alignment, fallback, sw_form):
         L.dlesm_set_tuning(b"sw_x2_fused", 1)
         if sw_form:
             L.dlesm_set_tuning(b"sw_x2_sw_form", 0)
+
+
+# ---- IEEE special values: subnormals, signed zeros, overflow, infinities, NaN, a zero denominator in z ---------------------------
+def _special_fields(D, g):
+    """twelve fields with patches of special values in levels n and n-1 (the ring of every level the same, as _fields)"""
+    F = _fields(D, g, SEED + 300)
+    rng = np.random.default_rng(11)
+    H = {n: F[n].get_data() for n in NAMES[:6]}
+    for n in NAMES[:6]:
+        h = H[n]
+        h[6:12, 10:40] = rng.random((6, 30)) * 1e-310          # subnormals
+        h[14:17, 20:50] = -0.0
+        h[14:17, 50:80] = 0.0
+        h[20:23, 30:60] = (1.6e308 if n[0] != "v" else -1.6e308)   # products and sums overflow
+        h[30:34, 40:100] = np.ldexp(rng.random((4, 60)), -1060)  # results cross the subnormal boundary
+    H["p"][26:29, 20:60] = 0.0                                  # p + p + p + p = 0 under z: x / 0
+    H["u"][38, 30] = np.inf
+    H["v"][38, 70] = -np.inf
+    H["pold"][40, 50] = np.nan
+    for n in NAMES[:6]:
+        F[n].set_data(H[n])
+    it = F["p"].internal
+    for k, n in enumerate(NAMES[6:]):                           # every level carries the ring of level n
+        D.copy_field(F[NAMES[k % 3]], F[n])
+    for k, n in enumerate(NAMES[3:6]):
+        keep = F[n].data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop].clone()
+        D.copy_field(F[NAMES[k]], F[n])
+        F[n].data[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop] = keep
+    return F
+
+
+def _same_ieee(got, want, what):
+    nan_w, nan_g = np.isnan(want), np.isnan(got)
+    assert np.array_equal(nan_w, nan_g), (what, "NaN positions differ", int(np.count_nonzero(nan_w != nan_g)))
+    a, b = got[~nan_w].view(np.uint64), want[~nan_w].view(np.uint64)
+    assert np.array_equal(a, b), (what, int(np.count_nonzero(a != b)))
+
+
+def test_special_values_follow_ieee_like_the_cpu(D):
+    """the fused step, the two-step kernel and the filtered two-step kernel on inputs with subnormals (not flushed), signed
+    zeros, overflow, infinities, NaN and a zero denominator: bit-identical to the oracle's loops wherever the result is not a NaN,
+    NaN exactly where the oracle has one (the first stage's redundant rim evaluates the same operations on the same operands)"""
+    import torch
+    g = _grid(D, 140, 48, 8)
+    prm = D.psy.shallow_params(1.0e5, 0.9e5, 40.0)
+    F = _special_fields(D, g)
+    it = F["p"].internal
+    box = it.box()
+    H = {n: F[n].get_data() for n in NAMES}
+    with np.errstate(all="ignore"):
+        n1, n2 = _oracle_two_steps(prm, g, box, H)
+    D.psy.invoke_shallow_step_x2(prm, *[F[n] for n in NAMES])
+    torch.cuda.synchronize()
+    for name, want in zip(NAMES[6:], n1 + n2):
+        _same_ieee(F[name].get_data(), want, "two steps: " + name)
+    assert sum(int(np.count_nonzero(np.isnan(w))) for w in n2) > 0 and sum(int(np.count_nonzero(np.isinf(w))) for w in n1) > 0
+    sub = sum(int(np.count_nonzero((np.abs(w) > 0) & (np.abs(w) < 2.3e-308))) for w in n1 + n2)
+    assert sub > 50, sub                                        # subnormal results really occur
+    # one step, for the record of the single-step kernel
+    G = _special_fields(D, g)
+    D.psy.invoke_shallow_step(prm, *[G[n] for n in NAMES[:9]])
+    torch.cuda.synchronize()
+    for name, want in zip(NAMES[6:9], n1):
+        _same_ieee(G[name].get_data(), want, "one step: " + name)
+    # two filtered steps per launch against two one-launch filtered steps (each checked against the oracle's loop nests elsewhere)
+    A, B = _special_fields(D, g), _special_fields(D, g)
+    a_cur, a_old, a_n2, a_o2 = ([A[n] for n in NAMES[k:k + 3]] for k in (0, 3, 6, 9))
+    for src, dst in zip(a_cur, a_o2):
+        D.copy_field(src, dst)
+    b_cur, b_old, b_new = ([B[n] for n in NAMES[k:k + 3]] for k in (0, 3, 6))
+    D.psy.invoke_shallow_step_smooth_x2(prm, 0.001, *a_cur, *a_old, *a_n2, *a_o2)
+    for _ in range(2):
+        D.psy.invoke_shallow_step_smooth(prm, 0.001, *b_cur, *b_old, *b_new)
+        b_cur, b_new = b_new, b_cur
+    torch.cuda.synchronize()
+    cut = lambda f: f.get_data()[it.ystart - 1:it.ystop, it.xstart - 1:it.xstop]      # noqa: E731
+    for x, y, name in zip(a_n2 + a_o2, b_cur + b_old, NAMES[6:]):
+        _same_ieee(cut(x), cut(y), "two filtered steps: " + name)
+
+
+def test_special_values_in_the_periodic_model(D):
+    """the same for the SW-offset doubly periodic kernels (their own expression trees): one-launch step and two steps per launch
+    against the oracle's model of the loop (step + the reference's periodic copies), halos included"""
+    import torch
+    g = _grid_sw(D, 130, 44, 8)
+    prm = D.psy.shallow_params(1.0e5, 0.9e5, 40.0)
+    F = _periodic_fields(D, g, SEED + 310)
+    it = F["p"].internal
+    rng = np.random.default_rng(12)
+    for n in NAMES[:6]:
+        h = F[n].get_data()
+        h[6:12, 10:40] = rng.random((6, 30)) * 1e-310
+        h[14:17, 20:50] = -0.0
+        h[20:23, 30:60] = (1.6e308 if n[0] != "v" else -1.6e308)
+        h[30:34, 40:100] = np.ldexp(rng.random((4, 60)), -1060)
+        if n == "p":
+            h[26:29, 20:60] = 0.0
+        if n == "u":
+            h[38, 30] = np.inf
+        if n == "pold":
+            h[40, 50] = np.nan
+        F[n].set_data(h)
+        D.psy.apply_periodic_halos(F[n])
+    torch.cuda.synchronize()
+    H = {n: F[n].get_data() for n in NAMES}
+    n1 = [H[n].copy() for n in NAMES[6:9]]
+    n2 = [H[n].copy() for n in NAMES[9:]]
+    with np.errstate(all="ignore"):
+        O.sw_step_sw(prm, g.nx, it.box(), H["u"], H["v"], H["p"], H["uold"], H["vold"], H["pold"], *n1)
+        for f in n1:
+            O.apply_periodic_halos(f, g.nx, it.box(), 0, 0)
+        O.sw_step_sw(prm, g.nx, it.box(), *n1, H["u"], H["v"], H["p"], *n2)
+        for f in n2:
+            O.apply_periodic_halos(f, g.nx, it.box(), 0, 0)
+    D.psy.invoke_shallow_step_sw_x2_periodic(prm, *[F[n] for n in NAMES])
+    torch.cuda.synchronize()
+    for name, want in zip(NAMES[6:], n1 + n2):
+        got = F[name].get_data()
+        _same_ieee(got[:it.ystop + 1, :it.xstop + 1], want[:it.ystop + 1, :it.xstop + 1], "periodic two steps: " + name)
+    assert sum(int(np.count_nonzero(np.isnan(w))) for w in n2) > 0
+    G = _periodic_fields(D, g, SEED + 310)
+    for n in NAMES[:6]:
+        G[n].set_data(H[n])
+    D.psy.invoke_shallow_step_sw_periodic(prm, *[G[n] for n in NAMES[:9]])
+    torch.cuda.synchronize()
+    for name, want in zip(NAMES[6:9], n1):
+        got = G[name].get_data()
+        _same_ieee(got[:it.ystop + 1, :it.xstop + 1], want[:it.ystop + 1, :it.xstop + 1], "periodic one step: " + name)
