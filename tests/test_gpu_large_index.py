@@ -89,3 +89,30 @@ def test_shallow_step_beyond_2_31_elements(T):
         assert bool((outs[k][0] == 9.0).all()) and bool((outs[k][N + 1:] == 9.0).all())
     del ins, outs
     torch.cuda.empty_cache()
+
+
+def test_utility_sweeps_beyond_2_31_elements(T):
+    """fill, hash_init, copy_patch and the checksum on a box of more than 2^31 cells: the checksum of a constant field is exact
+    (value x cells, a power-of-two-friendly value), hash_init equals its small-array self on row bands, the patch copy moves the
+    last rows intact"""
+    torch, D, L = T
+    f = torch.full((NY, LD), -1.0, dtype=torch.float64, device="cuda")
+    D._cabi.check(L.dlesm_fill_f64(_ptr(f), LD, NY, 1, LD, 1, NY, C.c_double(0.5), None))
+    res = C.c_double(0.0)
+    D._cabi.check(L.dlesm_checksum_f64(_ptr(f), LD, NY, 1, LD, 1, NY, C.byref(res), None))
+    assert res.value == 0.5 * LD * NY, (res.value, 0.5 * LD * NY)          # exact: every partial sum is a multiple of 0.5 below 2^53
+    D._cabi.check(L.dlesm_hash_init_f64(_ptr(f), LD, NY, 2, N + 1, 2, N + 1, C.c_uint64(99), C.c_int64(1), C.c_int64(1), None))
+    torch.cuda.synchronize()
+    for r in _bands():
+        lo, hi = max(r, 1), min(r + 5, N + 1)            # rows of the band inside the box (0-based lo .. hi-1)
+        s = torch.full((hi - lo, LD), 0.5, dtype=torch.float64, device="cuda")
+        # the same cells as a small array: global row offset = lo (the hash takes global indices)
+        D._cabi.check(L.dlesm_hash_init_f64(_ptr(s), LD, hi - lo, 2, N + 1, 1, hi - lo, C.c_uint64(99), C.c_int64(1), C.c_int64(lo + 1), None))
+        torch.cuda.synchronize()
+        assert torch.equal(f[lo:hi], s), r
+    g = torch.zeros((NY, LD), dtype=torch.float64, device="cuda")
+    D._cabi.check(L.dlesm_copy_patch_f64(_ptr(f), _ptr(g), LD, NY, 2, N - 2, 2, N - 2, N, 4, None))      # the last four rows of the box
+    torch.cuda.synchronize()
+    assert torch.equal(g[N - 3:N + 1, 1:N + 1], f[N - 3:N + 1, 1:N + 1]) and float(g[:N - 3].abs().sum()) == 0.0
+    del f, g
+    torch.cuda.empty_cache()
